@@ -1,0 +1,187 @@
+"""Seeded synthetic weights and inputs (there are no checkpoints, tokenizer or videos offline).
+
+State-dict names are the reference's (observed by instantiating
+internvl/model/internvl_chat_eval2/modeling_internvl_chat.py:195-273).  Initialisers follow the
+reference where it defines them: Linear/Embedding ~ N(0, 0.02²) (internlm2/modeling_internlm2.py:728-737),
+norm weights 1, biases 0, layer-scale = initializer_factor (modeling_intern_vit.py:211-212),
+score head U(-0.15, 0.15) (modeling_internvl_chat.py:74).  ``rich=True`` perturbs every bias / norm
+weight / layer-scale so that parity tests exercise those terms, and calibrates the last score layer so
+``score1`` lands in the trained range (0, 1) instead of being ReLU-clamped to 0 half of the time.
+
+The canonical token layout is SURVEY.md §8d / Appendix A:  N = 73 + (7 + tokens_per_frame) * T.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .config import InternVLChatConfig
+
+
+def special_ids(vocab_size: int) -> Dict[str, int]:
+    """<|im_end|>, <|im_start|>, <img>, </img>, <IMG_CONTEXT> = V-11 … V-7.
+
+    For V = 92553 this gives 92542 … 92546, the reference's ids
+    (conversation.py:381-385, stage2_eval.py:755-759)."""
+    return {"im_end": vocab_size - 11, "im_start": vocab_size - 10, "img": vocab_size - 9,
+            "img_end": vocab_size - 8, "img_context": vocab_size - 7}
+
+
+def weight_shapes(cfg: InternVLChatConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(name, shape, kind) in a fixed order. kind ∈ linear|embed|norm_w|bias|ls|cls|pos|score_w|score_b."""
+    v, l = cfg.vision_config, cfg.llm_config
+    Hv, Iv, P = v.hidden_size, v.intermediate_size, v.patch_size
+    npos = (v.image_size // P) ** 2 + 1
+    out: List[Tuple[str, Tuple[int, ...], str]] = []
+    e = "vision_model.embeddings."
+    out += [(e + "class_embedding", (1, 1, Hv), "cls"),
+            (e + "position_embedding", (1, npos, Hv), "pos"),
+            (e + "patch_embedding.weight", (Hv, v.num_channels, P, P), "linear"),
+            (e + "patch_embedding.bias", (Hv,), "bias")]
+    for i in range(v.num_hidden_layers):
+        p = f"vision_model.encoder.layers.{i}."
+        out += [(p + "ls1", (Hv,), "ls"), (p + "ls2", (Hv,), "ls"),
+                (p + "attn.qkv.weight", (3 * Hv, Hv), "linear")]
+        if v.qkv_bias:
+            out += [(p + "attn.qkv.bias", (3 * Hv,), "bias")]
+        if v.qk_normalization:
+            out += [(p + "attn.q_norm.weight", (Hv,), "norm_w"), (p + "attn.k_norm.weight", (Hv,), "norm_w")]
+        out += [(p + "attn.proj.weight", (Hv, Hv), "linear"), (p + "attn.proj.bias", (Hv,), "bias"),
+                (p + "mlp.fc1.weight", (Iv, Hv), "linear"), (p + "mlp.fc1.bias", (Iv,), "bias"),
+                (p + "mlp.fc2.weight", (Hv, Iv), "linear"), (p + "mlp.fc2.bias", (Hv,), "bias"),
+                (p + "norm1.weight", (Hv,), "norm_w"), (p + "norm2.weight", (Hv,), "norm_w")]
+        if v.norm_type == "layer_norm":
+            out += [(p + "norm1.bias", (Hv,), "bias"), (p + "norm2.bias", (Hv,), "bias")]
+    H, I, V = l.hidden_size, l.intermediate_size, l.vocab_size
+    d = l.head_dim
+    qkv_out = (l.num_attention_heads + 2 * l.num_key_value_heads) * d
+    out += [("language_model.model.tok_embeddings.weight", (V, H), "embed")]
+    for i in range(l.num_hidden_layers):
+        p = f"language_model.model.layers.{i}."
+        out += [(p + "attention.wqkv.weight", (qkv_out, H), "linear"),
+                (p + "attention.wo.weight", (H, l.num_attention_heads * d), "linear"),
+                (p + "feed_forward.w1.weight", (I, H), "linear"),
+                (p + "feed_forward.w3.weight", (I, H), "linear"),
+                (p + "feed_forward.w2.weight", (H, I), "linear"),
+                (p + "attention_norm.weight", (H,), "norm_w"),
+                (p + "ffn_norm.weight", (H,), "norm_w")]
+    out += [("language_model.model.norm.weight", (H,), "norm_w"),
+            ("language_model.output.weight", (V, H), "linear")]
+    Pin = cfg.proj_in
+    out += [("mlp1.0.weight", (Pin,), "norm_w"), ("mlp1.0.bias", (Pin,), "bias"),
+            ("mlp1.1.weight", (H, Pin), "linear"), ("mlp1.1.bias", (H,), "bias"),
+            ("mlp1.3.weight", (H, H), "linear"), ("mlp1.3.bias", (H,), "bias")]
+    M = cfg.motion_dim
+    out += [("motion_mlp.0.weight", (M,), "norm_w"), ("motion_mlp.0.bias", (M,), "bias"),
+            ("motion_mlp.1.weight", (H, M), "linear"), ("motion_mlp.1.bias", (H,), "bias"),
+            ("motion_mlp.3.weight", (H, H), "linear"), ("motion_mlp.3.bias", (H,), "bias")]
+    dims = (H,) + tuple(cfg.score_dims)
+    for j in range(len(cfg.score_dims)):
+        out += [(f"mlpscore.fc{j + 1}.weight", (dims[j + 1], dims[j]), "score_w"),
+                (f"mlpscore.fc{j + 1}.bias", (dims[j + 1],), "score_b")]
+    # mlpscore.ln1 exists in the reference state-dict but is unused (modeling_internvl_chat.py:55,85)
+    out += [("mlpscore.ln1.weight", (cfg.score_dims[0],), "norm_w"), ("mlpscore.ln1.bias", (cfg.score_dims[0],), "bias")]
+    return out
+
+
+def make_state_dict(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16, device="cpu",
+                    rich: bool = False) -> Dict[str, torch.Tensor]:
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    n_score = len(cfg.score_dims)
+
+    def randn(shape, std):
+        return torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std
+
+    def rand(shape, lo, hi):
+        return torch.rand(shape, generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
+
+    for name, shape, kind in weight_shapes(cfg):
+        if kind in ("linear", "embed"):
+            if device != "cpu" and len(shape) == 2 and shape[0] * shape[1] > (1 << 26):
+                # large matrices on the GPU: generate directly in the target dtype, row-chunked
+                t = torch.empty(shape, dtype=dtype, device=device)
+                step = max(1, (1 << 26) // shape[1])
+                for r in range(0, shape[0], step):
+                    t[r:r + step] = (torch.randn((min(step, shape[0] - r), shape[1]), generator=g,
+                                                 device=device, dtype=torch.float32) * 0.02).to(dtype)
+                sd[name] = t
+                continue
+            t = randn(shape, 0.02)
+        elif kind in ("cls", "pos"):
+            t = randn(shape, 0.02 if not rich else 0.1)
+        elif kind == "norm_w":
+            t = torch.ones(shape, device=device) if not rich else 1.0 + randn(shape, 0.1)
+        elif kind == "bias":
+            t = torch.zeros(shape, device=device) if not rich else randn(shape, 0.02)
+        elif kind == "ls":
+            t = torch.full(shape, cfg.vision_config.initializer_factor, device=device) if not rich \
+                else rand(shape, 0.5, 1.5)
+        elif kind == "score_w":
+            t = rand(shape, -0.15, 0.15)
+            if rich and name == f"mlpscore.fc{n_score}.weight":
+                t = t * 0.05
+        elif kind == "score_b":
+            t = torch.zeros(shape, device=device)
+            if rich:
+                t = randn(shape, 0.02)
+                if name == f"mlpscore.fc{n_score}.bias":
+                    t = torch.full(shape, 0.6, device=device)
+        else:
+            raise AssertionError(kind)
+        sd[name] = t.to(dtype)
+    return sd
+
+
+def canonical_tokens(cfg: InternVLChatConfig, n_clips: int, n_frames: int, seed: int = 0,
+                     answer_len: int = 9) -> Dict[str, torch.Tensor]:
+    """input_ids / labels / attention_mask in the canonical layout of SURVEY.md §8d."""
+    V = cfg.llm_config.vocab_size
+    sp = special_ids(V)
+    hi = max(4, min(V - 553, sp["im_end"]) if V > 2000 else sp["im_end"])
+    g = torch.Generator().manual_seed(1000 + seed)
+
+    def text(n):
+        return torch.randint(3, hi, (n,), generator=g).tolist()
+
+    ntok = cfg.num_image_token
+    rows, labs = [], []
+    for _ in range(n_clips):
+        ids: List[int] = text(40)
+        for _f in range(n_frames):
+            ids += text(4) + [sp["img"]] + [sp["img_context"]] * ntok + [sp["img_end"]] + text(1)
+        ids += text(4) + [sp["img"]] + [sp["img_context"]] + [sp["img_end"]]
+        ids += text(16)
+        n_prompt = len(ids)
+        ans = text(answer_len) + [sp["im_end"]]
+        ids += ans
+        lab = [-100] * n_prompt + ans
+        rows.append(ids)
+        labs.append(lab)
+    input_ids = torch.tensor(rows, dtype=torch.long)
+    labels = torch.tensor(labs, dtype=torch.long)
+    return {"input_ids": input_ids, "labels": labels,
+            "attention_mask": torch.ones_like(input_ids, dtype=torch.bool),
+            "img_context_token_id": sp["img_context"], "im_end_id": sp["im_end"]}
+
+
+def canonical_len(cfg: InternVLChatConfig, n_frames: int, answer_len: int = 9) -> int:
+    return 40 + n_frames * (7 + cfg.num_image_token) + 7 + 16 + answer_len + 1
+
+
+def synthetic_frames(n_frames_total: int, image_size: int, seed: int = 0, dtype=torch.bfloat16,
+                     device="cpu") -> torch.Tensor:
+    """pixel_values ~ N(0,1) clipped to ±2.5 (≈ ImageNet-normalised range), NCHW."""
+    g = torch.Generator(device=device).manual_seed(1234 + seed)
+    x = torch.randn((n_frames_total, 3, image_size, image_size), generator=g, device=device,
+                    dtype=torch.float32).clamp_(-2.5, 2.5)
+    return x.to(dtype)
+
+
+def synthetic_motion(n_clips: int, motion_dim: int, seed: int = 0, dtype=torch.bfloat16,
+                     device="cpu") -> torch.Tensor:
+    """SlowFast feature stand-in (the SlowFast branch is an INPUT: SURVEY.md §2 row 6)."""
+    g = torch.Generator(device=device).manual_seed(4321 + seed)
+    return torch.rand((n_clips, motion_dim), generator=g, device=device, dtype=torch.float32).to(dtype)
