@@ -1,0 +1,861 @@
+// C ABI (include/aigv_amd.h) over the gfx950 kernels: context, weight store, workspaces and the
+// orchestration of the scorer hot path.  Host-side C++ only; every device op is one of the hand-written
+// kernels in gemm.hip / attention.hip / rowops.hip / head.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/aigv_amd.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct VitLayer {
+  const bf16_t *ls1, *ls2, *qkv_w, *qkv_b, *qn, *kn, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *n1w, *n1b, *n2w, *n2b;
+};
+struct LlmLayer {
+  const bf16_t *wqkv, *wo, *w13, *w2, *an, *fn;
+};
+
+struct ProfRec {
+  int cls;
+  hipEvent_t a, b;
+  double flops, bytes;
+};
+
+}  // namespace
+
+struct aigv_ctx {
+  aigv_config cfg{};
+  int device = 0;
+  std::string err;
+  std::unordered_map<std::string, DevBuf> w;
+  std::vector<void*> allocs;
+  bool finalized = false;
+  // derived sizes
+  int np = 0, S = 0, Kp = 0, grid = 0, ntok = 0, proj_in = 0, qkv_out = 0, head_dim = 0, vit_head_dim = 0, g = 0;
+  // derived weights
+  std::vector<VitLayer> vit;
+  std::vector<LlmLayer> llm;
+  const bf16_t *patch_w = nullptr, *patch_b = nullptr, *pos = nullptr, *cls_pos = nullptr;
+  const bf16_t *tok_emb = nullptr, *final_norm = nullptr, *lm_head = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+  const bf16_t *p_ln_w[2] = {nullptr, nullptr}, *p_ln_b[2] = {nullptr, nullptr}, *p_w1[2] = {nullptr, nullptr},
+               *p_b1[2] = {nullptr, nullptr}, *p_w2[2] = {nullptr, nullptr}, *p_b2[2] = {nullptr, nullptr};  // 0 mlp1, 1 motion_mlp
+  ScoreHeadArgs score{};
+  // workspaces
+  bf16_t *v_col = nullptr, *v_x = nullptr, *v_t = nullptr, *v_qkv = nullptr, *v_ao = nullptr, *v_h = nullptr;
+  int32_t* v_cu = nullptr;
+  bf16_t *p_t = nullptr, *p_mid = nullptr;
+  bf16_t *l_h = nullptr, *l_t = nullptr, *l_qkv = nullptr, *l_ao = nullptr, *l_ffn = nullptr, *l_rows = nullptr;
+  int32_t *l_pos = nullptr, *l_seq = nullptr, *l_cu = nullptr, *l_rowidx = nullptr, *l_kvlen = nullptr;
+  unsigned long long* l_packed = nullptr;
+  bf16_t *kc = nullptr, *vc = nullptr;   // [layer][seq][kv head][cap][D]
+  std::vector<int32_t> h_pos, h_seq, h_rowidx, h_kvlen;
+  int kv_seqs = 0;
+  bool kv_valid = false;
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(aigv_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess) return fail(c, AIGV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define TRY(x)            \
+  do {                    \
+    int r_ = (x);         \
+    if (r_ != 0) return r_; \
+  } while (0)
+
+template <typename T>
+int dalloc(aigv_ctx* c, T** out, size_t count) {
+  void* p = nullptr;
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(c, AIGV_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  e = hipMemset(p, 0, bytes);
+  if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+  c->allocs.push_back(p);
+  *out = (T*)p;
+  return 0;
+}
+
+inline uint16_t f32_to_bf16_host(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32_host(uint16_t v) {
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- profiling brackets --------------------------------------------------------------------------------
+hipEvent_t get_event(aigv_ctx* c) {
+  if (!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+struct ProfScope {
+  aigv_ctx* c;
+  hipStream_t s;
+  ProfRec r{};
+  bool on;
+  ProfScope(aigv_ctx* c_, int cls, double flops, double bytes, hipStream_t s_) : c(c_), s(s_), on(c_ && c_->prof) {
+    if (!on) return;
+    r.cls = cls; r.flops = flops; r.bytes = bytes;
+    r.a = get_event(c); r.b = get_event(c);
+    if (!r.a || !r.b) { on = false; return; }
+    hipEventRecord(r.a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(r.b, s);
+    c->recs.push_back(r);
+  }
+};
+
+int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
+  if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
+  ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * a.M * (double)a.N * a.K,
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N), s);
+  HIPCHK(c, aigv_launch_gemm(a, epi, s));
+  return 0;
+}
+
+GemmArgs gemm_args(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C, int ldc, int M, int N, int K) {
+  GemmArgs a{};
+  a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  return a;
+}
+
+int run_skinny(aigv_ctx* c, const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
+               const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi, hipStream_t s) {
+  ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * R * (double)N * K, 2.0 * (double)N * K, s);
+  hipError_t e = aigv_launch_skinny_gemm(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, epi, s);
+  if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP,
+                                   "skinny gemm (R=%d N=%d K=%d epi=%d): %s", R, N, K, epi, hipGetErrorString(e));
+  return 0;
+}
+
+const bf16_t* W(aigv_ctx* c, const std::string& name) {
+  auto it = c->w.find(name);
+  return it == c->w.end() ? nullptr : (const bf16_t*)it->second.p;
+}
+
+int need(aigv_ctx* c, const std::string& name, size_t elems, const bf16_t** out) {
+  auto it = c->w.find(name);
+  if (it == c->w.end()) return fail(c, AIGV_ERR_STATE, "weight '%s' was never loaded", name.c_str());
+  if (it->second.bytes != elems * 2)
+    return fail(c, AIGV_ERR_STATE, "weight '%s' has %zu elements, expected %zu", name.c_str(), it->second.bytes / 2, elems);
+  *out = (const bf16_t*)it->second.p;
+  return 0;
+}
+
+}  // namespace
+
+// ==========================================================================================================
+extern "C" {
+
+int aigv_abi_version(void) { return AIGV_ABI_VERSION; }
+int aigv_sizeof_config(void) { return (int)sizeof(aigv_config); }
+
+const char* aigv_last_error(const aigv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, AIGV_ERR_ARG, "aigv_ctx_create: null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, AIGV_ERR_HIP, "aigv_ctx_create: no HIP device is visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, AIGV_ERR_ARG, "aigv_ctx_create: device %d out of range (%d visible)", device, ndev);
+  const aigv_config& k = *cfg;
+  // ---- shape constraints of the kernels ----
+  if (k.vit_hidden <= 0 || k.vit_heads <= 0 || k.vit_hidden % k.vit_heads) return fail(nullptr, AIGV_ERR_ARG, "bad ViT head split");
+  if (k.vit_hidden / k.vit_heads != 64 && k.vit_hidden / k.vit_heads != 128)
+    return fail(nullptr, AIGV_ERR_ARG, "ViT head_dim %d not supported (64 or 128)", k.vit_hidden / k.vit_heads);
+  if (k.llm_hidden <= 0 || k.llm_heads <= 0 || k.llm_hidden % k.llm_heads || k.llm_hidden / k.llm_heads != 128)
+    return fail(nullptr, AIGV_ERR_ARG, "LLM head_dim must be 128");
+  if (k.llm_kv_heads <= 0 || k.llm_heads % k.llm_kv_heads) return fail(nullptr, AIGV_ERR_ARG, "bad GQA split");
+  if (k.vit_hidden % 128 || k.vit_inter % 128 || k.llm_hidden % 128 || k.llm_inter % 128)
+    return fail(nullptr, AIGV_ERR_ARG, "hidden/intermediate sizes must be multiples of 128");
+  if (k.image_size % k.patch_size || k.shuffle != 2 || ((k.image_size / k.patch_size) % 2))
+    return fail(nullptr, AIGV_ERR_ARG, "image/patch/shuffle combination not supported");
+  if (k.motion_dim % 128) return fail(nullptr, AIGV_ERR_ARG, "motion_dim must be a multiple of 128");
+  if (k.n_score_layers < 1 || k.n_score_layers > 8) return fail(nullptr, AIGV_ERR_ARG, "n_score_layers out of range");
+  if (k.max_frames <= 0 || k.vit_chunk <= 0 || k.max_tokens <= 0 || k.max_seqs <= 0 || k.max_out_rows <= 0)
+    return fail(nullptr, AIGV_ERR_ARG, "capacities must be positive");
+
+  aigv_ctx* c = new (std::nothrow) aigv_ctx();
+  if (!c) return fail(nullptr, AIGV_ERR_ALLOC, "out of host memory");
+  c->cfg = k;
+  c->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) { delete c; return fail(nullptr, AIGV_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e)); }
+  c->grid = k.image_size / k.patch_size;
+  c->np = c->grid * c->grid;
+  c->S = c->np + 1;
+  c->Kp = roundup(k.num_channels * k.patch_size * k.patch_size, 64);
+  c->ntok = c->np / (k.shuffle * k.shuffle);
+  c->proj_in = k.vit_hidden * k.shuffle * k.shuffle;
+  c->head_dim = k.llm_hidden / k.llm_heads;
+  c->vit_head_dim = k.vit_hidden / k.vit_heads;
+  c->g = k.llm_heads / k.llm_kv_heads;
+  c->qkv_out = (k.llm_heads + 2 * k.llm_kv_heads) * c->head_dim;
+
+  int rc = 0;
+  const size_t vr = (size_t)k.vit_chunk * c->S;
+  const size_t pr = (size_t)k.vit_chunk * c->ntok;
+  const size_t T = (size_t)k.max_tokens;
+  do {
+    if ((rc = dalloc(c, &c->v_col, (size_t)k.vit_chunk * c->np * c->Kp))) break;
+    if ((rc = dalloc(c, &c->v_x, vr * k.vit_hidden))) break;
+    if ((rc = dalloc(c, &c->v_t, vr * k.vit_hidden))) break;
+    if ((rc = dalloc(c, &c->v_qkv, vr * 3 * k.vit_hidden))) break;
+    if ((rc = dalloc(c, &c->v_ao, vr * k.vit_hidden))) break;
+    if ((rc = dalloc(c, &c->v_h, vr * k.vit_inter))) break;
+    if ((rc = dalloc(c, &c->v_cu, (size_t)k.vit_chunk + 1))) break;
+    if ((rc = dalloc(c, &c->p_t, pr * c->proj_in))) break;
+    if ((rc = dalloc(c, &c->p_mid, pr * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_h, T * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_t, T * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_qkv, T * c->qkv_out))) break;
+    if ((rc = dalloc(c, &c->l_ao, T * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_ffn, T * k.llm_inter))) break;
+    if ((rc = dalloc(c, &c->l_rows, (size_t)(k.max_out_rows + k.max_seqs + 64) * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_pos, T))) break;
+    if ((rc = dalloc(c, &c->l_seq, T))) break;
+    if ((rc = dalloc(c, &c->l_cu, (size_t)k.max_seqs + 1))) break;
+    if ((rc = dalloc(c, &c->l_rowidx, (size_t)k.max_out_rows + k.max_seqs + 64))) break;
+    if ((rc = dalloc(c, &c->l_kvlen, (size_t)k.max_seqs))) break;
+    if ((rc = dalloc(c, &c->l_packed, (size_t)64))) break;
+    if (k.kv_capacity > 0) {
+      const size_t per = (size_t)k.llm_layers * k.max_seqs * k.llm_kv_heads * k.kv_capacity * c->head_dim;
+      if ((rc = dalloc(c, &c->kc, per))) break;
+      if ((rc = dalloc(c, &c->vc, per))) break;
+    }
+    std::vector<int32_t> cu(k.vit_chunk + 1);
+    for (int i = 0; i <= k.vit_chunk; ++i) cu[i] = i * c->S;
+    e = hipMemcpy(c->v_cu, cu.data(), cu.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(c, AIGV_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+  } while (0);
+  if (rc) {
+    g_err = c->err;
+    aigv_ctx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+void aigv_ctx_destroy(aigv_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (void* p : c->allocs) hipFree(p);
+  for (auto& kv : c->w) hipFree(kv.second.p);
+  for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (auto e : c->ev_pool) hipEventDestroy(e);
+  delete c;
+}
+
+int aigv_load_weight(aigv_ctx* c, const char* name, const void* data, const int64_t* shape, int ndim, int dtype,
+                     int on_device) {
+  if (!c || !name || !data || !shape || ndim <= 0) return fail(c, AIGV_ERR_ARG, "aigv_load_weight: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] <= 0) return fail(c, AIGV_ERR_ARG, "aigv_load_weight(%s): bad shape", name);
+    n *= (size_t)shape[i];
+  }
+  const std::string key(name);
+  const aigv_config& k = c->cfg;
+  const bool is_patch = key == "vision_model.embeddings.patch_embedding.weight";
+  const bool is_w1 = key.find("feed_forward.w1.weight") != std::string::npos;
+  const bool is_w3 = key.find("feed_forward.w3.weight") != std::string::npos;
+  std::vector<uint16_t> host;
+  const void* src = data;           // bf16 source (host or device)
+  bool src_dev = on_device != 0;
+  if (dtype == AIGV_F32 || is_patch) {
+    // stage through the host: convert and/or repack
+    std::vector<uint8_t> raw;
+    const void* hsrc = data;
+    const size_t esz = dtype == AIGV_F32 ? 4 : 2;
+    if (on_device) {
+      raw.resize(n * esz);
+      HIPCHK(c, hipMemcpy(raw.data(), data, n * esz, hipMemcpyDeviceToHost));
+      hsrc = raw.data();
+    }
+    host.resize(n);
+    if (dtype == AIGV_F32) for (size_t i = 0; i < n; ++i) host[i] = f32_to_bf16_host(((const float*)hsrc)[i]);
+    else memcpy(host.data(), hsrc, n * 2);
+    if (is_patch) {  // [Hv, C, P, P] -> [Hv, Kp] zero padded
+      const size_t kk = (size_t)k.num_channels * k.patch_size * k.patch_size;
+      if (n != (size_t)k.vit_hidden * kk) return fail(c, AIGV_ERR_ARG, "patch_embedding.weight has the wrong size");
+      std::vector<uint16_t> padded((size_t)k.vit_hidden * c->Kp, 0);
+      for (int r = 0; r < k.vit_hidden; ++r) memcpy(&padded[(size_t)r * c->Kp], &host[(size_t)r * kk], kk * 2);
+      host.swap(padded);
+      n = host.size();
+    }
+    src = host.data();
+    src_dev = false;
+  } else if (dtype != AIGV_BF16) {
+    return fail(c, AIGV_ERR_ARG, "aigv_load_weight(%s): unknown dtype %d", name, dtype);
+  }
+
+  if (is_w1 || is_w3) {
+    // w1 / w3 [I, H] are stored interleaved in 16-row blocks (even block = w1, odd = w3) for the SwiGLU epilogue
+    if (ndim != 2 || shape[0] != k.llm_inter || shape[1] != k.llm_hidden)
+      return fail(c, AIGV_ERR_ARG, "aigv_load_weight(%s): expected [%d,%d]", name, k.llm_inter, k.llm_hidden);
+    std::string fused = key.substr(0, key.find("feed_forward.")) + "feed_forward.w13.weight";
+    auto it = c->w.find(fused);
+    if (it == c->w.end()) {
+      DevBuf b;
+      b.bytes = (size_t)2 * k.llm_inter * k.llm_hidden * 2;
+      hipError_t e = hipMalloc(&b.p, b.bytes);
+      if (e != hipSuccess) return fail(c, AIGV_ERR_ALLOC, "hipMalloc(%zu) for %s: %s", b.bytes, fused.c_str(), hipGetErrorString(e));
+      it = c->w.emplace(fused, b).first;
+    }
+    const size_t blk = (size_t)16 * k.llm_hidden * 2;  // bytes of one 16-row block
+    char* dst = (char*)it->second.p + (is_w3 ? blk : 0);
+    HIPCHK(c, hipMemcpy2D(dst, 2 * blk, src, blk, blk, k.llm_inter / 16, src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    c->w[key + "#seen"] = DevBuf{};  // marker (no storage)
+    c->finalized = false;
+    return 0;
+  }
+
+  auto it = c->w.find(key);
+  if (it != c->w.end() && it->second.bytes != n * 2) {
+    hipFree(it->second.p);
+    c->w.erase(it);
+    it = c->w.end();
+  }
+  if (it == c->w.end()) {
+    DevBuf b;
+    b.bytes = n * 2;
+    hipError_t e = hipMalloc(&b.p, b.bytes);
+    if (e != hipSuccess) return fail(c, AIGV_ERR_ALLOC, "hipMalloc(%zu) for %s: %s", b.bytes, name, hipGetErrorString(e));
+    it = c->w.emplace(key, b).first;
+  }
+  HIPCHK(c, hipMemcpy(it->second.p, src, n * 2, src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  c->finalized = false;
+  return 0;
+}
+
+int aigv_finalize_weights(aigv_ctx* c) {
+  if (!c) return fail(c, AIGV_ERR_ARG, "null ctx");
+  HIPCHK(c, hipSetDevice(c->device));
+  const aigv_config& k = c->cfg;
+  const size_t Hv = k.vit_hidden, Iv = k.vit_inter, H = k.llm_hidden, I = k.llm_inter;
+  const std::string e = "vision_model.embeddings.";
+  TRY(need(c, e + "patch_embedding.weight", Hv * c->Kp, &c->patch_w));
+  TRY(need(c, e + "patch_embedding.bias", Hv, &c->patch_b));
+  TRY(need(c, e + "position_embedding", (size_t)c->S * Hv, &c->pos));
+  const bf16_t* cls = nullptr;
+  TRY(need(c, e + "class_embedding", Hv, &cls));
+  {  // class token row = bf16(cls + pos[0])  (modeling_intern_vit.py:100-106)
+    std::vector<uint16_t> a(Hv), b(Hv), o(Hv);
+    HIPCHK(c, hipMemcpy(a.data(), cls, Hv * 2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(b.data(), c->pos, Hv * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < Hv; ++i) o[i] = f32_to_bf16_host(bf16_to_f32_host(a[i]) + bf16_to_f32_host(b[i]));
+    const int64_t shp[1] = {(int64_t)Hv};
+    TRY(aigv_load_weight(c, "derived.cls_pos", o.data(), shp, 1, AIGV_BF16, 0));
+    TRY(need(c, "derived.cls_pos", Hv, &c->cls_pos));
+  }
+  c->vit.assign(k.vit_layers, VitLayer{});
+  for (int i = 0; i < k.vit_layers; ++i) {
+    const std::string p = "vision_model.encoder.layers." + std::to_string(i) + ".";
+    VitLayer& L = c->vit[i];
+    TRY(need(c, p + "ls1", Hv, &L.ls1));
+    TRY(need(c, p + "ls2", Hv, &L.ls2));
+    TRY(need(c, p + "attn.qkv.weight", 3 * Hv * Hv, &L.qkv_w));
+    if (k.vit_qkv_bias) TRY(need(c, p + "attn.qkv.bias", 3 * Hv, &L.qkv_b));
+    if (k.vit_qk_norm) {
+      TRY(need(c, p + "attn.q_norm.weight", Hv, &L.qn));
+      TRY(need(c, p + "attn.k_norm.weight", Hv, &L.kn));
+    }
+    TRY(need(c, p + "attn.proj.weight", Hv * Hv, &L.proj_w));
+    TRY(need(c, p + "attn.proj.bias", Hv, &L.proj_b));
+    TRY(need(c, p + "mlp.fc1.weight", Iv * Hv, &L.fc1_w));
+    TRY(need(c, p + "mlp.fc1.bias", Iv, &L.fc1_b));
+    TRY(need(c, p + "mlp.fc2.weight", Hv * Iv, &L.fc2_w));
+    TRY(need(c, p + "mlp.fc2.bias", Hv, &L.fc2_b));
+    TRY(need(c, p + "norm1.weight", Hv, &L.n1w));
+    TRY(need(c, p + "norm2.weight", Hv, &L.n2w));
+    if (!k.vit_norm_rms) {
+      TRY(need(c, p + "norm1.bias", Hv, &L.n1b));
+      TRY(need(c, p + "norm2.bias", Hv, &L.n2b));
+    }
+  }
+  TRY(need(c, "language_model.model.tok_embeddings.weight", (size_t)k.vocab * H, &c->tok_emb));
+  TRY(need(c, "language_model.model.norm.weight", H, &c->final_norm));
+  TRY(need(c, "language_model.output.weight", (size_t)k.vocab * H, &c->lm_head));
+  TRY(need(c, "rope.cos", (size_t)k.max_positions * c->head_dim / 2, &c->rope_cos));
+  TRY(need(c, "rope.sin", (size_t)k.max_positions * c->head_dim / 2, &c->rope_sin));
+  c->llm.assign(k.llm_layers, LlmLayer{});
+  for (int i = 0; i < k.llm_layers; ++i) {
+    const std::string p = "language_model.model.layers." + std::to_string(i) + ".";
+    LlmLayer& L = c->llm[i];
+    TRY(need(c, p + "attention.wqkv.weight", (size_t)c->qkv_out * H, &L.wqkv));
+    TRY(need(c, p + "attention.wo.weight", H * H, &L.wo));
+    if (!c->w.count(p + "feed_forward.w1.weight#seen") || !c->w.count(p + "feed_forward.w3.weight#seen"))
+      return fail(c, AIGV_ERR_STATE, "layer %d: feed_forward.w1/w3 were not both loaded", i);
+    TRY(need(c, p + "feed_forward.w13.weight", 2 * I * H, &L.w13));
+    TRY(need(c, p + "feed_forward.w2.weight", H * I, &L.w2));
+    TRY(need(c, p + "attention_norm.weight", H, &L.an));
+    TRY(need(c, p + "ffn_norm.weight", H, &L.fn));
+  }
+  const char* pn[2] = {"mlp1", "motion_mlp"};
+  const size_t pin[2] = {(size_t)c->proj_in, (size_t)k.motion_dim};
+  for (int j = 0; j < 2; ++j) {
+    const std::string p = std::string(pn[j]) + ".";
+    TRY(need(c, p + "0.weight", pin[j], &c->p_ln_w[j]));
+    TRY(need(c, p + "0.bias", pin[j], &c->p_ln_b[j]));
+    TRY(need(c, p + "1.weight", H * pin[j], &c->p_w1[j]));
+    TRY(need(c, p + "1.bias", H, &c->p_b1[j]));
+    TRY(need(c, p + "3.weight", H * H, &c->p_w2[j]));
+    TRY(need(c, p + "3.bias", H, &c->p_b2[j]));
+  }
+  c->score = ScoreHeadArgs{};
+  c->score.n_layers = k.n_score_layers;
+  c->score.dims[0] = (int)H;
+  for (int j = 0; j < k.n_score_layers; ++j) {
+    c->score.dims[j + 1] = k.score_dims[j];
+    const std::string p = "mlpscore.fc" + std::to_string(j + 1) + ".";
+    TRY(need(c, p + "weight", (size_t)c->score.dims[j + 1] * c->score.dims[j], &c->score.w[j]));
+    TRY(need(c, p + "bias", (size_t)c->score.dims[j + 1], &c->score.b[j]));
+  }
+  if (H > 4096) return fail(c, AIGV_ERR_ARG, "score head input wider than 4096 is not supported yet");
+  c->finalized = true;
+  return 0;
+}
+
+// ---- InternViT ---------------------------------------------------------------------------------------------
+static int vit_norm(aigv_ctx* c, const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, hipStream_t s) {
+  const aigv_config& k = c->cfg;
+  if (k.vit_norm_rms) HIPCHK(c, aigv_launch_rmsnorm(x, k.vit_hidden, w, y, k.vit_hidden, rows, k.vit_hidden, k.vit_eps, nullptr, s));
+  else HIPCHK(c, aigv_launch_layernorm(x, k.vit_hidden, w, b, y, k.vit_hidden, rows, k.vit_hidden, k.vit_eps, s));
+  return 0;
+}
+
+int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_tokens, void* stream) {
+  if (!c || !frames || !out_tokens) return fail(c, AIGV_ERR_ARG, "aigv_vit_forward: null argument");
+  if (!c->finalized) return fail(c, AIGV_ERR_STATE, "aigv_vit_forward: call aigv_finalize_weights first");
+  const aigv_config& k = c->cfg;
+  if (n_frames <= 0 || n_frames > k.max_frames) return fail(c, AIGV_ERR_ARG, "n_frames %d outside 1..%d", n_frames, k.max_frames);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Hv = k.vit_hidden, Iv = k.vit_inter;
+  int n_layers = k.vit_layers;
+  if (k.select_layer != -1) n_layers = k.select_layer < 0 ? k.vit_layers + 1 + k.select_layer : k.select_layer;
+  if (n_layers < 0 || n_layers > k.vit_layers) return fail(c, AIGV_ERR_ARG, "select_layer %d out of range", k.select_layer);
+  const size_t frame_elems = (size_t)k.num_channels * k.image_size * k.image_size;
+  for (int f0 = 0; f0 < n_frames; f0 += k.vit_chunk) {
+    const int F = std::min(k.vit_chunk, n_frames - f0);
+    const int rows = F * c->S;
+    const bf16_t* fr = (const bf16_t*)frames + (size_t)f0 * frame_elems;
+    // patch embed: im2col + GEMM with the bias / position / row-remap epilogue (modeling_intern_vit.py:95-107)
+    HIPCHK(c, aigv_launch_im2col(fr, F, k.num_channels, k.image_size, k.patch_size, c->Kp, c->v_col, s));
+    HIPCHK(c, aigv_launch_cls_rows(c->cls_pos, c->v_x, F, c->S, Hv, s));
+    {
+      GemmArgs a = gemm_args(c->v_col, c->Kp, c->patch_w, c->Kp, c->v_x, Hv, F * c->np, Hv, c->Kp);
+      a.bias = c->patch_b; a.pos = c->pos; a.np = c->np;
+      TRY(run_gemm(c, a, EPI_PATCH, s));
+    }
+    for (int li = 0; li < n_layers; ++li) {
+      const VitLayer& L = c->vit[li];
+      TRY(vit_norm(c, c->v_x, L.n1w, L.n1b, c->v_t, rows, s));
+      {
+        GemmArgs a = gemm_args(c->v_t, Hv, L.qkv_w, Hv, c->v_qkv, 3 * Hv, rows, 3 * Hv, Hv);
+        a.bias = L.qkv_b;
+        TRY(run_gemm(c, a, EPI_STORE, s));
+      }
+      if (k.vit_qk_norm) {  // full-width RMSNorm of q and k, in place (modeling_intern_vit.py:148-151)
+        HIPCHK(c, aigv_launch_rmsnorm(c->v_qkv, 3 * Hv, L.qn, c->v_qkv, 3 * Hv, rows, Hv, k.vit_eps, nullptr, s));
+        HIPCHK(c, aigv_launch_rmsnorm(c->v_qkv + Hv, 3 * Hv, L.kn, c->v_qkv + Hv, 3 * Hv, rows, Hv, k.vit_eps, nullptr, s));
+      }
+      {
+        AttnArgs a{};
+        a.q = c->v_qkv; a.k = c->v_qkv + Hv; a.v = c->v_qkv + 2 * Hv;
+        a.ldq = a.ldk = a.ldv = 3 * Hv;
+        a.o = c->v_ao; a.ldo = Hv;
+        a.cu = c->v_cu; a.n_seq = F; a.max_len = c->S;
+        a.n_heads = a.n_kv_heads = k.vit_heads;
+        a.q_group_stride = a.kv_head_stride = c->vit_head_dim;
+        a.causal = 0; a.post_div = 1.0f; a.q_prescale = 1.0f / sqrtf((float)c->vit_head_dim);
+        if (const char* m = aigv_attn_check(a, c->vit_head_dim)) return fail(c, AIGV_ERR_ARG, "%s", m);
+        ProfScope ps(c, AIGV_PROF_ATTN_VIT, 4.0 * F * (double)c->S * c->S * Hv, 2.0 * 4 * rows * (double)Hv, s);
+        HIPCHK(c, aigv_launch_attention(a, c->vit_head_dim, s));
+      }
+      {
+        GemmArgs a = gemm_args(c->v_ao, Hv, L.proj_w, Hv, c->v_x, Hv, rows, Hv, Hv);
+        a.bias = L.proj_b; a.ls = L.ls1; a.resid = c->v_x; a.ldr = Hv;
+        TRY(run_gemm(c, a, EPI_LS_RESID, s));
+      }
+      TRY(vit_norm(c, c->v_x, L.n2w, L.n2b, c->v_t, rows, s));
+      {
+        GemmArgs a = gemm_args(c->v_t, Hv, L.fc1_w, Hv, c->v_h, Iv, rows, Iv, Hv);
+        a.bias = L.fc1_b;
+        TRY(run_gemm(c, a, EPI_GELU, s));
+      }
+      {
+        GemmArgs a = gemm_args(c->v_h, Iv, L.fc2_w, Iv, c->v_x, Hv, rows, Hv, Iv);
+        a.bias = L.fc2_b; a.ls = L.ls2; a.resid = c->v_x; a.ldr = Hv;
+        TRY(run_gemm(c, a, EPI_LS_RESID, s));
+      }
+    }
+    HIPCHK(c, aigv_launch_pixel_shuffle(c->v_x, c->grid, Hv, (bf16_t*)out_tokens + (size_t)f0 * c->ntok * c->proj_in, F, s));
+  }
+  return 0;
+}
+
+int aigv_project(aigv_ctx* c, const void* tokens, int rows, void* out, void* stream) {
+  if (!c || !tokens || !out) return fail(c, AIGV_ERR_ARG, "aigv_project: null argument");
+  if (!c->finalized) return fail(c, AIGV_ERR_STATE, "aigv_project: call aigv_finalize_weights first");
+  if (rows <= 0) return fail(c, AIGV_ERR_ARG, "aigv_project: rows must be positive");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  const aigv_config& k = c->cfg;
+  const int H = k.llm_hidden, Pin = c->proj_in;
+  const int chunk = k.vit_chunk * c->ntok;
+  for (int r0 = 0; r0 < rows; r0 += chunk) {
+    const int R = std::min(chunk, rows - r0);
+    const bf16_t* x = (const bf16_t*)tokens + (size_t)r0 * Pin;
+    HIPCHK(c, aigv_launch_layernorm(x, Pin, c->p_ln_w[0], c->p_ln_b[0], c->p_t, Pin, R, Pin, 1e-5f, s));
+    {
+      GemmArgs a = gemm_args(c->p_t, Pin, c->p_w1[0], Pin, c->p_mid, H, R, H, Pin);
+      a.bias = c->p_b1[0];
+      TRY(run_gemm(c, a, EPI_GELU, s));
+    }
+    {
+      GemmArgs a = gemm_args(c->p_mid, H, c->p_w2[0], H, (bf16_t*)out + (size_t)r0 * H, H, R, H, H);
+      a.bias = c->p_b2[0];
+      TRY(run_gemm(c, a, EPI_STORE, s));
+    }
+  }
+  return 0;
+}
+
+int aigv_motion_project(aigv_ctx* c, const void* motion_feature, int n_clips, void* out, void* stream) {
+  if (!c || !motion_feature || !out) return fail(c, AIGV_ERR_ARG, "aigv_motion_project: null argument");
+  if (!c->finalized) return fail(c, AIGV_ERR_STATE, "aigv_motion_project: call aigv_finalize_weights first");
+  if (n_clips <= 0 || n_clips > c->cfg.max_seqs) return fail(c, AIGV_ERR_ARG, "n_clips %d outside 1..%d", n_clips, c->cfg.max_seqs);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  const aigv_config& k = c->cfg;
+  const int H = k.llm_hidden, Md = k.motion_dim;
+  // scratch: p_t (>= ntok*proj_in elements) holds the normalised feature, p_mid the hidden layer
+  if ((size_t)n_clips * Md > (size_t)k.vit_chunk * c->ntok * c->proj_in || n_clips > k.vit_chunk * c->ntok)
+    return fail(c, AIGV_ERR_STATE, "motion batch does not fit the projector workspace");
+  HIPCHK(c, aigv_launch_layernorm((const bf16_t*)motion_feature, Md, c->p_ln_w[1], c->p_ln_b[1], c->p_t, Md, n_clips, Md, 1e-5f, s));
+  for (int r0 = 0; r0 < n_clips; r0 += 64) {
+    const int R = std::min(64, n_clips - r0);
+    TRY(run_skinny(c, c->p_t + (size_t)r0 * Md, Md, R, c->p_w1[1], Md, H, Md, c->p_b1[1], nullptr, 0,
+                   c->p_mid + (size_t)r0 * H, H, 3 /*gelu*/, s));
+    TRY(run_skinny(c, c->p_mid + (size_t)r0 * H, H, R, c->p_w2[1], H, H, H, c->p_b2[1], nullptr, 0,
+                   (bf16_t*)out + (size_t)r0 * H, H, 0 /*store*/, s));
+  }
+  return 0;
+}
+
+// ---- InternLM2 -----------------------------------------------------------------------------------------------
+static int final_rows(aigv_ctx* c, const int32_t* score_rows, float* score, int B, const int32_t* logit_rows, int R,
+                      int64_t* argmax, const bf16_t* hidden, int total_rows, hipStream_t s) {
+  const aigv_config& k = c->cfg;
+  const int H = k.llm_hidden;
+  const int nS = score ? B : 0;
+  if (R > k.max_out_rows) return fail(c, AIGV_ERR_ARG, "%d logit rows exceed max_out_rows %d", R, k.max_out_rows);
+  c->h_rowidx.clear();
+  for (int i = 0; i < nS; ++i) c->h_rowidx.push_back(score_rows[i]);
+  for (int i = 0; i < R; ++i) c->h_rowidx.push_back(logit_rows[i]);
+  for (int v : c->h_rowidx)
+    if (v < 0 || v >= total_rows) return fail(c, AIGV_ERR_ARG, "output row index %d outside 0..%d", v, total_rows - 1);
+  const int n = (int)c->h_rowidx.size();
+  if (n == 0) return 0;
+  HIPCHK(c, hipMemcpyAsync(c->l_rowidx, c->h_rowidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  // final RMSNorm only on the rows that are consumed (modeling_internlm2.py:984)
+  HIPCHK(c, aigv_launch_rmsnorm(hidden, H, c->final_norm, c->l_rows, H, n, H, k.rms_eps, c->l_rowidx, s));
+  if (nS) {
+    ScoreHeadArgs a = c->score;
+    a.x = c->l_rows; a.ldx = H; a.B = nS; a.score = score;
+    HIPCHK(c, aigv_launch_score_head(a, s));
+  }
+  for (int r0 = 0; r0 < R; r0 += 64) {
+    const int rr = std::min(64, R - r0);
+    ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * rr * (double)k.vocab * H, 2.0 * (double)k.vocab * H, s);
+    HIPCHK(c, aigv_launch_lm_head_argmax(c->l_rows + (size_t)(nS + r0) * H, rr, H, c->lm_head, k.vocab, c->l_packed,
+                                         argmax + r0, nullptr, s));
+  }
+  return 0;
+}
+
+int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const int32_t* cu, int B, const void* vis,
+                     int n_vis, const void* motion, const int32_t* score_rows, float* score, const int32_t* logit_rows,
+                     int R, int64_t* argmax, int keep_kv, void* stream) {
+  if (!c || !ids || !slot || !cu) return fail(c, AIGV_ERR_ARG, "aigv_llm_prefill: null argument");
+  if (!c->finalized) return fail(c, AIGV_ERR_STATE, "aigv_llm_prefill: call aigv_finalize_weights first");
+  const aigv_config& k = c->cfg;
+  if (B <= 0 || B > k.max_seqs) return fail(c, AIGV_ERR_ARG, "n_clips %d outside 1..%d", B, k.max_seqs);
+  if (cu[0] != 0) return fail(c, AIGV_ERR_ARG, "cu_seqlens[0] must be 0");
+  int max_len = 0;
+  for (int b = 0; b < B; ++b) {
+    const int len = cu[b + 1] - cu[b];
+    if (len <= 0) return fail(c, AIGV_ERR_ARG, "clip %d has an empty token sequence", b);
+    if (len > k.max_positions) return fail(c, AIGV_ERR_ARG, "clip %d: %d tokens exceed the RoPE table (%d)", b, len, k.max_positions);
+    max_len = std::max(max_len, len);
+  }
+  const int T = cu[B];
+  if (T > k.max_tokens) return fail(c, AIGV_ERR_ARG, "%d packed tokens exceed max_tokens %d", T, k.max_tokens);
+  if ((score && !score_rows) || (R > 0 && (!logit_rows || !argmax))) return fail(c, AIGV_ERR_ARG, "output rows/buffers inconsistent");
+  if (n_vis < 0 || (n_vis > 0 && !vis)) return fail(c, AIGV_ERR_ARG, "visual tokens missing");
+  if (keep_kv && (k.kv_capacity <= 0 || max_len >= k.kv_capacity))
+    return fail(c, AIGV_ERR_STATE, "keep_kv needs kv_capacity > longest prompt (%d vs %d)", k.kv_capacity, max_len);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int H = k.llm_hidden, I = k.llm_inter, D = c->head_dim, g = c->g, nkv = k.llm_kv_heads;
+
+  c->h_pos.resize(T);
+  c->h_seq.resize(T);
+  for (int b = 0; b < B; ++b)
+    for (int t = cu[b]; t < cu[b + 1]; ++t) { c->h_pos[t] = t - cu[b]; c->h_seq[t] = b; }
+  HIPCHK(c, hipMemcpyAsync(c->l_pos, c->h_pos.data(), (size_t)T * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->l_seq, c->h_seq.data(), (size_t)T * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->l_cu, cu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
+
+  HIPCHK(c, aigv_launch_embed(ids, slot, c->tok_emb, (const bf16_t*)vis, (const bf16_t*)motion, n_vis, c->l_h, T, H, s));
+  double attn_flops = 0;
+  for (int b = 0; b < B; ++b) { const double L = cu[b + 1] - cu[b]; attn_flops += 4.0 * (L * (L + 1) / 2) * D * k.llm_heads; }
+  const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
+  for (int li = 0; li < k.llm_layers; ++li) {
+    const LlmLayer& L = c->llm[li];
+    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
+    TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
+    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, g + 1, g + 2, nkv, D, s));
+    if (keep_kv)
+      HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, T,
+                                     nkv, g, D, k.kv_capacity, s));
+    {
+      AttnArgs a{};
+      a.q = c->l_qkv; a.k = c->l_qkv + (size_t)g * D; a.v = c->l_qkv + (size_t)(g + 1) * D;
+      a.ldq = a.ldk = a.ldv = c->qkv_out;
+      a.o = c->l_ao; a.ldo = H;
+      a.cu = c->l_cu; a.n_seq = B; a.max_len = max_len;
+      a.n_heads = k.llm_heads; a.n_kv_heads = nkv;
+      a.q_group_stride = a.kv_head_stride = (g + 2) * D;
+      a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
+      if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
+      ProfScope ps(c, AIGV_PROF_ATTN_LLM, attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
+      HIPCHK(c, aigv_launch_attention(a, D, s));
+    }
+    {
+      GemmArgs a = gemm_args(c->l_ao, H, L.wo, H, c->l_h, H, T, H, H);
+      a.resid = c->l_h; a.ldr = H;
+      TRY(run_gemm(c, a, EPI_RESID, s));
+    }
+    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, T, H, k.rms_eps, nullptr, s));
+    TRY(run_gemm(c, gemm_args(c->l_t, H, L.w13, H, c->l_ffn, I, T, 2 * I, H), EPI_SWIGLU, s));
+    {
+      GemmArgs a = gemm_args(c->l_ffn, I, L.w2, I, c->l_h, H, T, H, I);
+      a.resid = c->l_h; a.ldr = H;
+      TRY(run_gemm(c, a, EPI_RESID, s));
+    }
+  }
+  TRY(final_rows(c, score_rows, score, B, logit_rows, R, argmax, c->l_h, T, s));
+  if (keep_kv) {
+    c->h_kvlen.resize(B);
+    for (int b = 0; b < B; ++b) c->h_kvlen[b] = cu[b + 1] - cu[b];
+    c->kv_seqs = B;
+    c->kv_valid = true;
+  } else {
+    c->kv_valid = false;
+  }
+  return 0;
+}
+
+int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* stream) {
+  if (!c || !ids || !next) return fail(c, AIGV_ERR_ARG, "aigv_decode_step: null argument");
+  if (!c->kv_valid) return fail(c, AIGV_ERR_STATE, "aigv_decode_step: no KV state (run aigv_llm_prefill with keep_kv)");
+  const aigv_config& k = c->cfg;
+  const int B = c->kv_seqs, H = k.llm_hidden, I = k.llm_inter, D = c->head_dim, g = c->g, nkv = k.llm_kv_heads;
+  if (B > 64) return fail(c, AIGV_ERR_ARG, "decode supports at most 64 clips per step");
+  for (int b = 0; b < B; ++b)
+    if (c->h_kvlen[b] + 1 > k.kv_capacity || c->h_kvlen[b] + 1 > k.max_positions)
+      return fail(c, AIGV_ERR_STATE, "clip %d: KV cache / RoPE table exhausted at %d tokens", b, c->h_kvlen[b]);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  // positions of the new tokens = current lengths; keys visible afterwards = length + 1
+  c->h_pos.assign(c->h_kvlen.begin(), c->h_kvlen.end());
+  c->h_seq.resize(B);
+  c->h_rowidx.resize(B);
+  std::vector<int32_t>& vis_len = c->h_rowidx;
+  for (int b = 0; b < B; ++b) { c->h_seq[b] = b; vis_len[b] = c->h_kvlen[b] + 1; }
+  HIPCHK(c, hipMemcpyAsync(c->l_pos, c->h_pos.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->l_seq, c->h_seq.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->l_kvlen, vis_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  // slot = -1 everywhere: plain token embeddings.  l_rowidx is reused as the int32 slot array.
+  std::vector<int32_t> neg(B, -1);
+  HIPCHK(c, hipMemcpyAsync(c->l_rowidx, neg.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipStreamSynchronize(s));  // `neg` and the host vectors above are about to be reused
+  HIPCHK(c, aigv_launch_embed(ids, c->l_rowidx, c->tok_emb, nullptr, nullptr, 0, c->l_h, B, H, s));
+  const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
+  for (int li = 0; li < k.llm_layers; ++li) {
+    const LlmLayer& L = c->llm[li];
+    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, B, H, k.rms_eps, nullptr, s));
+    TRY(run_skinny(c, c->l_t, H, B, L.wqkv, H, c->qkv_out, H, nullptr, nullptr, 0, c->l_qkv, c->qkv_out, 0, s));
+    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, B, g + 1, g + 2, nkv, D, s));
+    HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, B,
+                                   nkv, g, D, k.kv_capacity, s));
+    HIPCHK(c, aigv_launch_attention_decode(c->l_qkv, c->qkv_out, (g + 2) * D, c->kc + li * kv_layer, c->vc + li * kv_layer,
+                                           c->l_kvlen, k.kv_capacity, c->l_ao, H, B, nkv, g, D, sqrtf((float)D), s));
+    TRY(run_skinny(c, c->l_ao, H, B, L.wo, H, H, H, nullptr, c->l_h, H, c->l_h, H, 1, s));
+    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, B, H, k.rms_eps, nullptr, s));
+    TRY(run_skinny(c, c->l_t, H, B, L.w13, H, 2 * I, H, nullptr, nullptr, 0, c->l_ffn, I, 2, s));
+    TRY(run_skinny(c, c->l_ffn, I, B, L.w2, I, H, I, nullptr, c->l_h, H, c->l_h, H, 1, s));
+  }
+  HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, c->final_norm, c->l_rows, H, B, H, k.rms_eps, nullptr, s));
+  HIPCHK(c, aigv_launch_lm_head_argmax(c->l_rows, B, H, c->lm_head, k.vocab, c->l_packed, next, nullptr, s));
+  for (int b = 0; b < B; ++b) c->h_kvlen[b] += 1;
+  return 0;
+}
+
+// ---- single operators ----------------------------------------------------------------------------------------
+int aigv_op_gemm(const void* A, int lda, const void* W_, int ldw, void* C, int ldc, const void* bias, const void* ls,
+                 const void* resid, int ldr, const void* pos, int np, int M, int N, int K, int epi, void* stream) {
+  GemmArgs a = gemm_args((const bf16_t*)A, lda, (const bf16_t*)W_, ldw, (bf16_t*)C, ldc, M, N, K);
+  a.bias = (const bf16_t*)bias; a.ls = (const bf16_t*)ls; a.resid = (const bf16_t*)resid; a.ldr = ldr;
+  a.pos = (const bf16_t*)pos; a.np = np;
+  return run_gemm(nullptr, a, epi, (hipStream_t)stream);
+}
+
+int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W_, int ldw, int N, int K, const void* bias,
+                        const void* resid, int ldr, void* out, int ldo, int epi, void* stream) {
+  return run_skinny(nullptr, (const bf16_t*)x, ldx, R, (const bf16_t*)W_, ldw, N, K, (const bf16_t*)bias,
+                    (const bf16_t*)resid, ldr, (bf16_t*)out, ldo, epi, (hipStream_t)stream);
+}
+
+int aigv_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H, float eps,
+                      void* stream) {
+  HIPCHK(nullptr, aigv_launch_layernorm((const bf16_t*)x, ldx, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, rows, H,
+                                        eps, (hipStream_t)stream));
+  return 0;
+}
+
+int aigv_op_rmsnorm(const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps,
+                    const int32_t* row_idx, void* stream) {
+  HIPCHK(nullptr, aigv_launch_rmsnorm((const bf16_t*)x, ldx, (const bf16_t*)w, (bf16_t*)y, ldy, rows, H, eps, row_idx,
+                                      (hipStream_t)stream));
+  return 0;
+}
+
+int aigv_op_rope(void* qkv, int ld, const int32_t* pos, const void* cos, const void* sin, int tokens, int n_rot, int slots,
+                 int n_groups, int head_dim, void* stream) {
+  HIPCHK(nullptr, aigv_launch_rope((bf16_t*)qkv, ld, pos, (const bf16_t*)cos, (const bf16_t*)sin, tokens, n_rot, slots,
+                                   n_groups, head_dim, (hipStream_t)stream));
+  return 0;
+}
+
+int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                      const int32_t* cu, int n_seq, int max_len, int n_heads, int n_kv_heads, int q_group_stride,
+                      int kv_head_stride, int head_dim, int causal, float post_div, float q_prescale, void* stream) {
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
+  a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
+  a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
+  a.causal = causal; a.post_div = post_div; a.q_prescale = q_prescale;
+  if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
+  HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));
+  return 0;
+}
+
+int aigv_op_pixel_shuffle(const void* vit_out, int grid, int vit_hidden, void* out, int n_frames, void* stream) {
+  HIPCHK(nullptr, aigv_launch_pixel_shuffle((const bf16_t*)vit_out, grid, vit_hidden, (bf16_t*)out, n_frames, (hipStream_t)stream));
+  return 0;
+}
+
+int aigv_op_im2col(const void* frames, int n_frames, int channels, int image_size, int patch, int kp, void* out,
+                   void* stream) {
+  HIPCHK(nullptr, aigv_launch_im2col((const bf16_t*)frames, n_frames, channels, image_size, patch, kp, (bf16_t*)out,
+                                     (hipStream_t)stream));
+  return 0;
+}
+
+int aigv_op_lm_head_argmax(const void* h, int rows, int hidden, const void* W_, int vocab, void* scratch_u64, int64_t* idx,
+                           float* val, void* stream) {
+  HIPCHK(nullptr, aigv_launch_lm_head_argmax((const bf16_t*)h, rows, hidden, (const bf16_t*)W_, vocab,
+                                             (unsigned long long*)scratch_u64, idx, val, (hipStream_t)stream));
+  return 0;
+}
+
+// ---- measurement -----------------------------------------------------------------------------------------------
+int aigv_prof_enable(aigv_ctx* c, int on) {
+  if (!c) return fail(c, AIGV_ERR_ARG, "null ctx");
+  c->prof = on != 0;
+  return 0;
+}
+
+int aigv_prof_read(aigv_ctx* c, int cls, int64_t* launches, double* total_ms, double* flops, double* bytes) {
+  if (!c || cls < 0 || cls >= AIGV_PROF_COUNT) return fail(c, AIGV_ERR_ARG, "aigv_prof_read: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  int64_t n = 0;
+  double ms = 0, fl = 0, by = 0;
+  std::vector<ProfRec> keep;
+  for (auto& r : c->recs) {
+    if (r.cls != cls) { keep.push_back(r); continue; }
+    HIPCHK(c, hipEventSynchronize(r.b));
+    float t = 0;
+    HIPCHK(c, hipEventElapsedTime(&t, r.a, r.b));
+    ms += t; fl += r.flops; by += r.bytes; ++n;
+    c->ev_pool.push_back(r.a);
+    c->ev_pool.push_back(r.b);
+  }
+  c->recs.swap(keep);
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,344 @@
+// Fused (flash-style) attention forward for gfx950, bf16 in / fp32 accumulate, packed varlen layout.
+//   D = 64  non-causal : InternViT multi-head attention   (reference: modeling_intern_vit.py:143-160 / flash :162-177)
+//   D = 128 causal GQA : InternLM2 prefill attention       (reference: modeling_internlm2.py:355-440 / flash :444-614)
+//
+// Work split: grid = (q blocks of 128 rows, q heads, sequences); 4 waves per workgroup, each wave owns
+// 32 query rows; the workgroup streams 64-key K/V tiles through LDS (register-staged: the loads of tile
+// t+1 are issued before the MFMAs of tile t and written to LDS after them).
+//
+// MFMA formulation ("key on the row, query on the lane"):
+//   S^T[key, q] = K · Q^T      v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128, XOR-swizzled),
+//                              B = Q^T fragments held in registers for the whole kernel.
+//     -> each lane owns ONE query column, so softmax statistics are lane-local (+ one lane^32 exchange)
+//   O^T[d, q] += V^T · P^T     the S^T accumulator (converted to bf16) IS the B operand of this product
+//                              (no LDS round trip); A = V^T read with ds_read_b64_tr_b16 from the row-major
+//                              V tile, in the accumulator's permuted key order
+//                              (key = 16s + 8(j>>2) + 4h + (j&3), guide §3 "accumulator tile as operand").
+//
+// Rounding points follow the reference's eager path where that is free: the q pre-scale rounds to bf16
+// (exact for d^-1/2 = 2^-3), the raw score rounds to bf16, the LLM's division by sqrt(d) rounds again,
+// softmax runs in fp32, P rounds to bf16 before P·V, the output rounds to bf16.  (The reference
+// normalises P before rounding; here P is rounded un-normalised and the row is divided at the end.)
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int QB = 128;   // query rows per workgroup
+constexpr int KT = 64;    // keys per tile
+
+template <int D> struct Lay;
+template <> struct Lay<64> {
+  static constexpr int ROWB = 128;
+  // K tile: 32x32 row reads (ds_read_b128) are conflict-free with chunk ^= (row>>1)&7 on 128-B rows
+  __device__ static int kchunk(int row, int ch) { return ch ^ ((row >> 1) & 7); }
+  // V tile: transposed reads take 4 consecutive keys x 64 B per 32-lane half
+  __device__ static int vchunk(int row, int ch) { return ch ^ (((row >> 1) & 1) << 2); }
+};
+template <> struct Lay<128> {
+  static constexpr int ROWB = 256;
+  __device__ static int kchunk(int row, int ch) { return ch ^ (row & 15); }
+  __device__ static int vchunk(int row, int ch) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)); }
+};
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+  constexpr int ROWB = Lay<D>::ROWB;
+  constexpr int CPR = D / 8;                 // 16-byte chunks per row
+  constexpr int NLD = KT * CPR / 256;        // chunks per thread per operand tile (2 for D=64, 4 for D=128)
+  constexpr int NKS = D / 16;                // k-steps of the S^T product
+  constexpr int NDT = D / 32;                // 32-row tiles of O^T
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT * ROWB];
+  char* sK = smem;
+  char* sV = smem + KT * ROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int seq = blockIdx.z, hq = blockIdx.y;
+  const int g = p.n_heads / p.n_kv_heads;
+  const int hk = hq / g;
+  const int row0 = p.cu[seq];
+  const int len = p.cu[seq + 1] - row0;          // queries (= keys appended this call)
+  const int q0 = blockIdx.x * QB;
+  if (q0 >= len) return;
+  const int kv_len = len + p.kv_len_offset;       // keys visible in total (prefill: offset 0)
+  const int qw = q0 + wave * 32;                  // first query row of this wave
+
+  // ---- Q^T fragments: lane (c,h) holds Q[qw+c][16*ks + 8h + j] --------------------------------------
+  bf16x8 qf[NKS];
+  {
+    const int qr = qw + c;
+    const bool ok = qr < len;
+    const bf16_t* qp = p.q + (size_t)(row0 + (ok ? qr : 0)) * p.ldq + (size_t)(hq / g) * p.q_group_stride + (hq % g) * D;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u16x8 raw = *(const u16x8*)(qp + 16 * ks + 8 * h);
+      if (p.q_prescale != 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[e] = f2bf(bf2f(raw[e]) * p.q_prescale);
+      }
+      if (!ok) raw = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8, raw);
+    }
+  }
+
+  // ---- tile range ----------------------------------------------------------------------------------
+  int n_tiles = (kv_len + KT - 1) / KT;
+  if (CAUSAL) {
+    const int last_q = min(q0 + QB, len) - 1 + p.kv_len_offset;   // last visible key index of the block
+    n_tiles = min(n_tiles, last_q / KT + 1);
+  }
+  const bf16_t* kbase = p.k + (size_t)row0 * p.ldk + (size_t)hk * p.kv_head_stride;
+  const bf16_t* vbase = p.v + (size_t)row0 * p.ldv + (size_t)hk * p.kv_head_stride;
+
+  u16x8 kreg[NLD], vreg[NLD];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 256, r = idx / CPR, ch = idx % CPR;
+      const int key = kt * KT + r;
+      if (key < kv_len) {
+        kreg[i] = *(const u16x8*)(kbase + (size_t)key * p.ldk + ch * 8);
+        vreg[i] = *(const u16x8*)(vbase + (size_t)key * p.ldv + ch * 8);
+      } else {
+        kreg[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        vreg[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 256, r = idx / CPR, ch = idx % CPR;
+      *(u16x8*)(sK + r * ROWB + Lay<D>::kchunk(r, ch) * 16) = kreg[i];
+      *(u16x8*)(sV + r * ROWB + Lay<D>::vchunk(r, ch) * 16) = vreg[i];
+    }
+  };
+
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float LOG2E = 1.4426950408889634f;
+
+  // transposed-read lane constants: 16-lane group gi = lane>>4 -> d columns 16*(gi&1).., key rows 4*(gi>>1)..
+  const int li = lane & 15, gi = lane >> 4;
+  const int tr_key = 4 * (gi >> 1) + (li >> 2);       // + 32*st + 16*s + 8*jh
+  const int tr_dcol = 16 * (gi & 1) + 4 * (li & 3);   // + 32*dt
+
+  gload(0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (kt + 1 < n_tiles) gload(kt + 1);
+
+    const int key0 = kt * KT;
+    // wave-uniform skip of tiles that are entirely in this wave's causal future
+    if (CAUSAL && key0 > qw + 31 + p.kv_len_offset) continue;
+
+    // ---- S^T = K · Q^T -------------------------------------------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[st][e] = 0.f;
+      const int kr = st * 32 + c;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(sK + kr * ROWB + Lay<D>::kchunk(kr, 2 * ks + h) * 16);
+        sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[st], 0, 0, 0);
+      }
+    }
+
+    // ---- scores: bf16 rounding points, mask, online softmax -----------------------------------------
+    const int qpos = qw + c + p.kv_len_offset;   // index of the last key this query may see (causal)
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = key0 + st * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float s = rbf(sacc[st][e]);
+        if (p.post_div != 1.0f) s = rbf(s / p.post_div);
+        const bool vis = key < kv_len && (!CAUSAL || key <= qpos);
+        s = vis ? s : -INFINITY;
+        sacc[st][e] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    // rows with no visible key yet keep m = -inf; guard the exp arguments
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f((m_run - m_use) * LOG2E);   // m_run = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = exp2f((sacc[st][e] - m_use) * LOG2E);
+        psum += pv;
+        sacc[st][e] = pv;
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+
+    // ---- O^T += V^T · P^T ---------------------------------------------------------------------------
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u16x8 pr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pr[j] = f2bf(sacc[st][8 * s2 + j]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pr);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const int dcol = 32 * dt + tr_dcol;
+          const int k_lo = 32 * st + 16 * s2 + tr_key, k_hi = k_lo + 8;
+          const char* a_lo = sV + k_lo * ROWB + Lay<D>::vchunk(k_lo, dcol >> 3) * 16 + (dcol & 7) * 2;
+          const char* a_hi = sV + k_hi * ROWB + Lay<D>::vchunk(k_hi, dcol >> 3) * 16 + (dcol & 7) * 2;
+          const s16x4 v_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a_lo);
+          const s16x4 v_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)a_hi);
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 vv = {v_lo[0], v_lo[1], v_lo[2], v_lo[3], v_hi[0], v_hi[1], v_hi[2], v_hi[3]};
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[dt], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- normalise and store: lane (c,h) owns O[qw+c][32*dt + 8*(e>>2) + 4h + (e&3)] -------------------------
+  const int qr = qw + c;
+  if (qr < len) {
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    bf16_t* op = p.o + (size_t)(row0 + qr) * p.ldo + (size_t)hq * D;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(oacc[dt][4 * e4 + e] * inv);
+        *(u16x4*)(op + 32 * dt + 8 * e4 + 4 * h) = o;
+      }
+  }
+}
+
+// ---- decode attention: one query per sequence against a KV cache (HBM-bound) -----------------------------
+// grid = (kv heads, sequences); the g query heads of a kv group share each K/V row read.
+// cache layout [seq][kv head][cap][D]; query i of sequence s sees keys 0 .. kv_len-1.
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int ldq, int q_group_stride,
+                                                          const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+                                                          const int32_t* __restrict__ kv_lens, int cap,
+                                                          bf16_t* __restrict__ o, int ldo, float post_div) {
+  // each wave owns keys w, w+4, ...; lane owns 2 (D=128) contiguous dims; partial (m, l, acc) merged via LDS
+  constexpr int EPL = D / 64;
+  __shared__ float s_m[4][G], s_l[4][G], s_acc[4][G][D];
+  const int hk = blockIdx.x, seq = blockIdx.y, n_kv = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kv_len = kv_lens[seq];
+  float qv[G][EPL];
+#pragma unroll
+  for (int j = 0; j < G; ++j)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+      qv[j][e] = bf2f(q[(size_t)seq * ldq + (size_t)hk * q_group_stride + j * D + lane * EPL + e]);
+  float m[G], l[G], acc[G][EPL];
+#pragma unroll
+  for (int j = 0; j < G; ++j) { m[j] = -INFINITY; l[j] = 0.f; for (int e = 0; e < EPL; ++e) acc[j][e] = 0.f; }
+  const bf16_t* kb = kc + ((size_t)seq * n_kv + hk) * cap * D;
+  const bf16_t* vb = vc + ((size_t)seq * n_kv + hk) * cap * D;
+  for (int key = wave; key < kv_len; key += 4) {
+    float kk[EPL], vv[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { kk[e] = bf2f(kb[(size_t)key * D + lane * EPL + e]); vv[e] = bf2f(vb[(size_t)key * D + lane * EPL + e]); }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d += qv[j][e] * kk[e];
+      d = wave_sum(d);
+      float s = rbf(d);
+      if (post_div != 1.0f) s = rbf(s / post_div);
+      const float mn = fmaxf(m[j], s);
+      const float a = __expf(m[j] - mn), pv = __expf(s - mn);
+      l[j] = l[j] * a + pv;
+      const float pb = rbf(pv);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[j][e] = acc[j][e] * a + pb * vv[e];
+      m[j] = mn;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    if (lane == 0) { s_m[wave][j] = m[j]; s_l[wave][j] = l[j]; }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s_acc[wave][j][lane * EPL + e] = acc[j][e];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < G * D; idx += 256) {
+    const int j = idx / D, d = idx % D;
+    float mm = -INFINITY;
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, s_m[w][j]);
+    float ll = 0.f, aa = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      const float sc = (s_m[w][j] == -INFINITY) ? 0.f : __expf(s_m[w][j] - mm);
+      ll += s_l[w][j] * sc;
+      aa += s_acc[w][j][d] * sc;
+    }
+    o[(size_t)seq * ldo + (size_t)(hk * G + j) * D + d] = f2bf(ll > 0.f ? aa / ll : 0.f);
+  }
+}
+
+}  // namespace
+
+const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
+  if (head_dim != 64 && head_dim != 128) return "attention: head_dim must be 64 or 128";
+  if (a.n_seq <= 0 || a.max_len <= 0) return "attention: empty problem";
+  if (a.n_kv_heads <= 0 || a.n_heads % a.n_kv_heads) return "attention: n_heads must be a multiple of n_kv_heads";
+  if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4) || (a.q_group_stride % 8) || (a.kv_head_stride % 8))
+    return "attention: strides must keep 16-byte alignment";
+  if (!a.q || !a.k || !a.v || !a.o || !a.cu) return "attention: null operand";
+  if (a.kv_len_offset != 0) return "attention: prefill kernel needs kv_len_offset == 0";
+  return nullptr;
+}
+
+hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
+  dim3 grid((a.max_len + QB - 1) / QB, a.n_heads, a.n_seq);
+  if (head_dim == 64) {
+    if (a.causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (a.causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_attention_decode(const bf16_t* q, int ldq, int q_group_stride, const bf16_t* kc,
+                                        const bf16_t* vc, const int32_t* kv_lens, int cap, bf16_t* o, int ldo,
+                                        int n_seq, int n_kv, int g, int head_dim, float post_div, hipStream_t s) {
+  if (head_dim != 128) return hipErrorInvalidValue;
+  dim3 grid(n_kv, n_seq);
+#define DEC(G) hipLaunchKernelGGL((attn_decode_kernel<128, G>), grid, dim3(256), 0, s, q, ldq, q_group_stride, kc, vc, kv_lens, cap, o, ldo, post_div)
+  switch (g) {
+    case 1: DEC(1); break;
+    case 2: DEC(2); break;
+    case 4: DEC(4); break;
+    case 6: DEC(6); break;
+    case 8: DEC(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef DEC
+  return hipGetLastError();
+}

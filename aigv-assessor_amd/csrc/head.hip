@@ -1,0 +1,264 @@
+// Skinny (<= 64 rows) weight-streaming GEMM for gfx950, used where the weights are read once per call and the
+// kernel is HBM-bound:  the lm-head on the answer rows with a fused vocabulary argmax
+// (reference: modeling_internlm2.py:1094-1096 + modeling_internvl_chat.py:451-463,488), the q_len = 1 decode
+// steps of generate() (modeling_internlm2.py:1126-1163), the motion projector (M = clips), and the score head
+// (modeling_internvl_chat.py:43-94).
+//
+// One workgroup = 4 waves = one 16-row slab of W (two slabs for SwiGLU); the waves split K four ways, stream
+// their W fragments straight from global memory into MFMA A-operands (no LDS round trip: every weight byte
+// is used once), keep the x fragments (L2-resident) as B-operands, and combine partial sums through LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+enum { SK_STORE = 0, SK_RESID = 1, SK_SWIGLU = 2, SK_GELU = 3, SK_ARGMAX = 4 };
+
+__device__ __forceinline__ unsigned int ord_f32(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int RT, int EPI>
+__global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ x, int ldx, int R,
+                                                     const bf16_t* __restrict__ W, int ldw, int N, int K,
+                                                     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ resid,
+                                                     int ldr, bf16_t* __restrict__ out, int ldo,
+                                                     unsigned long long* __restrict__ packed) {
+  constexpr int NS = (EPI == SK_SWIGLU) ? 2 : 1;   // W slabs per workgroup
+  __shared__ float part[3][NS][RT][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * 16 * NS;
+  const int kper = K / 4, kbeg = wave * kper;      // K % 128 == 0 checked by the launcher
+
+  const bf16_t* wrow[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) wrow[s] = W + (size_t)min(n0 + s * 16 + fr, N - 1) * ldw + kbeg + fq * 8;
+  const bf16_t* xrow[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) xrow[t] = x + (size_t)min(t * 16 + fr, R - 1) * ldx + kbeg + fq * 8;
+
+  f32x4 acc[NS][RT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // 4 k-steps (4 x 16 B per lane per operand) are loaded before their MFMAs so several loads are in flight
+  int k = 0;
+  for (; k + 128 <= kper; k += 128) {
+    bf16x8 wf[4][NS], xf[4][RT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) wf[u][s] = *(const bf16x8*)(wrow[s] + k + 32 * u);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) xf[u][t] = *(const bf16x8*)(xrow[t] + k + 32 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][s], xf[u][t], acc[s][t], 0, 0, 0);
+  }
+  for (; k < kper; k += 32) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const bf16x8 wf = *(const bf16x8*)(wrow[s] + k);
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, *(const bf16x8*)(xrow[t] + k), acc[s][t], 0, 0, 0);
+    }
+  }
+
+  // ---- combine the four K slices: waves 1..3 publish, wave 0 sums in a fixed order -------------------------
+  if (wave > 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[wave - 1][s][t][e][lane] = acc[s][t][e];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[s][t][e] += (part[0][s][t][e][lane] + part[1][s][t][e][lane]) + part[2][s][t][e][lane];
+
+  // lane owns x row r = 16t + fr and W rows n = n0 + 4*fq + e
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const int r = t * 16 + fr;
+    if constexpr (EPI == SK_ARGMAX) {
+      unsigned long long best = 0ull;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + 4 * fq + e;
+        if (n < N) {
+          const unsigned long long key = ((unsigned long long)ord_f32(rbf(acc[0][t][e])) << 32) | (0xFFFFFFFFu - (unsigned)n);
+          best = key > best ? key : best;
+        }
+      }
+      unsigned long long o = __shfl_xor(best, 16, 64); best = o > best ? o : best;
+      o = __shfl_xor(best, 32, 64); best = o > best ? o : best;
+      if (fq == 0 && r < R) atomicMax(packed + r, best);
+    } else if constexpr (EPI == SK_SWIGLU) {
+      if (r < R) {
+        const int n = n0 / 2 + 4 * fq;
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = rbf(acc[0][t][e]), u = rbf(acc[1][t][e]);
+          o[e] = f2bf(rbf(silu_f(g)) * u);
+        }
+        *(u16x4*)(out + (size_t)r * ldo + n) = o;
+      }
+    } else {
+      const int n = n0 + 4 * fq;
+      if (r < R && n < N) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[0][t][e] + (bias ? bf2f(bias[n + e]) : 0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+        if constexpr (EPI == SK_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+        }
+        if constexpr (EPI == SK_RESID) {
+          const u16x4 rr = *(const u16x4*)(resid + (size_t)r * ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rbf(bf2f(rr[e]) + v[e]);
+        }
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *(u16x4*)(out + (size_t)r * ldo + n) = o;
+      }
+    }
+  }
+}
+
+__global__ void unpack_argmax_kernel(const unsigned long long* __restrict__ packed, int64_t* __restrict__ idx,
+                                     float* __restrict__ val, int R) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const unsigned long long p = packed[r];
+  idx[r] = (int64_t)(0xFFFFFFFFu - (unsigned)(p & 0xFFFFFFFFull));
+  if (val) {
+    unsigned int u = (unsigned)(p >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    val[r] = __uint_as_float(u);
+  }
+}
+
+// ---- score head ------------------------------------------------------------------------------------------
+// x = hidden[:, -4, :] (post final norm); if ANY NaN is present in the batch slice the reference applies
+// nan_to_num(nan=0, posinf=1e9, neginf=-1e9) to every row (modeling_internvl_chat.py:469-473); then a chain
+// of Linear+ReLU with a bf16 rounding after each Linear (:82-94).
+__global__ __launch_bounds__(256) void score_head_kernel(const ScoreHeadArgs a) {
+  __shared__ float buf[2][4096];
+  __shared__ int any_nan;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = a.dims[0];
+  if (threadIdx.x == 0) any_nan = 0;
+  __syncthreads();
+  int nan_here = 0;
+  for (int i = threadIdx.x; i < a.B * H; i += 256) {
+    const float v = bf2f(a.x[(size_t)(i / H) * a.ldx + (i % H)]);
+    nan_here |= (v != v);
+  }
+  if (nan_here) atomicOr(&any_nan, 1);
+  __syncthreads();
+  const bool fix = any_nan != 0;
+  for (int i = threadIdx.x; i < H; i += 256) {
+    float v = bf2f(a.x[(size_t)b * a.ldx + i]);
+    if (fix) {
+      if (v != v) v = 0.f;
+      else if (isinf(v)) v = rbf(v > 0 ? 1e9f : -1e9f);
+    }
+    buf[0][i] = v;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int L = 0; L < a.n_layers; ++L) {
+    const int din = a.dims[L], dout = a.dims[L + 1];
+    const bf16_t* w = a.w[L];
+    const bf16_t* bb = a.b[L];
+    for (int o = wave; o < dout; o += 4) {
+      float s = 0.f;
+      for (int i = lane; i < din; i += 64) s += bf2f(w[(size_t)o * din + i]) * buf[cur][i];
+      s = wave_sum(s);
+      if (lane == 0) buf[cur ^ 1][o] = fmaxf(rbf(s + bf2f(bb[o])), 0.f);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (threadIdx.x == 0) a.score[b] = buf[cur][0];
+}
+
+template <int EPI>
+hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
+                         const bf16_t* resid, int ldr, bf16_t* out, int ldo, unsigned long long* packed,
+                         hipStream_t s) {
+  const int ns = (EPI == SK_SWIGLU) ? 2 : 1;
+  const int blocks = (N + 16 * ns - 1) / (16 * ns);
+  const int rt = (R + 15) / 16;
+#define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, EPI>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed)
+  switch (rt) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef GO
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// epi: 0 store(+bias) | 1 residual | 2 swiglu (16-row interleaved w1/w3, out is N/2 wide) | 3 gelu(+bias)
+hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K,
+                                   const bf16_t* bias, const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi,
+                                   hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  if (R > 64 || K % 128 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return hipErrorInvalidValue;
+  if (epi != SK_SWIGLU && N % 4) return hipErrorInvalidValue;
+  if (epi == SK_SWIGLU && N % 32) return hipErrorInvalidValue;
+  switch (epi) {
+    case SK_STORE: return launch_skinny<SK_STORE>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
+    case SK_RESID: return launch_skinny<SK_RESID>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
+    case SK_SWIGLU: return launch_skinny<SK_SWIGLU>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
+    case SK_GELU: return launch_skinny<SK_GELU>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t aigv_launch_lm_head_argmax(const bf16_t* h, int R, int H, const bf16_t* W, int V,
+                                      unsigned long long* packed, int64_t* out_idx, float* out_val, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  if (R > 64 || H % 128) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(packed, 0, sizeof(unsigned long long) * R, s);
+  if (e != hipSuccess) return e;
+  e = launch_skinny<SK_ARGMAX>(h, H, R, W, H, V, H, nullptr, nullptr, 0, nullptr, 0, packed, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(unpack_argmax_kernel, dim3((R + 63) / 64), dim3(64), 0, s, packed, out_idx, out_val, R);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_score_head(const ScoreHeadArgs& a, hipStream_t s) {
+  if (a.B <= 0) return hipSuccess;
+  if (a.n_layers < 1 || a.n_layers > 8) return hipErrorInvalidValue;
+  for (int i = 0; i <= a.n_layers; ++i)
+    if (a.dims[i] <= 0 || a.dims[i] > 4096) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(score_head_kernel, dim3(a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}

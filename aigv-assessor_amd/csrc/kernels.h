@@ -1,0 +1,98 @@
+// Internal launcher declarations (C++ side of the library; the public C ABI is include/aigv_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+// ---- GEMM ---------------------------------------------------------------------------------------
+enum GemmEpilogue {
+  EPI_STORE = 0,     // C = bf16(acc + bias?)
+  EPI_GELU = 1,      // C = bf16(gelu_erf(bf16(acc + bias?)))
+  EPI_LS_RESID = 2,  // C = bf16(resid + bf16(bf16(acc + bias?) * ls))
+  EPI_RESID = 3,     // C = bf16(resid + bf16(acc + bias?))
+  EPI_SWIGLU = 4,    // W = 16-row interleave of (w1, w3); C[M, N/2] = bf16(bf16(silu(bf16(g))) * bf16(u))
+  EPI_PATCH = 5,     // patch-embed: C[m + m/np + 1] = bf16(bf16(acc + bias) + pos[m % np + 1])
+  EPI_COUNT = 6
+};
+
+struct GemmArgs {
+  const bf16_t* A; int lda;     // activations [M, K], row stride lda
+  const bf16_t* W; int ldw;     // weights [N, K] (nn.Linear layout), row stride ldw
+  bf16_t* C; int ldc;           // output, row stride ldc
+  const bf16_t* bias;           // [N] or null
+  const bf16_t* ls;             // [N] layer-scale (EPI_LS_RESID)
+  const bf16_t* resid; int ldr; // residual [M, N]
+  const bf16_t* pos;            // [np+1, N] position table (EPI_PATCH)
+  int M, N, K;
+  int np;                       // patches per frame (EPI_PATCH)
+};
+
+const char* aigv_gemm_check(const GemmArgs& a, int epi);   // nullptr if the shapes fit the kernel
+hipError_t aigv_launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+
+// ---- attention ------------------------------------------------------------------------------------
+// Packed varlen layout: sequence s occupies rows cu[s] .. cu[s+1]-1 of the token-major buffers.
+// q/k/v point at column 0 of head 0 of their operand inside a (possibly fused) row:
+//   q head hq  at column (hq / g) * q_group_stride + (hq % g) * D        (g = n_heads / n_kv_heads)
+//   kv head hk at column hk * kv_head_stride
+struct AttnArgs {
+  const bf16_t* q; int ldq;
+  const bf16_t* k; int ldk;
+  const bf16_t* v; int ldv;
+  bf16_t* o; int ldo;           // [tokens, n_heads*D]
+  const int32_t* cu;            // [n_seq+1] cumulative lengths (device)
+  int n_seq, max_len;
+  int n_heads, n_kv_heads;
+  int q_group_stride, kv_head_stride;
+  int kv_len_offset;            // must be 0 for the prefill kernel
+  int causal;
+  float post_div;               // score = bf16(bf16(q.k) / post_div)  (LLM: sqrt(d); ViT: 1, q is pre-scaled)
+  float q_prescale;             // q <- bf16(q * q_prescale)           (ViT: d^-1/2; LLM: 1)
+};
+const char* aigv_attn_check(const AttnArgs& a, int head_dim);
+hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s);
+// decode: one query row per sequence (fused qkv row), KV cache [seq][kv head][cap][D]
+hipError_t aigv_launch_attention_decode(const bf16_t* q, int ldq, int q_group_stride, const bf16_t* kc,
+                                        const bf16_t* vc, const int32_t* kv_lens, int cap, bf16_t* o, int ldo,
+                                        int n_seq, int n_kv, int g, int head_dim, float post_div, hipStream_t s);
+
+// ---- row-wise / elementwise ---------------------------------------------------------------------
+// LayerNorm over rows of length H (fp32 statistics, bf16 out).
+hipError_t aigv_launch_layernorm(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int ldy,
+                                 int rows, int H, float eps, hipStream_t s);
+// RMSNorm (fp32 normalise -> bf16 -> * weight -> bf16).  row_idx (optional) gathers input rows.
+hipError_t aigv_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int H,
+                               float eps, const int32_t* row_idx, hipStream_t s);
+// cls drop + pixel-shuffle v2 gather (pre-projector tokens; the frame-DP all-gather payload)
+hipError_t aigv_launch_pixel_shuffle(const bf16_t* vit, int grid, int Hv, bf16_t* out, int frames, hipStream_t s);
+// im2col for the patch-embed GEMM: frames NCHW bf16 -> [F*g*g, Kp] (k = c*P*P + py*P + px, zero padded)
+hipError_t aigv_launch_im2col(const bf16_t* frames, int F, int C, int S, int P, int Kp, bf16_t* out, hipStream_t s);
+// x[f*(np+1)] = cls_pos (class token + its position row, precomputed) for every frame
+hipError_t aigv_launch_cls_rows(const bf16_t* cls_pos, bf16_t* x, int F, int tokens_per_frame, int H, hipStream_t s);
+// RoPE in place on the fused qkv rows: per kv group, slots 0..g (q heads and K) are rotated.
+hipError_t aigv_launch_rope(bf16_t* qkv, int ld, const int32_t* pos, const bf16_t* cos, const bf16_t* sin,
+                            int tokens, int n_rot_heads_per_group, int slots_per_group, int n_groups, int D,
+                            hipStream_t s);
+// token embedding + visual/motion scatter: slot[t] < 0 -> tok_emb[ids[t]]; < n_vis -> vis[slot]; else motion
+hipError_t aigv_launch_embed(const int64_t* ids, const int32_t* slot, const bf16_t* emb, const bf16_t* vis,
+                             const bf16_t* motion, int n_vis, bf16_t* out, int tokens, int H, hipStream_t s);
+// skinny (R <= 64) weight-streaming GEMM; epi: 0 store(+bias) 1 residual 2 swiglu 3 gelu(+bias)
+hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K,
+                                   const bf16_t* bias, const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi,
+                                   hipStream_t s);
+// lm-head on R gathered rows + argmax over the vocabulary (first maximal index, bf16-rounded logits)
+hipError_t aigv_launch_lm_head_argmax(const bf16_t* h, int R, int H, const bf16_t* W, int V,
+                                      unsigned long long* packed, int64_t* out_idx, float* out_val, hipStream_t s);
+// score head: x[B,H] -> chain of Linear+ReLU (bf16 rounding after each Linear), NaN/Inf guard on x
+struct ScoreHeadArgs {
+  const bf16_t* x; int ldx; int B;
+  int n_layers; int dims[9];            // dims[0] = H, dims[i+1] = out of layer i
+  const bf16_t* w[8]; const bf16_t* b[8];
+  float* score;                         // [B] (the bf16 result widened to fp32)
+};
+hipError_t aigv_launch_score_head(const ScoreHeadArgs& a, hipStream_t s);
+// KV-cache append for decode: copies the K/V slots of fused qkv rows into [n_seq, n_kv, cap, D] caches
+hipError_t aigv_launch_kv_store(const bf16_t* qkv, int ld, const int32_t* seq_of_tok, const int32_t* pos,
+                                bf16_t* kc, bf16_t* vc, int tokens, int n_groups, int g, int D, int cap,
+                                hipStream_t s);

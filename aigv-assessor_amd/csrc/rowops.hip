@@ -1,0 +1,252 @@
+// Row-wise and element-wise kernels of the scorer hot path (all HBM-bound: 16-byte vector accesses,
+// fp32 statistics, bf16 rounding points as in the reference's eager path).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXC = 8;  // 16-byte chunks per thread (256 threads) -> rows up to 16384 elements
+
+// ---- LayerNorm -----------------------------------------------------------------------------------------
+// reference: nn.LayerNorm in InternVisionEncoderLayer (modeling_intern_vit.py:208-209) and as the first
+// stage of mlp1 / motion_mlp (modeling_internvl_chat.py:238-249).  fp32 statistics, one bf16 rounding.
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                        const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                        bf16_t* __restrict__ y, int ldy, int H, float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int nchunk = H >> 3;
+  float v[MAXC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      const u16x8 raw = *(const u16x8*)(x + (size_t)row * ldx + (ch << 3));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[c][e] = bf2f(raw[e]); sum += v[c][e]; }
+    }
+  }
+  const float mean = block_sum_256(sum, red) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    if (threadIdx.x + c * 256 < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(block_sum_256(sq, red) / (float)H + eps);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      const u16x8 ww = *(const u16x8*)(w + (ch << 3));
+      const u16x8 bb = *(const u16x8*)(b + (ch << 3));
+      u16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf((v[c][e] - mean) * rstd * bf2f(ww[e]) + bf2f(bb[e]));
+      *(u16x8*)(y + (size_t)row * ldy + (ch << 3)) = o;
+    }
+  }
+}
+
+// ---- RMSNorm: fp32 normalise -> bf16 -> * weight -> bf16 (modeling_internlm2.py:138-143) --------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                      const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int ldy,
+                                                      int H, float eps, const int32_t* __restrict__ row_idx) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int srow = row_idx ? row_idx[row] : row;
+  const int nchunk = H >> 3;
+  float v[MAXC][8];
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      const u16x8 raw = *(const u16x8*)(x + (size_t)srow * ldx + (ch << 3));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[c][e] = bf2f(raw[e]); sq += v[c][e] * v[c][e]; }
+    }
+  }
+  const float rstd = rsqrtf(block_sum_256(sq, red) / (float)H + eps);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      const u16x8 ww = *(const u16x8*)(w + (ch << 3));
+      u16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(ww[e]) * rbf(v[c][e] * rstd));
+      *(u16x8*)(y + (size_t)row * ldy + (ch << 3)) = o;
+    }
+  }
+}
+
+// ---- drop cls + pixel_shuffle v2 (modeling_internvl_chat.py:492-506,520-527): pre-projector tokens -------
+// out token (i2, j2) of frame f = concat over (di, dj) of vit[f, 1 + (2*i2+di)*grid + 2*j2+dj, :]
+__global__ void pixel_shuffle_kernel(const bf16_t* __restrict__ vit, int grid, int Hv, bf16_t* __restrict__ out,
+                                     int rows) {
+  const int cpr = (4 * Hv) >> 3;  // chunks per output row
+  const size_t total = (size_t)rows * cpr;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / cpr), ch = (int)(i - (size_t)row * cpr);
+    const int g2 = grid >> 1, per = g2 * g2;
+    const int f = row / per, t = row - f * per, i2 = t / g2, j2 = t - i2 * g2;
+    const int col = ch << 3, part = col / Hv, di = part >> 1, dj = part & 1;
+    const size_t tok = (size_t)f * (grid * grid + 1) + 1 + (size_t)(2 * i2 + di) * grid + (2 * j2 + dj);
+    *(u16x8*)(out + (size_t)row * 4 * Hv + col) = *(const u16x8*)(vit + tok * Hv + (col - part * Hv));
+  }
+}
+
+// ---- im2col for Conv2d(C, Hv, k=P, s=P) (modeling_intern_vit.py:78-80,97) -------------------------------
+// out[(f*g + py)*g + px][c*P*P + iy*P + ix] = frames[f][c][py*P + iy][px*P + ix]; columns >= C*P*P are 0.
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ frames, int C, int S, int P, int Kp,
+                                                     bf16_t* __restrict__ out) {
+  const int g = S / P;
+  const int patch = blockIdx.x;            // f*g*g + py*g + px
+  const int f = patch / (g * g), r = patch - f * g * g, py = r / g, px = r - py * g;
+  const int K = C * P * P;
+  for (int k = threadIdx.x; k < Kp; k += 256) {
+    bf16_t val = 0;
+    if (k < K) {
+      const int c = k / (P * P), rr = k - c * P * P, iy = rr / P, ix = rr - iy * P;
+      val = frames[(((size_t)f * C + c) * S + (py * P + iy)) * S + (px * P + ix)];
+    }
+    out[(size_t)patch * Kp + k] = val;
+  }
+}
+
+__global__ void cls_rows_kernel(const bf16_t* __restrict__ cls_pos, bf16_t* __restrict__ x, int tokens_per_frame,
+                                int H) {
+  const int f = blockIdx.x;
+  for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x)
+    *(u16x8*)(x + (size_t)f * tokens_per_frame * H + (c << 3)) = *(const u16x8*)(cls_pos + (c << 3));
+}
+
+// ---- RoPE in place (modeling_internlm2.py:247-261): out = bf16(bf16(x*cos) + bf16(rot(x)*sin)) ---------
+// qkv row layout: n_groups x slots_per_group x D; slots [0, n_rot) of every group are rotated (q heads + K).
+// cos/sin tables are [max_pos, D/2] bf16 (the second half of the reference's table repeats the first).
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int ld, const int32_t* __restrict__ pos,
+                                                   const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn,
+                                                   int tokens, int n_rot, int slots, int n_groups, int D) {
+  const int half = D >> 1, cph = half >> 3;            // 16-byte chunks per half head
+  const int per_tok = n_groups * n_rot * cph;
+  const size_t total = (size_t)tokens * per_tok;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i / per_tok);
+    int r = (int)(i - (size_t)t * per_tok);
+    const int c = r % cph; r /= cph;
+    const int s = r % n_rot, gidx = r / n_rot;
+    bf16_t* base = qkv + (size_t)t * ld + (size_t)(gidx * slots + s) * D + (c << 3);
+    const size_t tb = (size_t)pos[t] * half + (c << 3);
+    const u16x8 lo = *(const u16x8*)base, hi = *(const u16x8*)(base + half);
+    const u16x8 co = *(const u16x8*)(cs + tb), si = *(const u16x8*)(sn + tb);
+    u16x8 olo, ohi;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x1 = bf2f(lo[e]), x2 = bf2f(hi[e]), cc = bf2f(co[e]), ss = bf2f(si[e]);
+      olo[e] = f2bf(rbf(x1 * cc) + rbf(-x2 * ss));
+      ohi[e] = f2bf(rbf(x2 * cc) + rbf(x1 * ss));
+    }
+    *(u16x8*)base = olo;
+    *(u16x8*)(base + half) = ohi;
+  }
+}
+
+// ---- token embedding gather + visual / motion scatter (modeling_internvl_chat.py:324,351-378) ------------
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ slot,
+                                                    const bf16_t* __restrict__ emb, const bf16_t* __restrict__ vis,
+                                                    const bf16_t* __restrict__ motion, int n_vis,
+                                                    bf16_t* __restrict__ out, int H) {
+  const int t = blockIdx.x;
+  const int s = slot[t];
+  const bf16_t* src = s < 0 ? emb + (size_t)ids[t] * H : (s < n_vis ? vis + (size_t)s * H : motion + (size_t)(s - n_vis) * H);
+  for (int c = threadIdx.x; c < (H >> 3); c += 256)
+    *(u16x8*)(out + (size_t)t * H + (c << 3)) = *(const u16x8*)(src + (c << 3));
+}
+
+// ---- KV cache append -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kv_store_kernel(const bf16_t* __restrict__ qkv, int ld,
+                                                       const int32_t* __restrict__ seq_of_tok,
+                                                       const int32_t* __restrict__ pos, bf16_t* __restrict__ kc,
+                                                       bf16_t* __restrict__ vc, int n_groups, int g, int D, int cap) {
+  const int t = blockIdx.x;
+  const int sq = seq_of_tok[t], p = pos[t];
+  const int cpd = D >> 3;
+  for (int i = threadIdx.x; i < n_groups * 2 * cpd; i += 256) {
+    const int c = i % cpd, r = i / cpd, which = r & 1, h = r >> 1;
+    const bf16_t* src = qkv + (size_t)t * ld + (size_t)(h * (g + 2) + g + which) * D + (c << 3);
+    bf16_t* dst = (which ? vc : kc) + (((size_t)sq * n_groups + h) * cap + p) * D + (c << 3);
+    *(u16x8*)dst = *(const u16x8*)src;
+  }
+}
+
+}  // namespace
+
+hipError_t aigv_launch_layernorm(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int ldy,
+                                 int rows, int H, float eps, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (H % 8 || H > MAXC * 256 * 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, b, y, ldy, H, eps);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int H,
+                               float eps, const int32_t* row_idx, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (H % 8 || H > MAXC * 256 * 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, y, ldy, H, eps, row_idx);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_pixel_shuffle(const bf16_t* vit, int grid, int Hv, bf16_t* out, int frames, hipStream_t s) {
+  if (frames <= 0) return hipSuccess;
+  if (Hv % 8 || grid % 2) return hipErrorInvalidValue;
+  const int rows = frames * (grid / 2) * (grid / 2);
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(2048), dim3(256), 0, s, vit, grid, Hv, out, rows);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_im2col(const bf16_t* frames, int F, int C, int S, int P, int Kp, bf16_t* out, hipStream_t s) {
+  if (F <= 0) return hipSuccess;
+  if (S % P || Kp < C * P * P) return hipErrorInvalidValue;
+  const int g = S / P;
+  hipLaunchKernelGGL(im2col_kernel, dim3(F * g * g), dim3(256), 0, s, frames, C, S, P, Kp, out);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_cls_rows(const bf16_t* cls_pos, bf16_t* x, int F, int tokens_per_frame, int H, hipStream_t s) {
+  if (F <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cls_rows_kernel, dim3(F), dim3(128), 0, s, cls_pos, x, tokens_per_frame, H);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_rope(bf16_t* qkv, int ld, const int32_t* pos, const bf16_t* cos, const bf16_t* sin,
+                            int tokens, int n_rot, int slots, int n_groups, int D, hipStream_t s) {
+  if (tokens <= 0) return hipSuccess;
+  if (D % 16) return hipErrorInvalidValue;
+  const size_t total = (size_t)tokens * n_groups * n_rot * (D / 16);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, s, qkv, ld, pos, cos, sin, tokens, n_rot, slots,
+                     n_groups, D);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_embed(const int64_t* ids, const int32_t* slot, const bf16_t* emb, const bf16_t* vis,
+                             const bf16_t* motion, int n_vis, bf16_t* out, int tokens, int H, hipStream_t s) {
+  if (tokens <= 0) return hipSuccess;
+  if (H % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_kernel, dim3(tokens), dim3(256), 0, s, ids, slot, emb, vis, motion, n_vis, out, H);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_kv_store(const bf16_t* qkv, int ld, const int32_t* seq_of_tok, const int32_t* pos,
+                                bf16_t* kc, bf16_t* vc, int tokens, int n_groups, int g, int D, int cap,
+                                hipStream_t s) {
+  if (tokens <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kv_store_kernel, dim3(tokens), dim3(256), 0, s, qkv, ld, seq_of_tok, pos, kc, vc, n_groups, g, D,
+                     cap);
+  return hipGetLastError();
+}

@@ -1,0 +1,668 @@
+"""Host-side mirror of the reference's ``InternVLChatModel`` over the gfx950 C-ABI library.
+
+Same class name, constructor, attributes and method signatures as
+internvl/model/internvl_chat_eval2/modeling_internvl_chat.py:195-853 (stage-2 flavour; ``stage=1`` gives
+internvl_chat_eval1's return dict), so ``stage{1,2}_eval.py`` call sites run unchanged:
+
+    model = InternVLChatModel.from_pretrained(path, torch_dtype=torch.bfloat16, config=cfg)
+    model.img_context_token_id = ...; model.eval(); model.cuda()
+    out = model(mos=..., pixel_values=..., input_ids=..., attention_mask=..., image_flags=..., labels=...)
+    out['score1'], out['logit'], out['label']
+
+PyTorch is used for tensor containers, weight (de)serialisation and index bookkeeping only; every FLOP of
+the hot path runs in ``libaigv_amd.so``.  There is no CPU / eager fallback: without the library or a GPU the
+hot-path methods raise.
+
+Documented deviations from the reference (all outside what its eval scripts exercise):
+  * ``logit`` holds argmax ids only at positions whose shifted label is not -100 (the answer rows the eval
+    slices, stage2_eval.py:940-941); other positions are -1 unless ``full_logits=True``.
+  * the score row ``hidden[:, -4]`` is taken relative to each clip's true (un-padded) end.
+  * a visual-token count mismatch raises instead of overwriting a prefix (modeling_internvl_chat.py:381-386).
+  * the SlowFast motion branch is an input: pass ``motion_feature=[B, 2304]`` or set ``slowfast_model`` to a
+    callable with the reference's interface (pytorchvideo is an un-vendored third-party dependency).
+  * ``generate`` is greedy (the reference defers to HF ``generate``; its eval configs use do_sample=False).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import warnings
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import native, synth
+from .config import InternVLChatConfig
+from .conversation import get_conv_template
+
+
+# ------------------------------------------------------------------------------------------------------
+# host-side weight preparation (not on the hot path: runs once per weight upload)
+# ------------------------------------------------------------------------------------------------------
+def rope_tables(head_dim: int, theta: float, n_pos: int, max_pos: int = 32768, scaling: Optional[dict] = None):
+    """cos/sin [n_pos, head_dim/2] bf16, computed as the reference does (modeling_internlm2.py:161-243):
+    fp32 inv_freq and angles, cos/sin in fp32, then cast to the activation dtype.  The reference table is
+    cat(freqs, freqs) so only the first half is stored.  Dynamic-NTK rescaling engages only past
+    max_position_embeddings (:230-235)."""
+    base = float(theta)
+    if scaling is not None and scaling.get("type") == "dynamic" and n_pos > max_pos:
+        f = float(scaling["factor"])
+        base = base * ((f * n_pos / max_pos) - (f - 1)) ** (head_dim / (head_dim - 2))
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    t = torch.arange(n_pos).to(inv_freq.dtype)
+    if scaling is not None and scaling.get("type") == "linear":
+        t = t / float(scaling["factor"])
+    freqs = torch.outer(t, inv_freq)
+    return freqs.cos().to(torch.bfloat16).contiguous(), freqs.sin().to(torch.bfloat16).contiguous()
+
+
+def resized_pos_table(pos: torch.Tensor, base_grid: int, grid: int) -> torch.Tensor:
+    """Position table for a ``grid x grid`` patch grid (modeling_intern_vit.py:87-93,102-105): class row
+    as-is, patch rows bicubic-resized in fp32 (align_corners=False) and cast back.  Precomputed once per
+    upload instead of on every forward; at the native grid it is the identity."""
+    pos = pos.detach().to("cpu")
+    dt = pos.dtype
+    patch = pos[:, 1:, :].float().reshape(1, base_grid, base_grid, -1).permute(0, 3, 1, 2)
+    patch = F.interpolate(patch, size=(grid, grid), mode="bicubic", align_corners=False)
+    patch = patch.reshape(1, -1, grid * grid).permute(0, 2, 1).to(dt)
+    return torch.cat([pos[:, :1, :], patch], dim=1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------
+# parameter containers with the reference's module paths (so state_dict keys match §8a row W)
+# ------------------------------------------------------------------------------------------------------
+class _Node(nn.Module):
+    """Parameter holder; children are added under their reference names."""
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+
+class _VisionModel(_Node):
+    """``model.vision_model`` surface used by the drivers (modeling_intern_vit.py:297-323)."""
+
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+
+    def resize_pos_embeddings(self, old_size, new_size, patch_size):
+        # modeling_intern_vit.py:309-319 (weight surgery, host side)
+        emb = self.embeddings
+        pos = emb.position_embedding.data
+        new = resized_pos_table(pos, old_size // patch_size, new_size // patch_size).to(pos.device)
+        emb.position_embedding = nn.Parameter(new, requires_grad=False)
+        self._owner.config.vision_config.image_size = new_size
+        self._owner._invalidate()
+
+    def get_input_embeddings(self):
+        return self.embeddings
+
+
+class _LanguageModel(_Node):
+    """``model.language_model`` surface (modeling_internlm2.py:1016-1032 + HF resize_token_embeddings)."""
+
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+
+    @property
+    def config(self):
+        return self._owner.config.llm_config
+
+    def get_input_embeddings(self):
+        return self.model.tok_embeddings
+
+    def get_output_embeddings(self):
+        return self.output
+
+    def resize_token_embeddings(self, n: int):
+        for node in (self.model.tok_embeddings, self.output):
+            old = node.weight.data
+            new = torch.zeros((n, old.shape[1]), dtype=old.dtype, device=old.device)
+            new[: min(n, old.shape[0])] = old[: min(n, old.shape[0])]
+            if n > old.shape[0]:
+                new[old.shape[0]:].normal_(0.0, self.config.initializer_range)
+            node.weight = nn.Parameter(new, requires_grad=False)
+        self.config.vocab_size = n
+        self._owner._invalidate()
+        return self.model.tok_embeddings
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor):
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+# ------------------------------------------------------------------------------------------------------
+class InternVLChatModel(nn.Module):
+    main_input_name = "pixel_values"
+
+    def __init__(self, config: InternVLChatConfig, vision_model=None, language_model=None, use_flash_attn=True,
+                 device=None, dtype=torch.bfloat16, stage: int = 2, max_clips: int = 4, max_frames: Optional[int] = None,
+                 max_new_tokens: int = 0):
+        super().__init__()
+        if vision_model is not None or language_model is not None:
+            raise NotImplementedError("pass weights through load_state_dict / from_pretrained")
+        if config.llm_config.architectures[0] != "InternLM2ForCausalLM":
+            # same restriction as the reference ctor accepts Llama too (modeling_internvl_chat.py:228-233);
+            # only InternLM2 is on this hot path
+            raise NotImplementedError(f"{config.llm_config.architectures[0]} is not implemented.")
+        if dtype != torch.bfloat16:
+            raise NotImplementedError("the gfx950 path computes in bf16 (the reference eval dtype, stage2_eval.py:780)")
+        self.config = config
+        self.stage = stage
+        self.patch_size = config.vision_config.patch_size
+        self.select_layer = config.select_layer
+        self.template = config.template
+        self.num_image_token = config.num_image_token
+        self.downsample_ratio = config.downsample_ratio
+        self.ps_version = config.ps_version
+        if self.ps_version != "v2":
+            raise NotImplementedError("only ps_version 'v2' (the shipped config) is on the hot path")
+        self.llm_arch_name = config.llm_config.architectures[0]
+        self.img_context_token_id = None
+        self.conv_template = get_conv_template(self.template)
+        self.system_message = self.conv_template.system_message
+        self.slowfast_model = None          # optional callable([slow, fast]) -> [B, 2304, 1, 1, 1]
+        self._max_clips, self._max_frames, self._max_new = max_clips, max_frames, max_new_tokens
+        self._ctx = None
+        self._ctx_key = None
+        self._dirty = True
+
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.vision_model = _VisionModel(self)
+        self.language_model = _LanguageModel(self)
+        for name, shape, _kind in synth.weight_shapes(config):
+            if stage == 1 and name.startswith("mlpscore."):
+                continue
+            root, rest = name.split(".", 1)
+            if root not in self._modules:
+                self.add_module(root, _Node())
+            _attach(self._modules[root], rest, torch.empty(shape, dtype=dtype, device=dev))
+
+    # ---- construction / (de)serialisation ----------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path, torch_dtype=torch.bfloat16, config: Optional[InternVLChatConfig] = None, **kw):
+        """Load ``config.json`` + ``*.safetensors`` / ``pytorch_model*.bin`` shards with the reference's
+        state-dict names (stage2_eval.py:779-780).  SlowFast weights (``slowfast_model.*``) are ignored."""
+        if config is None:
+            config = InternVLChatConfig.from_pretrained(path)
+        model = cls(config, dtype=torch_dtype, **kw)
+        sd: Dict[str, torch.Tensor] = {}
+        files = sorted(os.listdir(path))
+        for f in files:
+            fp = os.path.join(path, f)
+            if f.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                sd.update(load_file(fp))
+            elif f.endswith(".bin") or f.endswith(".pth") or f.endswith(".pt"):
+                sd.update(torch.load(fp, map_location="cpu", weights_only=True))
+        if not sd:
+            raise FileNotFoundError(f"no weight shards found under {path}")
+        model.load_state_dict(sd)
+        return model
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("slowfast_model.")}
+        if self.stage == 1:
+            sd = {k: v for k, v in sd.items() if not k.startswith("mlpscore.")}
+        own = dict(self.named_parameters())
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]}{'...' if len(missing) > 5 else ''}, "
+                               f"unexpected {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+        with torch.no_grad():
+            for k, p in own.items():
+                if k in sd:
+                    if tuple(sd[k].shape) != tuple(p.shape):
+                        raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(p.shape)}")
+                    p.copy_(sd[k].to(p.dtype))
+        self._invalidate()
+        return missing, unexpected
+
+    def _apply(self, fn, *a, **k):  # .cuda() / .to(): weights move, the native copy must follow
+        out = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return out
+
+    def _invalidate(self):
+        self._dirty = True
+
+    @property
+    def device(self):
+        return self.mlp1._modules["1"].weight.device
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    # ---- native context ---------------------------------------------------------------------------------
+    def _native(self, n_frames: int = 0, n_tokens: int = 0, n_clips: int = 0, out_rows: int = 0, kv_cap: int = 0):
+        """Create (or grow) the native context and upload weights if they changed."""
+        if self.device.type != "cuda":
+            raise native.NativeError("the scorer hot path runs on an MI355X only: move the model with .cuda() "
+                                     "(there is no CPU fallback)")
+        lib = native.load()
+        cfg, v, l = self.config, self.config.vision_config, self.config.llm_config
+        key = getattr(self, "_cap", None) or dict(frames=0, tokens=0, clips=0, rows=0, kv=0)
+        want = dict(frames=max(key["frames"], n_frames, self._max_frames or 0, 1),
+                    tokens=max(key["tokens"], n_tokens, 1), clips=max(key["clips"], n_clips, self._max_clips, 1),
+                    rows=max(key["rows"], out_rows, 64), kv=max(key["kv"], kv_cap))
+        geom = (v.image_size if cfg.force_image_size is None else cfg.force_image_size, v.hidden_size, l.vocab_size,
+                self.select_layer)
+        if self._ctx is None or want != key or geom != self._ctx_key:
+            if self._ctx is not None:
+                lib.aigv_ctx_destroy(self._ctx)
+                self._ctx = None
+            c = native.AigvConfig()
+            c.vit_hidden, c.vit_inter, c.vit_heads, c.vit_layers = v.hidden_size, v.intermediate_size, v.num_attention_heads, v.num_hidden_layers
+            c.image_size, c.patch_size, c.num_channels = cfg.image_size, v.patch_size, v.num_channels
+            c.vit_norm_rms = 1 if v.norm_type == "rms_norm" else 0
+            c.vit_qk_norm, c.vit_qkv_bias, c.vit_eps = int(v.qk_normalization), int(v.qkv_bias), v.layer_norm_eps
+            c.select_layer, c.shuffle = self.select_layer, int(round(1 / cfg.downsample_ratio))
+            c.llm_hidden, c.llm_inter, c.llm_heads, c.llm_kv_heads = l.hidden_size, l.intermediate_size, l.num_attention_heads, l.num_key_value_heads
+            c.llm_layers, c.vocab, c.rms_eps = l.num_hidden_layers, l.vocab_size, l.rms_norm_eps
+            c.max_positions = max(want["tokens"], want["kv"], 64)
+            c.motion_dim = cfg.motion_dim
+            dims = list(cfg.score_dims) if self.stage == 2 else [1]
+            c.n_score_layers = len(dims)
+            for i, d in enumerate(dims):
+                c.score_dims[i] = d
+            c.max_frames = want["frames"]
+            c.vit_chunk = min(want["frames"], 64)
+            c.max_tokens, c.max_seqs, c.max_out_rows, c.kv_capacity = want["tokens"], want["clips"], want["rows"], want["kv"]
+            h = C.c_void_p()
+            native.check(lib.aigv_ctx_create(self.device.index or 0, C.byref(c), C.byref(h)))
+            self._ctx, self._cap, self._ctx_key, self._dirty = h, want, geom, True
+            self._n_pos = c.max_positions
+        if self._dirty:
+            self._upload()
+        return lib, self._ctx
+
+    def _upload(self):
+        lib, ctx = native.load(), self._ctx
+        cfg, v, l = self.config, self.config.vision_config, self.config.llm_config
+
+        def put(name, t):
+            t = t.detach()
+            if t.dtype != torch.bfloat16:
+                t = t.to(torch.bfloat16)
+            t = t.contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            native.check(lib.aigv_load_weight(ctx, name.encode(), t.data_ptr(), shape, t.dim(), 0, int(t.is_cuda)), ctx)
+
+        for name, p in self.named_parameters():
+            if name.startswith("mlpscore.ln1"):
+                continue  # present in the reference state-dict, unused by its forward (:55,85)
+            if name == "vision_model.embeddings.position_embedding":
+                put(name, resized_pos_table(p.data, v.image_size // v.patch_size, cfg.image_size // v.patch_size))
+            else:
+                put(name, p.data)
+        if self.stage == 1:  # stage-1 flavour has no score head: a 1-wide dummy keeps the ABI uniform
+            put("mlpscore.fc1.weight", torch.zeros(1, l.hidden_size, dtype=torch.bfloat16))
+            put("mlpscore.fc1.bias", torch.zeros(1, dtype=torch.bfloat16))
+        cos, sin = rope_tables(l.head_dim, l.rope_theta, self._n_pos, l.max_position_embeddings, l.rope_scaling)
+        put("rope.cos", cos)
+        put("rope.sin", sin)
+        native.check(lib.aigv_finalize_weights(ctx), ctx)
+        self._dirty = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None) is not None:
+                native.load().aigv_ctx_destroy(self._ctx)
+        except Exception:
+            pass
+
+    # ---- hot path -----------------------------------------------------------------------------------------
+    def vit_tokens(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """InternViT -> drop cls -> pixel-shuffle: [F,3,S,S] -> [F, ntok, 4*Hv] pre-projector tokens (the
+        frame-DP all-gather payload; modeling_internvl_chat.py:509-527)."""
+        if pixel_values.dim() != 4:
+            raise ValueError(f"wrong pixel_values size: {pixel_values.shape}")  # modeling_intern_vit.py:345
+        nf = pixel_values.shape[0]
+        S = self.config.image_size
+        if tuple(pixel_values.shape[1:]) != (self.config.vision_config.num_channels, S, S):
+            raise ValueError(f"pixel_values must be [F,{self.config.vision_config.num_channels},{S},{S}], got {tuple(pixel_values.shape)}")
+        lib, ctx = self._native(n_frames=nf)
+        pv = pixel_values.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        out = torch.empty((nf, self.num_image_token, self.config.proj_in), dtype=torch.bfloat16, device=self.device)
+        native.check(lib.aigv_vit_forward(ctx, pv.data_ptr(), nf, out.data_ptr(), native.stream_ptr()), ctx)
+        return out
+
+    def project(self, tokens: torch.Tensor) -> torch.Tensor:
+        """mlp1 on pre-projector tokens [..., 4*Hv] -> [..., H] (modeling_internvl_chat.py:529)."""
+        lib, ctx = self._native()
+        t = tokens.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        rows = t.numel() // t.shape[-1]
+        out = torch.empty(t.shape[:-1] + (self.config.llm_config.hidden_size,), dtype=torch.bfloat16, device=self.device)
+        native.check(lib.aigv_project(ctx, t.data_ptr(), rows, out.data_ptr(), native.stream_ptr()), ctx)
+        return out
+
+    def extract_feature(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """modeling_internvl_chat.py:508-531: [F,3,S,S] -> [F, num_image_token, llm_hidden]."""
+        return self.project(self.vit_tokens(pixel_values))
+
+    def motion_embed(self, motion_feature: torch.Tensor) -> torch.Tensor:
+        """motion_mlp on the SlowFast feature [B, motion_dim] -> [B, H] (modeling_internvl_chat.py:344-345)."""
+        b = motion_feature.shape[0]
+        lib, ctx = self._native(n_clips=b)
+        m = motion_feature.reshape(b, -1).to(device=self.device, dtype=torch.bfloat16).contiguous()
+        if m.shape[1] != self.config.motion_dim:
+            raise ValueError(f"motion_feature must be [B,{self.config.motion_dim}]")
+        out = torch.empty((b, self.config.llm_config.hidden_size), dtype=torch.bfloat16, device=self.device)
+        native.check(lib.aigv_motion_project(ctx, m.data_ptr(), b, out.data_ptr(), native.stream_ptr()), ctx)
+        return out
+
+    def _motion_feature(self, pixel_values, batch, motion_feature):
+        if motion_feature is not None:
+            return motion_feature
+        if self.slowfast_model is None:
+            raise RuntimeError("the SlowFast motion branch is an input of this path: pass motion_feature=[B, "
+                               f"{self.config.motion_dim}] or set model.slowfast_model (SURVEY.md §2 row 6)")
+        # reference data flow (modeling_internvl_chat.py:337-344, pack_pathway_output :97-133)
+        S = self.config.image_size
+        frames = pixel_values.view(batch, pixel_values.shape[0] // batch, 3, S, S).permute(0, 2, 1, 3, 4)
+        idx = torch.linspace(0, frames.shape[2] - 1, frames.shape[2] // 4).long().to(frames.device)
+        with torch.no_grad():
+            return self.slowfast_model([frames.index_select(2, idx), frames]).view(batch, -1)
+
+    @staticmethod
+    def _pack(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]):
+        """Strip padding: returns (packed ids [T], cu_seqlens list, packed-row index of every [b, p] or -1)."""
+        b, n = input_ids.shape
+        mask = torch.ones_like(input_ids, dtype=torch.bool) if attention_mask is None else attention_mask.bool()
+        lens = mask.sum(1).tolist()
+        cu = [0]
+        for x in lens:
+            cu.append(cu[-1] + int(x))
+        row_of = torch.full((b, n), -1, dtype=torch.long, device=input_ids.device)
+        row_of[mask] = torch.arange(cu[-1], device=input_ids.device)
+        return input_ids[mask].contiguous(), cu, row_of
+
+    def _prefill(self, ids_packed, slot, cu, vis, n_vis, motion, score_rows, logit_rows, keep_kv=False, kv_cap=0):
+        b = len(cu) - 1
+        T = cu[-1]
+        lib, ctx = self._native(n_tokens=T, n_clips=b, out_rows=len(logit_rows), kv_cap=kv_cap)
+        dev = self.device
+        ids_d = ids_packed.to(device=dev, dtype=torch.long).contiguous()
+        slot_d = slot.to(device=dev, dtype=torch.int32).contiguous()
+        score = torch.empty(b, dtype=torch.float32, device=dev) if score_rows is not None else None
+        amax = torch.empty(max(len(logit_rows), 1), dtype=torch.long, device=dev)
+        cu_a = native.i32_array(cu)
+        sr_a = native.i32_array(score_rows) if score_rows is not None else None
+        lr_a = native.i32_array(logit_rows) if len(logit_rows) else None
+        native.check(lib.aigv_llm_prefill(
+            ctx, ids_d.data_ptr(), slot_d.data_ptr(), cu_a, b, native.ptr(vis), n_vis, native.ptr(motion),
+            sr_a, native.ptr(score), lr_a, len(logit_rows), amax.data_ptr(), int(keep_kv), native.stream_ptr()), ctx)
+        return score, amax[: len(logit_rows)]
+
+    def forward(self, mos: Optional[torch.Tensor] = None, pixel_values: Optional[torch.Tensor] = None,
+                input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                position_ids=None, image_flags: Optional[torch.Tensor] = None, past_key_values=None,
+                labels: Optional[torch.Tensor] = None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, motion_feature: Optional[torch.Tensor] = None,
+                visual_tokens: Optional[torch.Tensor] = None, full_logits: bool = False):
+        """Stage-2 eval pass (modeling_internvl_chat.py:306-488) or, with ``stage=1``, the stage-1 pass
+        (internvl_chat_eval1/modeling_internvl_chat.py:250-366).  ``visual_tokens`` optionally supplies
+        already all-gathered pre-projector tokens (frame-DP) instead of ``pixel_values``."""
+        if position_ids is not None or past_key_values is not None:
+            raise NotImplementedError("the eval pass takes default positions and no cache, like the reference drivers")
+        if self.img_context_token_id is None:
+            raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
+        B, N = input_ids.shape
+        dev = self.device
+        input_ids = input_ids.to(dev)
+        flags = image_flags.squeeze(-1).to(dev) if image_flags is not None else None
+        if visual_tokens is None:
+            visual_tokens = self.vit_tokens(pixel_values)
+        vit_embeds = self.project(visual_tokens)                       # [F, ntok, H]
+        if flags is not None:
+            vit_embeds = vit_embeds[flags == 1]
+        vit_embeds = vit_embeds.reshape(-1, vit_embeds.shape[-1]).contiguous()
+        motion = self.motion_embed(self._motion_feature(pixel_values, B, motion_feature))
+
+        ids_packed, cu, row_of = self._pack(input_ids, attention_mask.to(dev) if attention_mask is not None else None)
+        sel = ids_packed == self.img_context_token_id
+        seq_of = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor([cu[i + 1] - cu[i] for i in range(B)], device=dev))
+        # last <IMG_CONTEXT> of each clip <- motion token; the others, in order <- visual tokens (:351-378)
+        pos_idx = torch.arange(ids_packed.numel(), device=dev)
+        last_pos = torch.full((B,), -1, dtype=torch.long, device=dev)
+        last_pos.scatter_reduce_(0, seq_of[sel], pos_idx[sel], reduce="amax")
+        if bool((last_pos < 0).any()):
+            raise ValueError("every clip needs at least one <IMG_CONTEXT> token")
+        is_motion = torch.zeros_like(sel)
+        is_motion[last_pos] = True
+        vis_sel = sel & ~is_motion
+        n_vis = vit_embeds.shape[0]
+        if int(vis_sel.sum()) != n_vis:
+            raise ValueError(f"visual token count mismatch: {int(vis_sel.sum())} <IMG_CONTEXT> slots vs {n_vis} visual tokens")
+        slot = torch.full_like(ids_packed, -1, dtype=torch.int32)
+        slot[vis_sel] = torch.arange(n_vis, device=dev, dtype=torch.int32)
+        slot[is_motion] = n_vis + seq_of[is_motion].to(torch.int32)
+
+        # rows whose next-token argmax is consumed: shifted positions p with labels[p+1] != -100
+        labels = labels.to(dev)
+        shift_labels = labels[..., 1:].contiguous().view(-1)
+        if full_logits:
+            want = row_of[:, :-1] >= 0
+        else:
+            want = (labels[:, 1:] != -100) & (row_of[:, :-1] >= 0)
+        logit_rows = row_of[:, :-1][want].tolist()
+        score_rows = [cu[i + 1] - 4 for i in range(B)] if self.stage == 2 else None
+        if score_rows is not None and any(cu[i + 1] - cu[i] < 4 for i in range(B)):
+            raise ValueError("clips need at least 4 tokens for the score row hidden[:, -4]")
+        score, amax = self._prefill(ids_packed, slot, cu, vit_embeds, n_vis, motion, score_rows, logit_rows)
+        logit = torch.full((B, N - 1), -1, dtype=torch.long, device=dev)
+        logit[want] = amax
+        out = {"label": shift_labels, "logit": logit.view(-1)}
+        if self.stage == 2:
+            score1 = score.to(torch.bfloat16)       # the head computes in bf16; the value is exact in fp32
+            out["score1"] = score1
+            out["loss"] = F.l1_loss(score1, mos.to(dev).to(score1.dtype)) if mos is not None else None
+        return out
+
+    # ---- generation (API surface; greedy) -------------------------------------------------------------------
+    def _greedy(self, ids_packed, slot, cu, vis, n_vis, max_new_tokens: int, eos_ids: List[int], pad_id: int):
+        b = len(cu) - 1
+        longest = max(cu[i + 1] - cu[i] for i in range(b))
+        last_rows = [cu[i + 1] - 1 for i in range(b)]
+        _, nxt = self._prefill(ids_packed, slot, cu, vis, n_vis, None, None, last_rows, keep_kv=True,
+                               kv_cap=longest + max_new_tokens + 1)
+        lib, ctx = native.load(), self._ctx
+        done = torch.zeros(b, dtype=torch.bool, device=self.device)
+        eos = torch.tensor(eos_ids, device=self.device, dtype=torch.long) if eos_ids else None
+        outs = []
+        for step in range(max_new_tokens):
+            tok = torch.where(done, torch.full_like(nxt, pad_id), nxt)
+            outs.append(tok)
+            if eos is not None:
+                done = done | (tok[:, None] == eos[None, :]).any(1)
+                if bool(done.all()):
+                    break
+            if step + 1 == max_new_tokens:
+                break
+            new = torch.empty_like(tok)
+            native.check(lib.aigv_decode_step(ctx, tok.contiguous().data_ptr(), new.data_ptr(), native.stream_ptr()), ctx)
+            nxt = new
+        return torch.stack(outs, dim=1)
+
+    @staticmethod
+    def _gen_args(generation_config, kw):
+        cfg = dict(generation_config) if isinstance(generation_config, dict) else {}
+        if generation_config is not None and not isinstance(generation_config, dict):
+            cfg = {k: getattr(generation_config, k) for k in ("max_new_tokens", "do_sample", "num_beams", "eos_token_id", "pad_token_id")
+                   if hasattr(generation_config, k)}
+        cfg.update(kw)
+        if cfg.get("do_sample") or (cfg.get("num_beams") or 1) > 1:
+            raise NotImplementedError("only greedy decoding is implemented on the gfx950 path")
+        eos = cfg.get("eos_token_id")
+        eos = [] if eos is None else ([int(eos)] if not isinstance(eos, (list, tuple)) else [int(e) for e in eos])
+        return int(cfg.get("max_new_tokens") or 20), eos, cfg.get("pad_token_id")
+
+    @torch.no_grad()
+    def generate(self, pixel_values: Optional[torch.Tensor] = None, input_ids: Optional[torch.Tensor] = None,
+                 attention_mask: Optional[torch.Tensor] = None, visual_features: Optional[torch.Tensor] = None,
+                 generation_config=None, output_hidden_states=None, return_dict=None, **generate_kwargs) -> torch.Tensor:
+        """modeling_internvl_chat.py:769-811: every <IMG_CONTEXT> slot takes a visual token (no motion
+        token), then greedy decode with a KV cache.  Returns the NEW tokens [B, <=max_new_tokens]."""
+        assert self.img_context_token_id is not None
+        max_new, eos, pad = self._gen_args(generation_config, generate_kwargs)
+        pad = self.config.llm_config.pad_token_id if pad is None else pad
+        dev = self.device
+        input_ids = input_ids.to(dev)
+        ids_packed, cu, _ = self._pack(input_ids, attention_mask.to(dev) if attention_mask is not None else None)
+        slot = torch.full_like(ids_packed, -1, dtype=torch.int32)
+        vis, n_vis = None, 0
+        if pixel_values is not None or visual_features is not None:
+            vit = visual_features if visual_features is not None else self.extract_feature(pixel_values)
+            vis = vit.reshape(-1, vit.shape[-1]).to(dev).contiguous()
+            n_vis = vis.shape[0]
+            sel = ids_packed == self.img_context_token_id
+            assert int(sel.sum()) != 0
+            if int(sel.sum()) != n_vis:
+                raise ValueError(f"visual token count mismatch: {int(sel.sum())} slots vs {n_vis} tokens")
+            slot[sel] = torch.arange(n_vis, device=dev, dtype=torch.int32)
+        return self._greedy(ids_packed, slot, cu, vis, n_vis, max_new, eos, pad)
+
+    @torch.no_grad()
+    def generate2(self, input_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, visual_features=None,
+                  generation_config=None, output_hidden_states=None, return_dict=None, **generate_kwargs) -> torch.Tensor:
+        """modeling_internvl_chat.py:812-853: decode from precomputed input embeddings [B, N, C]."""
+        max_new, eos, pad = self._gen_args(generation_config, generate_kwargs)
+        pad = self.config.llm_config.pad_token_id if pad is None else pad
+        dev = self.device
+        b, n, c = input_embeds.shape
+        mask = torch.ones((b, n), dtype=torch.bool, device=dev) if attention_mask is None else attention_mask.to(dev).bool()
+        emb = input_embeds.to(dev)[mask].to(torch.bfloat16).contiguous()
+        lens = mask.sum(1).tolist()
+        cu = [0]
+        for x in lens:
+            cu.append(cu[-1] + int(x))
+        T = emb.shape[0]
+        ids = torch.zeros(T, dtype=torch.long, device=dev)
+        slot = torch.arange(T, dtype=torch.int32, device=dev)          # every row comes from `emb`
+        return self._greedy(ids, slot, cu, emb, T, max_new, eos, pad)
+
+    def _stage2_embeds(self, pixel_values, input_ids, image_flags, motion_feature=None):
+        """Embedding assembly of chat2 (modeling_internvl_chat.py:642-707): as forward(), with the motion token."""
+        dev = self.device
+        B, N = input_ids.shape
+        input_ids = input_ids.to(dev)
+        emb = self.language_model.model.tok_embeddings.weight[input_ids].clone()
+        vit = self.extract_feature(pixel_values)
+        vit = vit[image_flags.squeeze(-1).to(dev) == 1].reshape(-1, emb.shape[-1])
+        motion = self.motion_embed(self._motion_feature(pixel_values, B, motion_feature))
+        sel = input_ids == self.img_context_token_id
+        csum = torch.cumsum(sel, dim=1)
+        last = (csum == csum.max(dim=1, keepdim=True)[0]) & sel
+        flat = emb.view(B * N, -1)
+        flat[(sel & ~last).view(-1)] = vit
+        flat[last.view(-1)] = motion
+        return flat.view(B, N, -1)
+
+    def chat2(self, tokenizer, pixel_values, input_ids, generation_config, attention_mask, history=None,
+              return_history=False, image_flags=None, IMG_START_TOKEN="<img>", IMG_END_TOKEN="</img>",
+              IMG_CONTEXT_TOKEN="<IMG_CONTEXT>", verbose=False, motion_feature=None):
+        """modeling_internvl_chat.py:638-767."""
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        emb = self._stage2_embeds(pixel_values, input_ids, image_flags, motion_feature)
+        template = get_conv_template(self.template)
+        generation_config["eos_token_id"] = tokenizer.convert_tokens_to_ids(template.sep)
+        out = self.generate2(input_embeds=emb, attention_mask=attention_mask, **generation_config)
+        response = tokenizer.batch_decode(out, skip_special_tokens=True)[0].split(template.sep)[0].strip()
+        return (response, history) if return_history else response
+
+    def chat(self, tokenizer, pixel_values, question, generation_config, history=None, return_history=False,
+             num_patches_list=None, IMG_START_TOKEN="<img>", IMG_END_TOKEN="</img>", IMG_CONTEXT_TOKEN="<IMG_CONTEXT>",
+             verbose=False):
+        """modeling_internvl_chat.py:582-636 (mutates generation_config['eos_token_id'] like the reference)."""
+        if history is None and pixel_values is not None and "<image>" not in question:
+            question = "<image>\n" + question
+        if num_patches_list is None:
+            num_patches_list = [pixel_values.shape[0]] if pixel_values is not None else []
+        assert pixel_values is None or len(pixel_values) == sum(num_patches_list)
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        template = get_conv_template(self.template)
+        template.system_message = self.system_message
+        eos_token_id = tokenizer.convert_tokens_to_ids(template.sep)
+        history = [] if history is None else history
+        for old_q, old_a in history:
+            template.append_message(template.roles[0], old_q)
+            template.append_message(template.roles[1], old_a)
+        template.append_message(template.roles[0], question)
+        template.append_message(template.roles[1], None)
+        query = template.get_prompt()
+        for num_patches in num_patches_list:
+            image_tokens = IMG_START_TOKEN + IMG_CONTEXT_TOKEN * self.num_image_token * num_patches + IMG_END_TOKEN
+            query = query.replace("<image>", image_tokens, 1)
+        model_inputs = tokenizer(query, return_tensors="pt")
+        generation_config["eos_token_id"] = eos_token_id
+        out = self.generate(pixel_values=pixel_values, input_ids=model_inputs["input_ids"],
+                            attention_mask=model_inputs["attention_mask"], **generation_config)
+        response = tokenizer.batch_decode(out, skip_special_tokens=True)[0].split(template.sep)[0].strip()
+        history.append((question, response))
+        if return_history:
+            return response, history
+        if verbose:
+            print(query.replace(IMG_CONTEXT_TOKEN, "").replace(f"{IMG_START_TOKEN}{IMG_END_TOKEN}", "<image>"), response)
+        return response
+
+    def batch_chat(self, tokenizer, pixel_values, questions, generation_config, num_patches_list=None, history=None,
+                   return_history=False, IMG_START_TOKEN="<img>", IMG_END_TOKEN="</img>",
+                   IMG_CONTEXT_TOKEN="<IMG_CONTEXT>", verbose=False, image_counts=None):
+        """modeling_internvl_chat.py:533-580 (left padding is stripped by the packed layout)."""
+        if history is not None or return_history:
+            raise NotImplementedError("Now multi-turn chat is not supported in batch_chat.")
+        if image_counts is not None:
+            num_patches_list = image_counts
+        self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
+        queries = []
+        template = None
+        for idx, num_patches in enumerate(num_patches_list):
+            question = questions[idx]
+            if pixel_values is not None and "<image>" not in question:
+                question = "<image>\n" + question
+            template = get_conv_template(self.template)
+            template.system_message = self.system_message
+            template.append_message(template.roles[0], question)
+            template.append_message(template.roles[1], None)
+            query = template.get_prompt()
+            image_tokens = IMG_START_TOKEN + IMG_CONTEXT_TOKEN * self.num_image_token * num_patches + IMG_END_TOKEN
+            queries.append(query.replace("<image>", image_tokens, 1))
+        tokenizer.padding_side = "left"
+        model_inputs = tokenizer(queries, return_tensors="pt", padding=True)
+        generation_config["eos_token_id"] = tokenizer.convert_tokens_to_ids(template.sep)
+        out = self.generate(pixel_values=pixel_values, input_ids=model_inputs["input_ids"],
+                            attention_mask=model_inputs["attention_mask"], **generation_config)
+        responses = tokenizer.batch_decode(out, skip_special_tokens=True)
+        return [r.split(template.sep)[0].strip() for r in responses]
+
+    # ---- measurement ---------------------------------------------------------------------------------------
+    def prof_enable(self, on: bool = True):
+        lib, ctx = self._native()
+        native.check(lib.aigv_prof_enable(ctx, int(on)), ctx)
+
+    def prof_read(self) -> Dict[str, Dict[str, float]]:
+        lib, ctx = self._native()
+        out = {}
+        for cls, name in enumerate(("gemm", "attn_vit", "attn_llm", "skinny")):
+            n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            native.check(lib.aigv_prof_read(ctx, cls, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), ctx)
+            out[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return out

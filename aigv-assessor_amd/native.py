@@ -1,0 +1,115 @@
+"""ctypes binding of ``libaigv_amd.so`` (C ABI: include/aigv_amd.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` (hipcc --offload-arch=gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libaigv_amd.so")
+ABI_VERSION = 1
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class AigvConfig(C.Structure):
+    """Mirror of ``struct aigv_config`` (include/aigv_amd.h) — field order and types must match."""
+    _fields_ = [
+        ("vit_hidden", C.c_int32), ("vit_inter", C.c_int32), ("vit_heads", C.c_int32), ("vit_layers", C.c_int32),
+        ("image_size", C.c_int32), ("patch_size", C.c_int32), ("num_channels", C.c_int32),
+        ("vit_norm_rms", C.c_int32), ("vit_qk_norm", C.c_int32), ("vit_qkv_bias", C.c_int32),
+        ("vit_eps", C.c_float), ("select_layer", C.c_int32), ("shuffle", C.c_int32),
+        ("llm_hidden", C.c_int32), ("llm_inter", C.c_int32), ("llm_heads", C.c_int32), ("llm_kv_heads", C.c_int32),
+        ("llm_layers", C.c_int32), ("vocab", C.c_int32), ("rms_eps", C.c_float), ("max_positions", C.c_int32),
+        ("motion_dim", C.c_int32), ("n_score_layers", C.c_int32), ("score_dims", C.c_int32 * 8),
+        ("max_frames", C.c_int32), ("vit_chunk", C.c_int32), ("max_tokens", C.c_int32), ("max_seqs", C.c_int32),
+        ("max_out_rows", C.c_int32), ("kv_capacity", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_I64P = C.POINTER(C.c_int64)
+_I32P = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); every symbol declared in include/aigv_amd.h
+PROTOTYPES = {
+    "aigv_abi_version": (_I, []),
+    "aigv_sizeof_config": (_I, []),
+    "aigv_ctx_create": (_I, [_I, C.POINTER(AigvConfig), C.POINTER(_P)]),
+    "aigv_ctx_destroy": (None, [_P]),
+    "aigv_last_error": (C.c_char_p, [_P]),
+    "aigv_load_weight": (_I, [_P, C.c_char_p, _P, _I64P, _I, _I, _I]),
+    "aigv_finalize_weights": (_I, [_P]),
+    "aigv_vit_forward": (_I, [_P, _P, _I, _P, _P]),
+    "aigv_project": (_I, [_P, _P, _I, _P, _P]),
+    "aigv_motion_project": (_I, [_P, _P, _I, _P, _P]),
+    "aigv_llm_prefill": (_I, [_P, _P, _P, _I32P, _I, _P, _I, _P, _I32P, _P, _I32P, _I, _P, _I, _P]),
+    "aigv_decode_step": (_I, [_P, _P, _P, _P]),
+    "aigv_op_gemm": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "aigv_op_skinny_gemm": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
+    "aigv_op_layernorm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "aigv_op_rmsnorm": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P]),
+    "aigv_op_rope": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "aigv_op_attention": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "aigv_op_pixel_shuffle": (_I, [_P, _I, _I, _P, _I, _P]),
+    "aigv_op_im2col": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "aigv_op_lm_head_argmax": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "aigv_prof_enable": (_I, [_P, _I]),
+    "aigv_prof_read": (_I, [_P, _I, _I64P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the library and bind every prototype; raises if it is missing or the ABI differs."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
+                          "there is no CPU fallback for the product path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aigv_abi_version() != ABI_VERSION:
+        raise NativeError(f"ABI mismatch: library {lib.aigv_abi_version()} vs binding {ABI_VERSION}")
+    if lib.aigv_sizeof_config() != C.sizeof(AigvConfig):
+        raise NativeError(f"aigv_config layout mismatch: C {lib.aigv_sizeof_config()} vs ctypes {C.sizeof(AigvConfig)}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, ctx=None):
+    if rc != 0:
+        msg = load().aigv_last_error(ctx)
+        raise NativeError(f"libaigv_amd error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device (or host) address of a torch tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "native ops take contiguous tensors"
+    return t.data_ptr()
+
+
+def stream_ptr() -> Optional[int]:
+    import torch
+    s = torch.cuda.current_stream().cuda_stream
+    return s if s else None
+
+
+def i32_array(values):
+    arr = (C.c_int32 * len(values))(*[int(v) for v in values])
+    return arr

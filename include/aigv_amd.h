@@ -1,0 +1,143 @@
+/* aigv_amd.h — C ABI of libaigv_amd.so: the MI355X (gfx950) forward path of the AIGV-Assessor scorer.
+ *
+ * The reference has no FFI: its hot path sits behind the Python class InternVLChatModel
+ * (internvl/model/internvl_chat_eval2/modeling_internvl_chat.py).  This header is the boundary a
+ * maintainer binds instead (ctypes stub in INTEGRATION.md); each entry point names the reference
+ * code it replaces.  Plain pointers and sizes only — no torch types.  All tensor pointers are DEVICE
+ * pointers (bf16 = raw uint16 bits) unless marked host; outputs are caller-allocated; work is enqueued
+ * on the caller's HIP stream and nothing synchronises except where noted.  Every function returns
+ * 0 on success or a negative aigv_status; aigv_last_error() gives the message.  Never throws.
+ *
+ * Packed sequence convention: the B clips of a batch are concatenated without padding; clip b owns
+ * token rows cu_seqlens[b] .. cu_seqlens[b+1]-1 and its positions restart at 0 — what the reference
+ * computes for un-padded rows (modeling_internlm2.py:907-912) and for left/right padded batches
+ * (:1141-1147).
+ */
+#ifndef AIGV_AMD_H
+#define AIGV_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIGV_ABI_VERSION 1
+
+typedef struct aigv_ctx aigv_ctx;
+
+enum aigv_status {
+  AIGV_OK = 0,
+  AIGV_ERR_ARG = -1,      /* bad argument / shape the kernels do not cover */
+  AIGV_ERR_HIP = -2,      /* a HIP call failed */
+  AIGV_ERR_STATE = -3,    /* weights missing, capacity exceeded, no KV state ... */
+  AIGV_ERR_ALLOC = -4
+};
+
+enum aigv_dtype { AIGV_BF16 = 0, AIGV_F32 = 1 };
+
+/* Model + capacity description.  Field meanings follow the reference's config classes
+ * (configuration_intern_vit.py:20-119, configuration_internlm2.py:26-150, configuration_internvl_chat.py). */
+typedef struct aigv_config {
+  /* InternViT */
+  int32_t vit_hidden, vit_inter, vit_heads, vit_layers;
+  int32_t image_size, patch_size, num_channels;
+  int32_t vit_norm_rms;      /* 0: nn.LayerNorm (ViT-300M), 1: InternRMSNorm (ViT-6B) */
+  int32_t vit_qk_norm;       /* full-width QK RMSNorm (modeling_intern_vit.py:148-151) */
+  int32_t vit_qkv_bias;
+  float vit_eps;
+  int32_t select_layer;      /* -1 = last (modeling_internvl_chat.py:509-518) */
+  int32_t shuffle;           /* 1/downsample_ratio (2) */
+  /* InternLM2 */
+  int32_t llm_hidden, llm_inter, llm_heads, llm_kv_heads, llm_layers, vocab;
+  float rms_eps;
+  int32_t max_positions;     /* rows of the RoPE tables the host uploads */
+  /* heads */
+  int32_t motion_dim;        /* SlowFast feature width (2304) */
+  int32_t n_score_layers;    /* 5 */
+  int32_t score_dims[8];     /* 1024,256,64,16,1 */
+  /* capacity (workspaces are allocated once, in aigv_ctx_create) */
+  int32_t max_frames;        /* frames per aigv_vit_forward call (processed in chunks of vit_chunk) */
+  int32_t vit_chunk;         /* frames per ViT pass (workspace size) */
+  int32_t max_tokens;        /* packed tokens per aigv_llm_prefill call */
+  int32_t max_seqs;          /* clips per call */
+  int32_t max_out_rows;      /* lm-head rows per call (answer rows), <= 64 per launch, looped */
+  int32_t kv_capacity;       /* per-clip KV-cache length for decode (0 = no decode support) */
+} aigv_config;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+int aigv_abi_version(void);
+int aigv_sizeof_config(void);                        /* sizeof(aigv_config): binding self-check */
+int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out);
+void aigv_ctx_destroy(aigv_ctx* ctx);
+const char* aigv_last_error(const aigv_ctx* ctx);     /* ctx may be NULL (creation errors) */
+
+/* Weight upload.  `name` is the reference state-dict key, e.g.
+ * "vision_model.encoder.layers.3.attn.qkv.weight", "language_model.model.layers.0.attention.wqkv.weight",
+ * "mlp1.1.bias", "mlpscore.fc1.weight"; plus two host-precomputed tables "rope.cos" / "rope.sin"
+ * [max_positions, head_dim/2] (modeling_internlm2.py:176-194) and the position table already resized to this
+ * ctx's image size (modeling_intern_vit.py:87-93).  Data is bf16 (or f32, converted); `on_device` says where
+ * `data` lives.  The ctx keeps its own repacked copy (padded patch kernel, interleaved w1|w3).  Synchronous. */
+int aigv_load_weight(aigv_ctx* ctx, const char* name, const void* data, const int64_t* shape, int ndim,
+                     int dtype, int on_device);
+int aigv_finalize_weights(aigv_ctx* ctx);             /* checks that every tensor the config needs is present */
+
+/* ---- hot path ------------------------------------------------------------------------------------ */
+/* InternVisionModel.forward + cls drop + pixel_shuffle(v2)  (modeling_intern_vit.py:95-107,216-228,324-362;
+ * modeling_internvl_chat.py:492-527).  frames: [F,3,S,S] bf16 NCHW.  out: [F*ntok, shuffle^2*vit_hidden] bf16
+ * pre-projector tokens — the payload of the frame-DP all-gather. */
+int aigv_vit_forward(aigv_ctx* ctx, const void* frames, int n_frames, void* out_tokens, void* stream);
+/* mlp1: LayerNorm -> Linear -> GELU -> Linear (modeling_internvl_chat.py:238-243,529). rows x proj_in -> rows x llm_hidden */
+int aigv_project(aigv_ctx* ctx, const void* tokens, int rows, void* out, void* stream);
+/* motion_mlp on the SlowFast feature (modeling_internvl_chat.py:244-249,345). [B, motion_dim] -> [B, llm_hidden] */
+int aigv_motion_project(aigv_ctx* ctx, const void* motion_feature, int n_clips, void* out, void* stream);
+
+/* InternVLChatModel.forward from the embedding scatter onwards (modeling_internvl_chat.py:324-488,
+ * modeling_internlm2.py:868-998,1094-1096):
+ *   ids[T] int64 packed token ids; slot[T] int32: -1 = text token (embedding row ids[t]); 0..n_vis-1 = row of
+ *   `vis`; n_vis + b = row b of `motion`.  cu_seqlens: HOST int32[B+1].
+ *   score_rows[B]  (HOST int32, packed row index of hidden[:, -4] per clip) -> score[B] float (device), may be NULL
+ *   logit_rows[R]  (HOST int32, packed row indices whose next-token argmax is wanted) -> argmax[R] int64 (device)
+ *   keep_kv != 0 stores K/V of every layer into the ctx KV cache for aigv_decode_step.                      */
+int aigv_llm_prefill(aigv_ctx* ctx, const int64_t* ids, const int32_t* slot, const int32_t* cu_seqlens, int n_clips,
+                     const void* vis, int n_vis, const void* motion, const int32_t* score_rows, float* score,
+                     const int32_t* logit_rows, int n_logit_rows, int64_t* argmax, int keep_kv, void* stream);
+/* One greedy decode step for every clip of the last keep_kv prefill (generate(): modeling_internvl_chat.py:769-811,
+ * modeling_internlm2.py:1126-1163).  ids[B] int64 device (the previous tokens) -> next[B] int64 device. */
+int aigv_decode_step(aigv_ctx* ctx, const int64_t* ids, int64_t* next, void* stream);
+
+/* ---- single operators (parity tests call these through the same ABI) --------------------------------- */
+/* C = epilogue(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch */
+int aigv_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
+                 const void* resid, int ldr, const void* pos, int np, int M, int N, int K, int epi, void* stream);
+int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W, int ldw, int N, int K, const void* bias,
+                        const void* resid, int ldr, void* out, int ldo, int epi, void* stream);
+int aigv_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H,
+                      float eps, void* stream);
+int aigv_op_rmsnorm(const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps,
+                    const int32_t* row_idx, void* stream);
+int aigv_op_rope(void* qkv, int ld, const int32_t* pos, const void* cos, const void* sin, int tokens, int n_rot,
+                 int slots, int n_groups, int head_dim, void* stream);
+/* q/k/v as in kernels.h AttnArgs; cu is a DEVICE int32[n_seq+1] */
+int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                      const int32_t* cu, int n_seq, int max_len, int n_heads, int n_kv_heads, int q_group_stride,
+                      int kv_head_stride, int head_dim, int causal, float post_div, float q_prescale, void* stream);
+int aigv_op_pixel_shuffle(const void* vit_out, int grid, int vit_hidden, void* out, int n_frames, void* stream);
+int aigv_op_im2col(const void* frames, int n_frames, int channels, int image_size, int patch, int kp, void* out,
+                   void* stream);
+int aigv_op_lm_head_argmax(const void* h, int rows, int hidden, const void* W, int vocab, void* scratch_u64,
+                           int64_t* idx, float* val, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------------------ */
+/* When enabled every GEMM / attention launch of the hot path is bracketed by HIP events on the launch stream. */
+enum aigv_prof_class { AIGV_PROF_GEMM = 0, AIGV_PROF_ATTN_VIT = 1, AIGV_PROF_ATTN_LLM = 2, AIGV_PROF_SKINNY = 3,
+                       AIGV_PROF_COUNT = 4 };
+int aigv_prof_enable(aigv_ctx* ctx, int on);
+/* Synchronises the recorded events and returns (and clears) launches, total milliseconds and algorithmic
+ * FLOPs (2*M*N*K; attention 4*sum(len_q*len_kv_visible)*d*heads) and bytes per class. */
+int aigv_prof_read(aigv_ctx* ctx, int cls, int64_t* launches, double* total_ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIGV_AMD_H */

@@ -1,0 +1,338 @@
+"""Per-kernel parity tests (MI355X only): every op is called through the C ABI (libaigv_amd.so) and compared
+with a plain PyTorch fp32 reference of the same op that carries the reference's bf16 rounding points.
+
+Tolerances (written per test): GEMM-class outputs must equal the rounded fp32 reference up to 1 bf16 ulp
+(2^-8 relative) on a small fraction of elements — the only legitimate difference is fp32 summation order
+inside the MFMA chain.  Attention is compared against fp64 truth next to the reference's eager bf16 path:
+the kernel must be at least as accurate as that path (flash-style accumulation cannot match it bitwise).
+Byte-moving ops (im2col, pixel-shuffle) are bit-exact.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from aigv_assessor_amd import native
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return native.load()
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def rb(t):  # one bf16 rounding point
+    return t.to(BF).float()
+
+
+def ulp_check(got, want, frac=0.02, max_ulps=2):
+    """got/want: bf16-valued float tensors. Differences only at the 1-ulp level, on a small fraction."""
+    got, want = got.float().cpu(), want.float().cpu()
+    assert got.shape == want.shape
+    assert torch.isfinite(got).all()
+    ulp = (want.abs().clamp_min(1e-30)).log2().floor().exp2() * 2.0 ** -7
+    err = (got - want).abs()
+    nbad = (err > 0).float().mean().item()
+    worst = (err / ulp).max().item()
+    assert worst <= max_ulps + 1e-3, f"worst error {worst:.2f} ulp"
+    assert nbad <= frac, f"{nbad:.4f} of elements differ"
+
+
+def sync(rc, lib_):
+    from aigv_assessor_amd import native
+    native.check(rc)
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------------
+def gemm_ref(A, W, epi, bias=None, ls=None, resid=None, pos=None, np_=0):
+    acc = A.float() @ W.float().t()
+    if epi == 4:
+        n = W.shape[0]
+        blk = acc.view(acc.shape[0], n // 32, 2, 16)
+        g, u = rb(blk[:, :, 0, :]).reshape(acc.shape[0], -1), rb(blk[:, :, 1, :]).reshape(acc.shape[0], -1)
+        return rb(rb(torch.nn.functional.silu(g)) * u)
+    if bias is not None:
+        acc = acc + bias.float()
+    y = rb(acc)
+    if epi == 1:
+        y = rb(torch.nn.functional.gelu(y))
+    if epi == 2:
+        y = rb(y * ls.float())
+    if epi in (2, 3):
+        y = rb(resid.float() + y)
+    if epi == 5:
+        m = torch.arange(A.shape[0])
+        y = rb(y + pos.float()[(m % np_) + 1])
+    return y
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2050, 384, 192), (128, 128, 64), (1, 128, 64), (4099, 1024, 1024)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_epilogues(lib, M, N, K, epi):
+    g = torch.Generator().manual_seed(M * 7 + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(BF)
+    W = (torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K))).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF) if epi in (0, 1, 2) else None
+    ls = (torch.rand(N, generator=g) + 0.5).to(BF) if epi == 2 else None
+    nout = N // 2 if epi == 4 else N
+    resid = torch.randn(M, nout, generator=g).to(BF) if epi in (2, 3) else None
+    want = gemm_ref(A, W, epi, bias, ls, resid)
+    dA, dW = dev(A), dev(W)
+    dC = torch.full((M, nout), float("nan"), dtype=BF, device="cuda")
+    db, dl, dr = (dev(t) if t is not None else None for t in (bias, ls, resid))
+    from aigv_assessor_amd.native import ptr
+    sync(lib.aigv_op_gemm(ptr(dA), K, ptr(dW), K, ptr(dC), nout, ptr(db), ptr(dl), ptr(dr), nout, None, 0, M, N, K, epi,
+                          None), lib)
+    ulp_check(dC, want, frac=0.03 if epi in (1, 4) else 0.02)
+
+
+def test_gemm_identity_asymmetric(lib):
+    """A = I with an asymmetric W catches a transposed C write (guide §3)."""
+    from aigv_assessor_amd.native import ptr
+    n = 128
+    A = torch.eye(n).to(BF)
+    W = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(BF)   # W[i][j] != W[j][i]
+    dC = torch.empty(n, n, dtype=BF, device="cuda")
+    sync(lib.aigv_op_gemm(ptr(dev(A)), n, ptr(dev(W)), n, ptr(dC), n, None, None, None, 0, None, 0, n, n, n, 0, None), lib)
+    assert torch.equal(dC.cpu().float(), W.float().t())
+
+
+def test_gemm_inplace_residual_and_patch_epilogue(lib):
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(3)
+    # in-place residual (C aliases resid), as the ViT/LLM layers use it
+    M, N, K = 514, 256, 128
+    A, W = (torch.randn(M, K, generator=g) * 0.5).to(BF), (torch.randn(N, K, generator=g) * 0.1).to(BF)
+    x = torch.randn(M, N, generator=g).to(BF)
+    want = gemm_ref(A, W, 3, resid=x)
+    dx = dev(x.clone())
+    sync(lib.aigv_op_gemm(ptr(dev(A)), K, ptr(dev(W)), K, ptr(dx), N, None, None, ptr(dx), N, None, 0, M, N, K, 3, None), lib)
+    ulp_check(dx, want)
+    # patch epilogue: bias, position rows, one skipped class row per frame
+    F_, np_, N, K = 3, 128, 128, 64
+    M = F_ * np_
+    A, W = (torch.randn(M, K, generator=g) * 0.5).to(BF), (torch.randn(N, K, generator=g) * 0.1).to(BF)
+    bias, pos = (torch.randn(N, generator=g) * 0.1).to(BF), torch.randn(np_ + 1, N, generator=g).to(BF)
+    want = gemm_ref(A, W, 5, bias=bias, pos=pos, np_=np_)
+    dC = torch.zeros(F_ * (np_ + 1), N, dtype=BF, device="cuda")
+    sync(lib.aigv_op_gemm(ptr(dev(A)), K, ptr(dev(W)), K, ptr(dC), N, ptr(dev(bias)), None, None, 0, ptr(dev(pos)), np_, M, N,
+                          K, 5, None), lib)
+    got = dC.cpu().view(F_, np_ + 1, N)
+    assert (got[:, 0] == 0).all()            # class rows untouched
+    ulp_check(got[:, 1:].reshape(M, N), want)
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    from aigv_assessor_amd import native
+    a = torch.zeros(128, 64, dtype=BF, device="cuda")
+    rc = lib.aigv_op_gemm(native.ptr(a), 64, native.ptr(a), 64, native.ptr(a), 100, None, None, None, 0, None, 0, 128, 100, 64, 0, None)
+    assert rc == -1 and b"multiple of 128" in lib.aigv_last_error(None)
+    rc = lib.aigv_op_gemm(native.ptr(a), 64, native.ptr(a), 64, native.ptr(a), 128, None, None, None, 0, None, 0, 128, 128, 40, 0, None)
+    assert rc == -1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# row ops
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,H", [(37, 1024), (5, 4096), (3, 2304), (9, 128)])
+def test_layernorm(lib, rows, H):
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(rows + H)
+    x = (torch.randn(rows, H, generator=g) * 2 + 0.3).to(BF)
+    w, b = (1 + 0.1 * torch.randn(H, generator=g)).to(BF), (0.1 * torch.randn(H, generator=g)).to(BF)
+    want = torch.nn.functional.layer_norm(x.float(), (H,), w.float(), b.float(), 1e-6).to(BF)
+    y = torch.empty_like(x, device="cuda")
+    sync(lib.aigv_op_layernorm(ptr(dev(x)), H, ptr(dev(w)), ptr(dev(b)), ptr(y), H, rows, H, 1e-6, None), lib)
+    ulp_check(y, want.float())
+
+
+@pytest.mark.parametrize("rows,H", [(33, 4096), (7, 512)])
+def test_rmsnorm_and_row_gather(lib, rows, H):
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, H, generator=g) * 3).to(BF)
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(BF)
+
+    def ref(xx):
+        xf = xx.float()
+        return rb(w.float() * rb(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)))
+    y = torch.empty_like(x, device="cuda")
+    sync(lib.aigv_op_rmsnorm(ptr(dev(x)), H, ptr(dev(w)), ptr(y), H, rows, H, 1e-5, None, None), lib)
+    ulp_check(y, ref(x))
+    idx = torch.tensor([rows - 1, 0, 2], dtype=torch.int32)
+    y2 = torch.empty(3, H, dtype=BF, device="cuda")
+    sync(lib.aigv_op_rmsnorm(ptr(dev(x)), H, ptr(dev(w)), ptr(y2), H, 3, H, 1e-5, ptr(dev(idx)), None), lib)
+    ulp_check(y2, ref(x[idx.long()]))
+
+
+def test_rope_matches_reference_rounding(lib):
+    from aigv_assessor_amd.native import ptr
+    from aigv_assessor_amd.modeling import rope_tables
+    g = torch.Generator().manual_seed(9)
+    T, nkv, grp, D = 50, 2, 2, 128            # 2 kv groups x (2 q + K + V)
+    ld = nkv * (grp + 2) * D
+    qkv = torch.randn(T, ld, generator=g).to(BF)
+    pos = torch.randint(0, 300, (T,), generator=g, dtype=torch.int32)
+    cos, sin = rope_tables(D, 1e6, 300)
+    want = qkv.clone().view(T, nkv, grp + 2, D)
+    c = torch.cat([cos, cos], -1)[pos.long()][:, None, None, :]
+    s = torch.cat([sin, sin], -1)[pos.long()][:, None, None, :]
+    x = want[:, :, : grp + 1, :]
+    rot = torch.cat((-x[..., D // 2:], x[..., : D // 2]), dim=-1)
+    want[:, :, : grp + 1, :] = (x * c) + (rot * s)       # bf16 ops = the reference's three rounding points
+    d = dev(qkv.clone())
+    sync(lib.aigv_op_rope(ptr(d), ld, ptr(dev(pos)), ptr(dev(cos)), ptr(dev(sin)), T, grp + 1, grp + 2, nkv, D, None), lib)
+    assert torch.equal(d.cpu().view(T, nkv, grp + 2, D), want)
+
+
+def test_pixel_shuffle_and_im2col_are_bit_exact(lib):
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(4)
+    F_, grid, Hv = 3, 6, 64
+    vit = torch.randn(F_, grid * grid + 1, Hv, generator=g).to(BF)
+    x = vit[:, 1:].reshape(F_, grid, grid, Hv)
+    want = x.reshape(F_, grid // 2, 2, grid // 2, 2, Hv).permute(0, 1, 3, 2, 4, 5).reshape(F_, (grid // 2) ** 2, 4 * Hv)
+    out = torch.empty(F_, (grid // 2) ** 2, 4 * Hv, dtype=BF, device="cuda")
+    sync(lib.aigv_op_pixel_shuffle(ptr(dev(vit)), grid, Hv, ptr(out), F_, None), lib)
+    assert torch.equal(out.cpu(), want)
+    S, P, Kp = 56, 14, 640
+    fr = torch.randn(2, 3, S, S, generator=g).to(BF)
+    want = torch.nn.functional.unfold(fr.float(), P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P).to(BF)
+    col = torch.full((2 * 16, Kp), 7.0, dtype=BF, device="cuda")
+    sync(lib.aigv_op_im2col(ptr(dev(fr)), 2, 3, S, P, Kp, ptr(col), None), lib)
+    assert torch.equal(col.cpu()[:, : 3 * P * P], want) and (col.cpu()[:, 3 * P * P:] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------------
+def attn_truth(q, k, v, causal, scale_pre, post_div, dtype):
+    """q [n,h,d], k/v [n,hk,d] for ONE sequence.  dtype=float64 -> truth; bf16 -> the reference's eager path
+    (modeling_intern_vit.py:153-157 / modeling_internlm2.py:407-424) with its rounding points."""
+    h, hk = q.shape[1], k.shape[1]
+    rep = h // hk
+    qq = q.transpose(0, 1).to(dtype)
+    kk = k.transpose(0, 1).repeat_interleave(rep, 0).to(dtype)
+    vv = v.transpose(0, 1).repeat_interleave(rep, 0).to(dtype)
+    if scale_pre != 1.0:
+        qq = qq * scale_pre
+    s = qq @ kk.transpose(1, 2)
+    if post_div != 1.0:
+        s = s / post_div
+    if causal:
+        n = q.shape[0]
+        m = torch.full((n, n), torch.finfo(dtype).min, dtype=dtype).triu(1)
+        s = s + m
+    if dtype == BF and post_div != 1.0:
+        p = torch.softmax(s, -1, dtype=torch.float32).to(BF)      # LLM: fp32 softmax, cast back
+    else:
+        p = torch.softmax(s, -1)
+    return (p @ vv).transpose(0, 1)
+
+
+def run_attention(lib, q, k, v, lens, causal, d, pre, post):
+    from aigv_assessor_amd.native import ptr
+    T, h, hk = q.shape[0], q.shape[1], k.shape[1]
+    g = h // hk
+    # fused layout like the LLM's wqkv output: per kv group [g q heads | K | V]
+    fused = torch.zeros(T, hk, g + 2, d, dtype=BF)
+    fused[:, :, :g] = q.view(T, hk, g, d)
+    fused[:, :, g] = k
+    fused[:, :, g + 1] = v
+    dq = dev(fused.view(T, -1))
+    ld = hk * (g + 2) * d
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    out = torch.full((T, h * d), float("nan"), dtype=BF, device="cuda")
+    base = dq.data_ptr()
+    sync(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(dev(cu)),
+                               len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal), post, pre, None), lib)
+    return out.cpu().view(T, h, d)
+
+
+@pytest.mark.parametrize("d,causal,h,hk,lens", [
+    (64, False, 2, 2, [1025, 1025, 1025]),       # ViT: 448 px frames, cls tail row
+    (64, False, 3, 3, [257, 257]),               # ViT: 224 px
+    (128, True, 4, 2, [200, 77]),                # LLM: GQA, ragged clips
+    (128, True, 8, 2, [513, 64, 1]),             # group of 4, tile-boundary lengths, length-1 clip
+    (128, True, 2, 1, [1300]),
+])
+def test_attention_matches_eager_reference(lib, d, causal, h, hk, lens):
+    g = torch.Generator().manual_seed(sum(lens) + d)
+    T = sum(lens)
+    q = (torch.randn(T, h, d, generator=g) * 1.5).to(BF)
+    k = (torch.randn(T, hk, d, generator=g) * 1.5).to(BF)
+    v = torch.randn(T, hk, d, generator=g).to(BF)
+    # force large, late-arriving maxima so the online-softmax rescale path is exercised (guide rule 26)
+    k[lens[0] // 2] *= 6.0
+    pre = d ** -0.5 if not causal else 1.0
+    post = 1.0 if not causal else math.sqrt(d)
+    got = run_attention(lib, q, k, v, lens, causal, d, pre, post).double()
+    off = 0
+    for n in lens:
+        sl = slice(off, off + n)
+        truth = attn_truth(q[sl], k[sl], v[sl], causal, pre, post, torch.float64)
+        eager = attn_truth(q[sl], k[sl], v[sl], causal, pre, post, BF).double()
+        e_hip = (got[sl] - truth).abs()
+        e_ref = (eager - truth).abs()
+        assert torch.isfinite(got[sl]).all()
+        assert e_hip.mean() <= 1.5 * e_ref.mean() + 1e-4, (e_hip.mean().item(), e_ref.mean().item())
+        assert e_hip.max() <= 2.0 * e_ref.max() + 2e-3, (e_hip.max().item(), e_ref.max().item())
+        off += n
+
+
+# ---------------------------------------------------------------------------------------------------------
+# skinny GEMM / lm-head argmax
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,N,K,epi", [(5, 272, 256, 0), (16, 512, 384, 1), (33, 256, 1152, 3), (64, 640, 256, 2), (1, 128, 128, 0)])
+def test_skinny_gemm(lib, R, N, K, epi):
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(R + N + K)
+    x = (torch.randn(R, K, generator=g) * 0.5).to(BF)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF) if epi in (0, 3) else None
+    nout = N // 2 if epi == 2 else N
+    resid = torch.randn(R, nout, generator=g).to(BF) if epi == 1 else None
+    want = gemm_ref(x, W, {0: 0, 1: 3, 2: 4, 3: 1}[epi], bias=bias, resid=resid)
+    out = torch.full((R, nout), float("nan"), dtype=BF, device="cuda")
+    sync(lib.aigv_op_skinny_gemm(ptr(dev(x)), K, R, ptr(dev(W)), K, N, K, ptr(dev(bias)) if bias is not None else None,
+                                 ptr(dev(resid)) if resid is not None else None, nout, ptr(out), nout, epi, None), lib)
+    ulp_check(out, want, frac=0.03)
+
+
+@pytest.mark.parametrize("R,V,H", [(10, 1009, 256), (40, 92553, 512), (64, 4099, 128)])
+def test_lm_head_argmax_first_max_on_ties(lib, R, V, H):
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(V)
+    h = torch.randn(R, H, generator=g).to(BF)
+    W = (torch.randn(V, H, generator=g) / math.sqrt(H)).to(BF)
+    W[V - 1] = W[3]            # exact ties between a low and the very last vocabulary row
+    W[17] = W[3]
+    logits = rb(h.float() @ W.float().t())       # bf16 lm-head output, then .float() (modeling_internlm2.py:1095-1096)
+    want = logits.argmax(-1)
+    # torch.argmax returns the first maximal index; make the tie decisive for a few rows
+    idx = torch.empty(R, dtype=torch.long, device="cuda")
+    val = torch.empty(R, dtype=torch.float32, device="cuda")
+    scratch = torch.zeros(64, dtype=torch.int64, device="cuda")
+    sync(lib.aigv_op_lm_head_argmax(ptr(dev(h)), R, H, ptr(dev(W)), V, ptr(scratch), ptr(idx), ptr(val), None), lib)
+    got = idx.cpu()
+    gv = val.cpu()
+    # the winning VALUE must match the rounded reference to 1 ulp; where it matches exactly the index must too
+    wv = logits.max(-1).values
+    same = gv == wv
+    assert same.float().mean() > 0.9
+    assert torch.equal(got[same], want[same])
+    assert ((gv - wv).abs() <= wv.abs() * 2.0 ** -7 + 1e-6).all()
+    h2 = W[3:4].clone().expand(3, H).contiguous()   # rows whose best vocab rows are the tied 3/17/V-1 -> must return 3
+    sync(lib.aigv_op_lm_head_argmax(ptr(dev(h2)), 3, H, ptr(dev(W)), V, ptr(scratch), ptr(idx), ptr(val), None), lib)
+    l2 = rb(h2.float() @ W.float().t())
+    assert torch.equal(idx.cpu()[:3], l2.argmax(-1))

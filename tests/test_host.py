@@ -1,0 +1,123 @@
+"""CPU-only tests: host logic, the C-ABI surface, and agreement of the package's host-side weight preparation
+with the oracle.  No compute calls into the library (there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+import aigv_assessor_amd as pkg
+from aigv_assessor_amd import native, synth
+from aigv_assessor_amd.conversation import get_conv_template
+from aigv_assessor_amd.modeling import InternVLChatModel, resized_pos_table, rope_tables
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from aigv_assessor_amd import build
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(ROOT, "include", "aigv_amd.h")).read()
+    declared = set(re.findall(r"\b(aigv_[a-z0-9_]+)\s*\(", header))
+    declared -= {"aigv_ctx", "aigv_config"}
+    assert declared == set(native.PROTOTYPES), declared ^ set(native.PROTOTYPES)
+    lib = ctypes.CDLL(built)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.aigv_abi_version() == native.ABI_VERSION
+    assert lib.aigv_sizeof_config() == ctypes.sizeof(native.AigvConfig)
+
+
+def test_no_cpu_fallback_and_loud_errors(built):
+    lib = ctypes.CDLL(built)
+    lib.aigv_last_error.restype = ctypes.c_char_p
+    cfg = native.AigvConfig()
+    h = ctypes.c_void_p()
+    if not torch.cuda.is_available():
+        rc = lib.aigv_ctx_create(0, ctypes.byref(cfg), ctypes.byref(h))
+        assert rc != 0 and b"no HIP device" in lib.aigv_last_error(None)
+        model = InternVLChatModel(pkg.tiny(image_size=224))
+        with pytest.raises(native.NativeError):
+            model.extract_feature(torch.zeros(1, 3, 224, 224))
+
+
+def test_product_path_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "aigv-assessor_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "/root/reference" not in txt, f
+
+
+def test_canonical_layout_and_special_ids():
+    c8 = pkg.internvl2_8b()
+    assert synth.canonical_len(c8, 8) == 2177 and synth.canonical_len(c8, 16) == 4281
+    assert synth.special_ids(92553) == dict(im_end=92542, im_start=92543, img=92544, img_end=92545, img_context=92546)
+    cfg = pkg.tiny(image_size=224)
+    t = synth.canonical_tokens(cfg, 2, 4, seed=0)
+    assert t["input_ids"].shape == (2, synth.canonical_len(cfg, 4))
+    assert int((t["input_ids"][0] == t["img_context_token_id"]).sum()) == 4 * cfg.num_image_token + 1
+    assert int((t["labels"][0] != -100).sum()) == 10 and t["labels"][0, -1] == t["im_end_id"]
+    assert c8.num_image_token == 256 and c8.proj_in == 4096
+
+
+def test_state_dict_names_and_module_surface():
+    cfg = pkg.tiny(image_size=224)
+    sd = synth.make_state_dict(cfg, 3, rich=True)
+    m = InternVLChatModel(cfg)
+    assert m.load_state_dict(sd) == ([], [])
+    assert set(m.state_dict()) == set(sd)
+    # the attribute surface the reference drivers touch (stage2_eval.py:810-885)
+    assert len(m.vision_model.encoder.layers) == cfg.vision_config.num_hidden_layers
+    assert m.language_model.get_output_embeddings().weight.shape[0] == cfg.llm_config.vocab_size
+    for name in ("vision_model", "language_model", "mlp1", "motion_mlp", "mlpscore"):
+        for p in getattr(m, name).parameters():
+            p.requires_grad = False
+    m.language_model.resize_token_embeddings(cfg.llm_config.vocab_size + 9)
+    assert m.language_model.get_input_embeddings().weight.shape[0] == cfg.llm_config.vocab_size
+    assert m.num_image_token == 64 and m.template == "internlm2-chat" and m.img_context_token_id is None
+    m.vision_model.resize_pos_embeddings(224, 448, 14)
+    assert m.vision_model.embeddings.position_embedding.shape[1] == 1025
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"bogus": torch.zeros(1)})
+
+
+def test_host_weight_prep_matches_oracle():
+    cos, sin = rope_tables(128, 1e6, 300, 32768, {"type": "dynamic", "factor": 2.0})
+    oc, os_ = O.rope_tables(128, 1e6, 300, torch.bfloat16, 32768, {"type": "dynamic", "factor": 2.0})
+    assert torch.equal(cos, oc[:, :64]) and torch.equal(cos, oc[:, 64:]) and torch.equal(sin, os_[:, :64])
+    pos = torch.randn(1, 1025, 32, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16)
+    assert torch.equal(resized_pos_table(pos, 32, 16), O.vit_pos_embed(pos, 32, 16, 16))
+    assert torch.equal(resized_pos_table(pos, 32, 32), pos)       # identity at the native grid
+
+
+def test_prompt_template_internlm2_chat():
+    t = get_conv_template("internlm2-chat")
+    t.append_message(t.roles[0], "<image>\nHow would you rate the static quality of this video?")
+    t.append_message(t.roles[1], None)
+    p = t.get_prompt()
+    assert p.startswith("<|im_start|>system\n") and p.endswith("<|im_end|><|im_start|>assistant\n")
+    assert "<|im_end|><|im_start|>user\n<image>\nHow would you rate" in p and "<|im_end|>\n" not in p
+    assert t.stop_token_ids == [2, 92543, 92542] and t.sep == "<|im_end|>"
+    with pytest.raises(KeyError):
+        get_conv_template("phi3-chat")
+
+
+def test_pack_and_config_roundtrip():
+    ids = torch.tensor([[5, 6, 0, 0], [7, 8, 9, 0]])
+    am = torch.tensor([[1, 1, 0, 0], [1, 1, 1, 0]])
+    packed, cu, row_of = InternVLChatModel._pack(ids, am)
+    assert packed.tolist() == [5, 6, 7, 8, 9] and cu == [0, 2, 5]
+    assert row_of.tolist() == [[0, 1, -1, -1], [2, 3, 4, -1]]
+    c = pkg.InternVLChatConfig.from_dict(pkg.internvl2_8b().to_dict())
+    assert c.llm_config.intermediate_size == 14336 and c.vision_config.num_hidden_layers == 24
+    c26 = pkg.internvl2_26b()
+    assert c26.vision_config.norm_type == "rms_norm" and c26.llm_config.hidden_size == 6144
