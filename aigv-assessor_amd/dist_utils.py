@@ -1,0 +1,146 @@
+"""Process-group bootstrap and the frame/clip data-parallel scorer (one process per GPU, RCCL over xGMI).
+
+``init_dist`` keeps the reference's signature (internvl/dist_utils.py:32-42) but bootstraps
+``torch.distributed`` directly — backend 'nccl' IS RCCL on ROCm — instead of going through DeepSpeed
+(:51,103).  The reference's eval issues no collectives and would score the full set on every rank
+(stage2_eval.py:908-911); the data-parallel scorer below is the MI355X-native replacement:
+
+  1. frames of the whole batch are split evenly over the ranks, independent of clip boundaries
+     (a single clip's 8 frames spread over 8 GPUs in latency mode);
+  2. every rank runs InternViT + pixel-shuffle on its frames;
+  3. ONE all-gather of the pre-projector visual tokens [F_local, 256, 4*Hv] bf16 makes all tokens visible
+     everywhere (xGMI is a full mesh: RCCL's all-gather moves each shard once over each peer link);
+  4. clips are split over the ranks; each rank runs projector + motion token + LLM pass + heads for its clips;
+  5. a tiny all-gather returns (score, answer-row argmax) to every rank.
+Weights are replicated (8B: 16 GB, 26B: 51 GB << 288 GB HBM): no tensor/pipeline parallelism.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+from datetime import timedelta
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+timeout = timedelta(minutes=60)
+
+
+def init_dist(launcher: str, backend: str = "nccl", **kwargs):
+    """internvl/dist_utils.py:32-104: pick the device from the rank and create the default process group."""
+    if launcher == "pytorch":
+        rank = int(os.environ["RANK"])
+        _set_device(int(os.environ.get("LOCAL_RANK", rank)))
+    elif launcher == "mpi":
+        local_rank = int(os.environ["OMPI_COMM_WORLD_LOCAL_RANK"])
+        _set_device(local_rank)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_ADDR" not in os.environ:
+            raise KeyError("The environment variable MASTER_ADDR is not set")
+        os.environ["WORLD_SIZE"] = os.environ["OMPI_COMM_WORLD_SIZE"]
+        os.environ["RANK"] = os.environ["OMPI_COMM_WORLD_RANK"]
+    elif launcher == "slurm":
+        proc_id = int(os.environ["SLURM_PROCID"])
+        ntasks = int(os.environ["SLURM_NTASKS"])
+        _set_device(proc_id)
+        if "MASTER_ADDR" not in os.environ:
+            node_list = os.environ["SLURM_NODELIST"]
+            os.environ["MASTER_ADDR"] = subprocess.getoutput(f"scontrol show hostname {node_list} | head -n1")
+        port = kwargs.pop("port", None)
+        if port is not None:
+            os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ["WORLD_SIZE"] = str(ntasks)
+        os.environ["RANK"] = str(proc_id)
+    else:
+        raise ValueError(f"Invalid launcher type: {launcher}")
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, timeout=kwargs.pop("timeout", timeout), **kwargs)
+
+
+def _set_device(idx: int):
+    n = torch.cuda.device_count()      # does not initialise the GPU
+    if n > 0:
+        torch.cuda.set_device(idx % n)
+
+
+def even_split(n: int, world: int) -> List[Tuple[int, int]]:
+    """[lo, hi) of n items for each of `world` ranks; the first n % world ranks take one extra item."""
+    q, r = divmod(n, world)
+    out, lo = [], 0
+    for i in range(world):
+        hi = lo + q + (1 if i < r else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+    """All-gather along dim 0 with per-rank row counts (equal counts take the single-buffer fast path)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    tail = tuple(local.shape[1:])
+    if len(set(counts)) == 1:
+        out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    m = max(counts)
+    pad = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
+                   image_flags: Optional[torch.Tensor], labels: torch.Tensor, motion_feature: torch.Tensor,
+                   mos: Optional[torch.Tensor] = None, group=None) -> Dict[str, torch.Tensor]:
+    """Score a batch of B clips (F frames in total) over all ranks of `group`; every rank passes the same host
+    tensors and gets the full result: {'score1' [B], 'logit' [B*(N-1)], 'label' [B*(N-1)]}.
+
+    `model` is an InternVLChatModel (or any object with vit_tokens / forward(visual_tokens=...) / device / stage)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B, N = input_ids.shape
+    F_total = pixel_values.shape[0]
+    if F_total % B:
+        raise ValueError("frames must divide evenly over the clips")
+    fpc = F_total // B
+    # 1-2. frame shard -> ViT tokens
+    fsplit = even_split(F_total, world)
+    lo, hi = fsplit[rank]
+    ntok_shape = None
+    if hi > lo:
+        local = model.vit_tokens(pixel_values[lo:hi])
+    else:
+        probe = model.vit_tokens(pixel_values[:1])     # keeps shapes/dtypes uniform on idle ranks
+        local = probe[:0]
+    # 3. all-gather of pre-projector tokens
+    tokens = all_gather_rows(local, [h - l for l, h in fsplit], group)
+    # 4. clip shard -> projector + LLM pass
+    csplit = even_split(B, world)
+    clo, chi = csplit[rank]
+    dev = local.device
+    n1 = N - 1
+    score_l = torch.zeros((chi - clo,), dtype=torch.float32, device=dev)
+    logit_l = torch.full(((chi - clo) * n1,), -1, dtype=torch.long, device=dev)
+    if chi > clo:
+        sl = slice(clo, chi)
+        fl = slice(clo * fpc, chi * fpc)
+        out = model(mos=None if mos is None else mos[sl], pixel_values=None, input_ids=input_ids[sl],
+                    attention_mask=None if attention_mask is None else attention_mask[sl],
+                    image_flags=None if image_flags is None else image_flags[fl], labels=labels[sl],
+                    motion_feature=motion_feature[sl], visual_tokens=tokens[fl])
+        logit_l = out["logit"]
+        if "score1" in out:
+            score_l = out["score1"].float()
+    # 5. results everywhere
+    counts = [h - l for l, h in csplit]
+    score = all_gather_rows(score_l, counts, group)
+    logit = all_gather_rows(logit_l.view(chi - clo, n1), counts, group).reshape(-1)
+    res = {"logit": logit, "label": labels[..., 1:].contiguous().view(-1).to(logit.device)}
+    if getattr(model, "stage", 2) == 2:
+        res["score1"] = score.to(torch.bfloat16)
+    return res

@@ -153,7 +153,7 @@ class InternVLChatModel(nn.Module):
 
     def __init__(self, config: InternVLChatConfig, vision_model=None, language_model=None, use_flash_attn=True,
                  device=None, dtype=torch.bfloat16, stage: int = 2, max_clips: int = 4, max_frames: Optional[int] = None,
-                 max_new_tokens: int = 0):
+                 max_tokens: int = 0):
         super().__init__()
         if vision_model is not None or language_model is not None:
             raise NotImplementedError("pass weights through load_state_dict / from_pretrained")
@@ -178,7 +178,7 @@ class InternVLChatModel(nn.Module):
         self.conv_template = get_conv_template(self.template)
         self.system_message = self.conv_template.system_message
         self.slowfast_model = None          # optional callable([slow, fast]) -> [B, 2304, 1, 1, 1]
-        self._max_clips, self._max_frames, self._max_new = max_clips, max_frames, max_new_tokens
+        self._max_clips, self._max_frames, self._max_tokens = max_clips, max_frames, max_tokens
         self._ctx = None
         self._ctx_key = None
         self._dirty = True
@@ -261,7 +261,7 @@ class InternVLChatModel(nn.Module):
         cfg, v, l = self.config, self.config.vision_config, self.config.llm_config
         key = getattr(self, "_cap", None) or dict(frames=0, tokens=0, clips=0, rows=0, kv=0)
         want = dict(frames=max(key["frames"], n_frames, self._max_frames or 0, 1),
-                    tokens=max(key["tokens"], n_tokens, 1), clips=max(key["clips"], n_clips, self._max_clips, 1),
+                    tokens=max(key["tokens"], n_tokens, self._max_tokens, 1), clips=max(key["clips"], n_clips, self._max_clips, 1),
                     rows=max(key["rows"], out_rows, 64), kv=max(key["kv"], kv_cap))
         geom = (v.image_size if cfg.force_image_size is None else cfg.force_image_size, v.hidden_size, l.vocab_size,
                 self.select_layer)
@@ -427,50 +427,60 @@ class InternVLChatModel(nn.Module):
             raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
         B, N = input_ids.shape
         dev = self.device
-        input_ids = input_ids.to(dev)
-        flags = image_flags.squeeze(-1).to(dev) if image_flags is not None else None
-        if visual_tokens is None:
-            visual_tokens = self.vit_tokens(pixel_values)
-        vit_embeds = self.project(visual_tokens)                       # [F, ntok, H]
-        if flags is not None:
-            vit_embeds = vit_embeds[flags == 1]
-        vit_embeds = vit_embeds.reshape(-1, vit_embeds.shape[-1]).contiguous()
-        motion = self.motion_embed(self._motion_feature(pixel_values, B, motion_feature))
+        H = self.config.llm_config.hidden_size
 
-        ids_packed, cu, row_of = self._pack(input_ids, attention_mask.to(dev) if attention_mask is not None else None)
+        # ---- index bookkeeping first, on the host (one small D2H copy if the ids live on the device), so that
+        # every kernel of the step can then be enqueued back to back without a host sync in between ----
+        ids_h = input_ids.detach().to("cpu")
+        mask_h = attention_mask.detach().to("cpu") if attention_mask is not None else None
+        labels_h = labels.detach().to("cpu")
+        flags_h = image_flags.detach().to("cpu").squeeze(-1) if image_flags is not None else None
+        ids_packed, cu, row_of = self._pack(ids_h, mask_h)
+        lens = [cu[i + 1] - cu[i] for i in range(B)]
         sel = ids_packed == self.img_context_token_id
-        seq_of = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor([cu[i + 1] - cu[i] for i in range(B)], device=dev))
+        seq_of = torch.repeat_interleave(torch.arange(B), torch.tensor(lens))
         # last <IMG_CONTEXT> of each clip <- motion token; the others, in order <- visual tokens (:351-378)
-        pos_idx = torch.arange(ids_packed.numel(), device=dev)
-        last_pos = torch.full((B,), -1, dtype=torch.long, device=dev)
+        pos_idx = torch.arange(ids_packed.numel())
+        last_pos = torch.full((B,), -1, dtype=torch.long)
         last_pos.scatter_reduce_(0, seq_of[sel], pos_idx[sel], reduce="amax")
         if bool((last_pos < 0).any()):
             raise ValueError("every clip needs at least one <IMG_CONTEXT> token")
         is_motion = torch.zeros_like(sel)
         is_motion[last_pos] = True
         vis_sel = sel & ~is_motion
-        n_vis = vit_embeds.shape[0]
+        n_frames = visual_tokens.shape[0] if visual_tokens is not None else pixel_values.shape[0]
+        keep = torch.arange(n_frames) if flags_h is None else (flags_h == 1).nonzero().flatten()
+        n_vis = int(keep.numel()) * self.num_image_token
         if int(vis_sel.sum()) != n_vis:
             raise ValueError(f"visual token count mismatch: {int(vis_sel.sum())} <IMG_CONTEXT> slots vs {n_vis} visual tokens")
         slot = torch.full_like(ids_packed, -1, dtype=torch.int32)
-        slot[vis_sel] = torch.arange(n_vis, device=dev, dtype=torch.int32)
+        slot[vis_sel] = torch.arange(n_vis, dtype=torch.int32)
         slot[is_motion] = n_vis + seq_of[is_motion].to(torch.int32)
-
         # rows whose next-token argmax is consumed: shifted positions p with labels[p+1] != -100
-        labels = labels.to(dev)
-        shift_labels = labels[..., 1:].contiguous().view(-1)
         if full_logits:
             want = row_of[:, :-1] >= 0
         else:
-            want = (labels[:, 1:] != -100) & (row_of[:, :-1] >= 0)
+            want = (labels_h[:, 1:] != -100) & (row_of[:, :-1] >= 0)
         logit_rows = row_of[:, :-1][want].tolist()
         score_rows = [cu[i + 1] - 4 for i in range(B)] if self.stage == 2 else None
-        if score_rows is not None and any(cu[i + 1] - cu[i] < 4 for i in range(B)):
+        if score_rows is not None and min(lens) < 4:
             raise ValueError("clips need at least 4 tokens for the score row hidden[:, -4]")
+        motion_feature = self._motion_feature(pixel_values, B, motion_feature)
+
+        # ---- device work: ViT -> projector -> motion projector -> LLM pass + heads ----
+        self._native(n_frames=n_frames, n_tokens=cu[-1], n_clips=B, out_rows=len(logit_rows))   # size workspaces once
+        if visual_tokens is None:
+            visual_tokens = self.vit_tokens(pixel_values)
+        vit_embeds = self.project(visual_tokens)                       # [F, ntok, H]
+        if flags_h is not None and int(keep.numel()) != n_frames:
+            vit_embeds = vit_embeds[keep.to(dev)]
+        vit_embeds = vit_embeds.reshape(-1, H)
+        motion = self.motion_embed(motion_feature)
         score, amax = self._prefill(ids_packed, slot, cu, vit_embeds, n_vis, motion, score_rows, logit_rows)
-        logit = torch.full((B, N - 1), -1, dtype=torch.long, device=dev)
-        logit[want] = amax
-        out = {"label": shift_labels, "logit": logit.view(-1)}
+        logit = torch.full((B * (N - 1),), -1, dtype=torch.long, device=dev)
+        if len(logit_rows):
+            logit.index_copy_(0, want.reshape(-1).nonzero().flatten().to(dev), amax)   # index list built on the host: no sync
+        out = {"label": labels_h[..., 1:].contiguous().view(-1).to(dev), "logit": logit.view(-1)}
         if self.stage == 2:
             score1 = score.to(torch.bfloat16)       # the head computes in bf16; the value is exact in fp32
             out["score1"] = score1

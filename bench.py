@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""Headline benchmark: scored clips/s of the stage-2 scoring pass (InternVL2-8B, 8 frames x 448x448 per clip).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic clips: frames -> InternViT -> pixel-shuffle ->
+[all-gather] -> projector (+ motion token) -> InternLM2 pass -> answer-row argmax + score head.  Inputs are resident
+in HBM before the timed region.  Workload at N = 1: BASELINE.json configs[1] (batch 4 x 8 frames, 1 MI355X, bf16);
+at N > 1 every rank adds its own 4 clips (weak scaling, BASELINE.json configs[2] at N = 8) with the frame-DP
+all-gather of visual tokens over RCCL.  Prints ONE JSON line on rank 0.
+
+`roofline`: the bf16 MFMA GEMM kernel (95 % of the FLOPs) timed live with HIP events on the launch stream during the
+timed steps; `cpu_baseline`: the CPU oracle (torch CPU restatement of the reference path) timed on this box's host
+cores on a bounded sample (full-width layers, reduced depth, scaled by layer counts) — a reported baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X (MI355X_MICROARCH.md)
+
+
+def flops_per_clip(cfg, T, N, answer_rows):
+    """Algorithmic FLOPs of one scored clip, logits on the answer rows only (SURVEY.md §8d formulas)."""
+    v, l = cfg.vision_config, cfg.llm_config
+    S = cfg.grid ** 2 + 1
+    Hv, Iv, Lv = v.hidden_size, v.intermediate_size, v.num_hidden_layers
+    vit = T * (Lv * (8 * S * Hv * Hv + 4 * S * Hv * Iv + 4 * S * S * Hv) + 2 * (S - 1) * (3 * v.patch_size ** 2) * Hv)
+    H, I, L = l.hidden_size, l.intermediate_size, l.num_hidden_layers
+    ntok = cfg.num_image_token
+    proj = ntok * T * (2 * cfg.proj_in * H + 2 * H * H) + 2 * cfg.motion_dim * H + 2 * H * H
+    d = l.head_dim
+    llm = N * L * (2 * H * (l.num_attention_heads + 2 * l.num_key_value_heads) * d + 2 * H * H + 6 * H * I) \
+        + L * 4 * H * N * (N + 1) / 2
+    logits = answer_rows * 2 * H * l.vocab_size
+    return dict(vit=vit, projector=proj, llm=llm, logits=logits, total=vit + proj + llm + logits)
+
+
+def cpu_baseline(cfg, T, N, budget_s=30.0):
+    """Time the CPU oracle on this host: one full-width ViT layer over T frames, one full-width LLM layer over N
+    tokens, the lm-head over all N rows (as the reference computes it) and the projector; scale by layer counts."""
+    import aigv_assessor_amd as pkg
+    from aigv_assessor_amd import synth
+    from oracle import oracle as O   # the checker, timed as the CPU baseline (never on the product path)
+    v, l = cfg.vision_config, cfg.llm_config
+    small = pkg.InternVLChatConfig.from_dict(cfg.to_dict())
+    small.vision_config.num_hidden_layers = 1
+    small.llm_config.num_hidden_layers = 1
+    t0 = time.time()
+    sd = synth.make_state_dict(small, seed=1, dtype=torch.bfloat16)
+    gen_s = time.time() - t0
+    g = torch.Generator().manual_seed(0)
+    S = cfg.grid ** 2 + 1
+    xv = (torch.randn(T, S, v.hidden_size, generator=g) * 0.5).to(torch.bfloat16)
+    xl = torch.randn(1, N, l.hidden_size, generator=g).to(torch.bfloat16)
+    mask = O.additive_mask(torch.ones(1, N, dtype=torch.bool), N, 0, torch.bfloat16)
+    pos = torch.arange(N).unsqueeze(0)
+    frames = synth.synthetic_frames(T, cfg.image_size, seed=0)
+
+    def timed(fn, reps=2):
+        fn()  # warm
+        best = 1e30
+        for _ in range(reps):
+            t = time.time()
+            fn()
+            best = min(best, time.time() - t)
+        return best
+
+    with torch.no_grad():
+        t_vit_layer = timed(lambda: O.vit_layer(sd, small, 0, xv))
+        t_llm_layer = timed(lambda: O.llm_layer(sd, small, 0, xl, mask, pos))
+        t_embed = timed(lambda: O.vit_embeddings(sd, small, frames), reps=1)
+        tok = O.shuffled_tokens(xv, cfg.downsample_ratio)
+        t_proj = timed(lambda: O.projector(sd, "mlp1", tok), reps=1)
+        t_logits = timed(lambda: O.lm_logits(sd, xl).argmax(-1), reps=1)
+    per_clip = t_vit_layer * v.num_hidden_layers + t_llm_layer * l.num_hidden_layers + t_embed + t_proj + t_logits
+    return {
+        "value": 1.0 / per_clip, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"oracle (torch CPU bf16 eager restatement of the reference path), 1 clip: 1 full-width ViT layer x{v.num_hidden_layers} "
+                   f"({t_vit_layer:.2f}s each) + 1 full-width LLM layer x{l.num_hidden_layers} ({t_llm_layer:.2f}s each, N={N}) + patch-embed "
+                   f"{t_embed:.2f}s + projector {t_proj:.2f}s + lm-head on all rows {t_logits:.2f}s; weight gen {gen_s:.0f}s untimed"),
+        "s_per_clip": per_clip,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clips-per-gpu", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--model", default="8b", choices=["8b", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event roofline measurement")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import aigv_assessor_amd as pkg
+    from aigv_assessor_amd import synth
+    from aigv_assessor_amd.dist_utils import score_clips_dp
+    from aigv_assessor_amd.modeling import InternVLChatModel
+
+    cfg = pkg.internvl2_8b() if args.model == "8b" else pkg.tiny(image_size=448)
+    T, Bl = args.frames, args.clips_per_gpu
+    B = Bl * world
+    N = synth.canonical_len(cfg, T)
+    dev = torch.device("cuda", local_rank)
+
+    model = InternVLChatModel(cfg, device=dev, max_clips=Bl, max_frames=max(Bl * T, (B * T + world - 1) // world),
+                              max_tokens=Bl * N)
+    sd = synth.make_state_dict(cfg, seed=0, device=dev, rich=True)
+    model.load_state_dict(sd)
+    del sd
+    toks = synth.canonical_tokens(cfg, B, T, seed=0)
+    model.img_context_token_id = toks["img_context_token_id"]
+    model.eval()
+    # inputs resident in HBM before the timed region (token ids are host data in the reference loop; tiny either way)
+    pv = synth.synthetic_frames(B * T, cfg.image_size, seed=0, device=dev)
+    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=0, device=dev)
+    flags = torch.ones(B * T, 1, dtype=torch.long)
+    ids, labels, am = toks["input_ids"], toks["labels"], toks["attention_mask"]
+
+    def step():
+        if world == 1:
+            return model(mos=None, pixel_values=pv, input_ids=ids, attention_mask=am, image_flags=flags, labels=labels,
+                         motion_feature=motion)
+        return score_clips_dp(model, pv, ids, am, flags, labels, motion)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    prof = rank == 0 and not args.no_prof
+    if prof:
+        model.prof_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(out["score1"].float()).all()
+
+    if rank == 0:
+        fl = flops_per_clip(cfg, T, N, answer_rows=10)
+        clips_per_s = B * args.steps / dt
+        line = {
+            "metric": "scored clips/sec (8-frame 448x448, InternVL2-8B stage-2 score eval)", "value": clips_per_s,
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"InternVL2-{args.model.upper()} stage-2 score eval, {Bl} clips/GPU x {T} frames x {cfg.image_size}px, "
+                                   f"N={N} tokens/clip, canonical token layout (SURVEY.md 8d); random-init weights",
+                       "global_batch_clips": B, "frames_per_clip": T, "tokens_per_clip": N,
+                       "parallelism": f"frame/clip-dp{world}" + (" + RCCL all-gather of visual tokens" if world > 1 else "")},
+            "algorithmic_tflop_per_clip": fl["total"] / 1e12,
+            "achieved_tflops_whole_step_per_gpu": fl["total"] * B / dt / 1e12 / world * args.steps,
+        }
+        if prof:
+            p = model.prof_read()
+            gm = p["gemm"]
+            if gm["launches"]:
+                ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+                line["roofline"] = {
+                    "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                    "traffic": None, "kernel": "gemm_bf16_kernel (128x128x64 MFMA 16x16x32 bf16, all epilogues)",
+                    "launches": gm["launches"], "avg_launch_ms": gm["ms"] / gm["launches"],
+                    "flops_per_launch": gm["flops"] / gm["launches"], "gemm_ms_per_step": gm["ms"] / args.steps,
+                    "other_kernels_ms_per_step": {k: p[k]["ms"] / args.steps for k in ("attn_vit", "attn_llm", "skinny")},
+                    "attn_tflops": {k: (p[k]["flops"] / (p[k]["ms"] * 1e-3) / 1e12 if p[k]["ms"] else None) for k in ("attn_vit", "attn_llm")},
+                }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, T, N)
+            line["gpu_over_cpu"] = clips_per_s / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

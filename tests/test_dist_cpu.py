@@ -1,0 +1,93 @@
+"""world_size-2 test of the frame/clip data-parallel scorer on CPU (gloo): the partitioning, the all-gather of
+pre-projector visual tokens and the result gather must reproduce the single-process result exactly.  The model is a
+stand-in built from the CPU oracle (the HIP model cannot run here); the same code path drives the real model on RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import aigv_assessor_amd as pkg
+from aigv_assessor_amd import dist_utils, synth
+from oracle import oracle as O
+
+
+class OracleBackedModel:
+    """Duck-types the three members score_clips_dp uses (vit_tokens / __call__(visual_tokens=...) / stage)."""
+    stage = 2
+
+    def __init__(self, cfg, sd, ctx_id):
+        self.cfg, self.sd, self.ctx = cfg, sd, ctx_id
+        self.device = torch.device("cpu")
+
+    def vit_tokens(self, pv):
+        return O.shuffled_tokens(O.vit_forward(self.sd, self.cfg, pv), self.cfg.downsample_ratio)
+
+    def __call__(self, mos, pixel_values, input_ids, attention_mask, image_flags, labels, motion_feature, visual_tokens):
+        vit = O.projector(self.sd, "mlp1", visual_tokens)
+        vit = vit[image_flags.squeeze(-1) == 1]
+        mot = O.projector(self.sd, "motion_mlp", motion_feature)
+        emb = O.scatter_embeds(self.sd, input_ids, self.ctx, vit, mot)
+        hidden, _, _ = O.llm_forward(self.sd, self.cfg, emb, attention_mask)
+        logits = O.lm_logits(self.sd, hidden)
+        amax = logits[..., :-1, :].argmax(-1)
+        keep = labels[:, 1:] != -100
+        logit = torch.where(keep, amax, torch.full_like(amax, -1)).reshape(-1)
+        return {"logit": logit, "score1": O.score_head(self.sd, self.cfg, hidden[:, -4, :]).squeeze(1)}
+
+
+def _case():
+    cfg = pkg.tiny(vit_hidden=64, vit_heads=1, vit_layers=1, vit_inter=128, llm_hidden=256, llm_heads=2, llm_kv_heads=1,
+                   llm_layers=1, llm_inter=256, vocab=256, image_size=56, score_dims=(32, 1), motion_dim=128)
+    sd = synth.make_state_dict(cfg, seed=5, dtype=torch.float32, rich=True)
+    B, T = 3, 2            # 6 frames over 2 ranks = 3+3 (splits clip 1), 3 clips over 2 ranks = 2+1
+    toks = synth.canonical_tokens(cfg, B, T, seed=5)
+    pv = synth.synthetic_frames(B * T, 56, seed=5, dtype=torch.float32)
+    motion = synth.synthetic_motion(B, 128, seed=5, dtype=torch.float32)
+    return cfg, sd, toks, pv, motion, B, T
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    dist_utils.init_dist("pytorch", backend="gloo")
+    cfg, sd, toks, pv, motion, B, T = _case()
+    model = OracleBackedModel(cfg, sd, toks["img_context_token_id"])
+    out = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
+                                    toks["labels"], motion)
+    q.put((rank, out["score1"].float().tolist(), out["logit"].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_dp_two_ranks_equals_single_process():
+    cfg, sd, toks, pv, motion, B, T = _case()
+    ref = O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
+                         toks["labels"], motion, toks["img_context_token_id"], stage=2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_logit = torch.where(ref["label"] != -100, ref["logit"], torch.full_like(ref["logit"], -1)).tolist()
+    for rank, score, logit in res:
+        assert logit == want_logit, f"rank {rank}"
+        assert torch.allclose(torch.tensor(score).to(torch.bfloat16).float(), ref["score1"].to(torch.bfloat16).float(), atol=1e-6), (score, ref["score1"])
+
+
+def test_even_split_and_init_dist_errors():
+    assert dist_utils.even_split(8, 8) == [(i, i + 1) for i in range(8)]
+    assert dist_utils.even_split(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert sum(h - l for l, h in dist_utils.even_split(7, 3)) == 7
+    with pytest.raises(ValueError):
+        dist_utils.init_dist("bogus")

