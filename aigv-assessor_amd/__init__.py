@@ -8,3 +8,13 @@ from .config import (InternLM2Config, InternVisionConfig, InternVLChatConfig, in
 
 __all__ = ["InternVLChatConfig", "InternVisionConfig", "InternLM2Config", "internvl2_8b",
            "internvl2_26b", "tiny"]
+
+
+def __getattr__(name):  # lazy: importing the package must not require torch.cuda / the built library
+    if name == "InternVLChatModel":
+        from .modeling import InternVLChatModel
+        return InternVLChatModel
+    if name in ("init_dist", "score_clips_dp"):
+        from . import dist_utils
+        return getattr(dist_utils, name)
+    raise AttributeError(name)
