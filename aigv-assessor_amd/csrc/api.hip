@@ -64,6 +64,7 @@ struct aigv_ctx {
   bf16_t *l_h = nullptr, *l_t = nullptr, *l_qkv = nullptr, *l_ao = nullptr, *l_ffn = nullptr, *l_rows = nullptr;
   int32_t *l_pos = nullptr, *l_seq = nullptr, *l_cu = nullptr, *l_rowidx = nullptr, *l_kvlen = nullptr;
   unsigned long long* l_packed = nullptr;
+  bf16_t* l_score_ws = nullptr;
   bf16_t *kc = nullptr, *vc = nullptr;   // [layer][seq][kv head][cap][D]
   std::vector<int32_t> h_pos, h_seq, h_rowidx, h_kvlen;
   int kv_seqs = 0;
@@ -157,11 +158,63 @@ struct ProfScope {
   }
 };
 
-int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
-  if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
+// ---- GEMM dispatch: pick the tile kernel by a wave-quantisation cost model ------------------------------------
+// g_gemm_mode: 0 = auto, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel (where its shape rules allow)
+int g_gemm_mode = 0;
+double g_rate256 = 1.46;   // measured throughput of the 256 kernel relative to the 128 kernel at full occupancy
+
+// Costs in units of "one full round of the 128x128 kernel" (512 tiles: 256 CUs x 2 co-resident workgroups).
+double g_lone128 = 0.70;   // a last round that fills at most one workgroup per CU runs faster per tile
+double cost128(int M, int N) {
+  if (M <= 0) return 0;
+  const long tiles = (long)((M + 127) / 128) * (N / 128);
+  const long full = tiles / 512, part = tiles % 512;
+  return (double)full + (part == 0 ? 0.0 : part <= 256 ? g_lone128 : 1.0);
+}
+double cost256(int M, int N) {   // one workgroup per CU; a round = 256 tiles of 4x the work at g_rate256 x the speed
+  if (M <= 0) return 0;
+  const long tiles = (long)((M + 255) / 256) * (N / 256);
+  return (double)((tiles + 255) / 256) * 2.0 / g_rate256;
+}
+
+int launch_one(aigv_ctx* c, const GemmArgs& a, int epi, bool use256, hipStream_t s) {
   ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N), s);
-  HIPCHK(c, aigv_launch_gemm(a, epi, s));
+  HIPCHK(c, use256 ? aigv_launch_gemm256(a, epi, s) : aigv_launch_gemm(a, epi, s));
+  return 0;
+}
+
+// The first R*256 rows go to the 256x256 kernel, the remaining rows to the 128x128 kernel (rows are independent);
+// R is chosen so that the big kernel runs whole rounds and the ragged tail lands on the small tiles.
+int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
+  if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
+  const bool ok256 = aigv_gemm256_supported(a);
+  if (g_gemm_mode == 1 || !ok256) return launch_one(c, a, epi, false, s);
+  if (g_gemm_mode == 2) return launch_one(c, a, epi, true, s);
+  double best = cost256(a.M, a.N);
+  int bestR = -1;                               // -1: everything (ragged last tile included) on the 256 kernel
+  if (epi != EPI_PATCH) {
+    for (int R = 0; R * 256 <= a.M; ++R) {
+      const double cst = cost256(R * 256, a.N) + cost128(a.M - R * 256, a.N) + ((R > 0 && R * 256 < a.M) ? 0.02 : 0.0);
+      if (cst < best) { best = cst; bestR = R; }
+    }
+  } else if (cost128(a.M, a.N) < best) {
+    bestR = 0;
+  }
+  if (bestR < 0) return launch_one(c, a, epi, true, s);
+  if (bestR == 0) return launch_one(c, a, epi, false, s);
+  const int Mmain = bestR * 256;
+  GemmArgs top = a;
+  top.M = Mmain;
+  TRY(launch_one(c, top, epi, true, s));
+  if (Mmain < a.M) {
+    GemmArgs bot = a;
+    bot.M = a.M - Mmain;
+    bot.A = a.A + (size_t)Mmain * a.lda;
+    bot.C = a.C + (size_t)Mmain * a.ldc;
+    if (a.resid) bot.resid = a.resid + (size_t)Mmain * a.ldr;
+    return launch_one(c, bot, epi, false, s);
+  }
   return 0;
 }
 
@@ -271,6 +324,11 @@ int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out) {
     if ((rc = dalloc(c, &c->l_rowidx, (size_t)k.max_out_rows + k.max_seqs + 64))) break;
     if ((rc = dalloc(c, &c->l_kvlen, (size_t)k.max_seqs))) break;
     if ((rc = dalloc(c, &c->l_packed, (size_t)64))) break;
+    {
+      int maxd = k.llm_hidden;
+      for (int i = 0; i < k.n_score_layers; ++i) maxd = std::max(maxd, (int)k.score_dims[i]);
+      if ((rc = dalloc(c, &c->l_score_ws, (size_t)3 * 64 * maxd))) break;
+    }
     if (k.kv_capacity > 0) {
       const size_t per = (size_t)k.llm_layers * k.max_seqs * k.llm_kv_heads * k.kv_capacity * c->head_dim;
       if ((rc = dalloc(c, &c->kc, per))) break;
@@ -467,7 +525,6 @@ int aigv_finalize_weights(aigv_ctx* c) {
     TRY(need(c, p + "weight", (size_t)c->score.dims[j + 1] * c->score.dims[j], &c->score.w[j]));
     TRY(need(c, p + "bias", (size_t)c->score.dims[j + 1], &c->score.b[j]));
   }
-  if (H > 4096) return fail(c, AIGV_ERR_ARG, "score head input wider than 4096 is not supported yet");
   c->finalized = true;
   return 0;
 }
@@ -617,10 +674,11 @@ static int final_rows(aigv_ctx* c, const int32_t* score_rows, float* score, int 
   HIPCHK(c, hipMemcpyAsync(c->l_rowidx, c->h_rowidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
   // final RMSNorm only on the rows that are consumed (modeling_internlm2.py:984)
   HIPCHK(c, aigv_launch_rmsnorm(hidden, H, c->final_norm, c->l_rows, H, n, H, k.rms_eps, c->l_rowidx, s));
-  if (nS) {
+  for (int b0 = 0; b0 < nS; b0 += 64) {
+    // NB: the reference's NaN guard looks at the whole batch slice; batches above 64 clips are guarded per 64
     ScoreHeadArgs a = c->score;
-    a.x = c->l_rows; a.ldx = H; a.B = nS; a.score = score;
-    HIPCHK(c, aigv_launch_score_head(a, s));
+    a.x = c->l_rows + (size_t)b0 * H; a.ldx = H; a.B = std::min(64, nS - b0); a.score = score + b0;
+    HIPCHK(c, aigv_launch_score_head(a, c->l_score_ws, s));
   }
   for (int r0 = 0; r0 < R; r0 += 64) {
     const int rr = std::min(64, R - r0);
@@ -829,6 +887,13 @@ int aigv_op_lm_head_argmax(const void* h, int rows, int hidden, const void* W_, 
 }
 
 // ---- measurement -----------------------------------------------------------------------------------------------
+int aigv_tune_gemm(int mode, double rate256) {
+  if (mode < 0 || mode > 2) return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_gemm: mode must be 0 (auto), 1 (128 tile) or 2 (256 tile)");
+  g_gemm_mode = mode;
+  if (rate256 > 0) g_rate256 = rate256;
+  return 0;
+}
+
 int aigv_prof_enable(aigv_ctx* c, int on) {
   if (!c) return fail(c, AIGV_ERR_ARG, "null ctx");
   c->prof = on != 0;

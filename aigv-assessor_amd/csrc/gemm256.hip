@@ -1,0 +1,285 @@
+// bf16 GEMM, 256x256x64 tile, 8 waves, phase-interleaved schedule for gfx950 (one workgroup per CU).
+//
+//   C[M,N] = epilogue(A[M,K] . W[N,K]^T), same operand layouts and epilogues as gemm.hip.
+//
+// Why a second kernel: the 128x128 / one-barrier-per-K-step kernel tops out near 900 TFLOP/s (every wave
+// stalls together on the vmcnt(0)+barrier of each K step).  Here each SIMD holds two waves that alternate
+// roles: while one multiplies (16 MFMAs), the other reads its next fragments from LDS and issues the LDS-DMA
+// prefetch, separated by raw s_barriers; the DMA runs ~4 phases ahead behind a COUNTED vmcnt.
+//
+// Geometry
+//   8 waves = 2 (M, "group" g = wave>>2) x 4 (N); wave tile 128 x 64 = (2 m-halves x 4) x (2 n-halves x 2) MFMA
+//   16x16x32 tiles; 128 accumulator VGPRs.  A K-tile (64 deep) takes 4 phases, one 64x32 output quadrant each:
+//     j=0: A(mh0) x B(nh0)   j=1: A(mh0) x B(nh1)   j=2: A(mh1) x B(nh1)   j=3: A(mh1) x B(nh0)
+//   LDS: 2 buffers x 4 units x 16 KB = 128 KB.  A unit is what ONE phase reads (all waves):
+//     V0 = A rows {g*128 + 0..63}, V1 = A rows {g*128 + 64..127}, V2 = W rows {wc*64 + 0..31}, V3 = W rows {wc*64 + 32..63}
+//   each 128 rows x 128 B, filled by 16 global_load_lds wave-instructions (2 per wave), 16-B chunk index
+//   XOR-swizzled with (row & 7) on the SOURCE address and on the ds_read_b128 fragment reads.
+//
+// Schedule (program order of one wave; group 1 runs one barrier behind group 0, so on every SIMD one wave is in its
+// MFMA segment while the other is in its load segment):
+//   LOAD(p):  ds_read the fragments phase p needs (j=0: A(mh0)+B(nh0), j=1: B(nh1), j=2: A(mh1), j=3: none)
+//             issue the LDS-DMA of stream unit 6+p  (stream order per tile: V0, V2, V3, V1)
+//             s_waitcnt vmcnt(8)                    (4 units stay in flight)
+//   s_barrier ; MFMA(p): 16 x v_mfma_f32_16x16x32_bf16 ; s_barrier
+// Hazards (intervals between consecutive barriers are numbered; group g runs LOAD(p) in interval 2p+g):
+//   RAW  a unit read in LOAD(q) was waited for (vmcnt) by every wave at the end of its LOAD(q-1), i.e. before the
+//        barrier that precedes the reader's interval - also across the one-barrier stagger.
+//   WAR  unit X of tile t is last read in LOAD(4t+{0,0,1,2}) for {V0,V2,V3,V1}; its refill for tile t+2 is issued in
+//        LOAD(4t+{2,3,4,5}) - at least 3 intervals after the last reader's interval, whose ds_reads completed
+//        (lgkmcnt(0)) right after the barrier that ended it.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int UNIT = 128 * 128;            // bytes per unit (128 rows x 64 bf16)
+constexpr int BUF = 4 * UNIT;              // one K-tile
+constexpr int LDS_BYTES = 2 * BUF;         // 128 KB
+constexpr int GROUP_M256 = 4;
+
+#define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+__device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uniform
+  if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wc = wave & 3;
+
+  // ---- tile mapping: XCD-aware bijective remap, then groups of GROUP_M256 row-tiles sweep the column tiles ----
+  const int nbm = (p.M + TM - 1) / TM, nbn = p.N / TN;
+  const int nwg = nbm * nbn;
+  int wg;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int per_group = GROUP_M256 * nbn;
+  const int grp = wg / per_group, first_m = grp * GROUP_M256;
+  const int gsz = min(nbm - first_m, GROUP_M256);
+  const int in_g = wg - grp * per_group;
+  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  const int m0 = tm * TM, n0 = tn * TN;
+
+  // ---- LDS-DMA source pointers: this wave fills unit rows 16*wave .. 16*wave+15 (two 8-row wave-instructions) ----
+  // unit row r -> tile row:  V0: (r>>6)*128 + (r&63)   V1: +64   V2: (r>>5)*64 + (r&31)   V3: +32
+  const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+  const bf16_t* src[4][2];   // [unit][instr], at k = 0
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wave * 16 + i * 8 + lr;
+    const int ra0 = (r >> 6) * 128 + (r & 63), rb0 = (r >> 5) * 64 + (r & 31);
+    src[0][i] = p.A + (size_t)min(m0 + ra0, p.M - 1) * p.lda + lc * 8;
+    src[1][i] = p.A + (size_t)min(m0 + ra0 + 64, p.M - 1) * p.lda + lc * 8;
+    src[2][i] = p.W + (size_t)(n0 + rb0) * p.ldw + lc * 8;
+    src[3][i] = p.W + (size_t)(n0 + rb0 + 32) * p.ldw + lc * 8;
+  }
+  const int nk = p.K / TK;
+  const int n_units = 4 * nk;
+  // stream position o within a tile: 0 -> V0, 1 -> V2, 2 -> V3, 3 -> V1 (o is a compile-time constant at every call)
+  auto issue = [&](int tile, int o) {
+    if (tile >= nk) return;
+    const int unit = (o == 0) ? 0 : (o == 1) ? 2 : (o == 2) ? 3 : 1;
+    char* dst = smem + (tile & 1) * BUF + unit * UNIT + wave * 2048;
+    const int k0 = tile * TK;
+    glds16(src[unit][0] + k0, dst);
+    glds16(src[unit][1] + k0, dst + 1024);
+  };
+
+  // ---- fragment read offsets (bytes inside a unit) ----
+  const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+  int offA[2], offB[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const int phys = (kh * 4 + fq) ^ sw;
+    offA[kh] = (g * 64 + fr) * 128 + phys * 16;     // + mt*16*128
+    offB[kh] = (wc * 32 + fr) * 128 + phys * 16;    // + nt*16*128
+  }
+
+  f32x4 acc[2][4][2][2];   // [mh][mt][nh][nt]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];   // A(mh) [mt][kh]; B(nh0) / B(nh1) [nt][kh]
+
+  // ---- prologue: stream units 0..5, then make units 0,1 (V0, V2 of tile 0) visible ----
+  issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3); issue(1, 0); issue(1, 1);
+  {
+    const int issued = min(6, n_units);
+    wait_vm(2 * max(0, issued - 2));
+  }
+  RAW_BARRIER();
+  if (g == 1) RAW_BARRIER();   // stagger: group 1 runs one barrier behind group 0
+
+  const int n_phase = 4 * nk;
+  for (int t = 0; t < nk; ++t) {
+    const char* sb = smem + (t & 1) * BUF;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ph = 4 * t + j;
+      // ---------------- LOAD(ph) ----------------
+      if (j == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) fb0[nt][kh] = *(const bf16x8*)(sb + 2 * UNIT + offB[kh] + nt * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) fa[mt][kh] = *(const bf16x8*)(sb + 0 * UNIT + offA[kh] + mt * 2048);
+      } else if (j == 1) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) fb1[nt][kh] = *(const bf16x8*)(sb + 3 * UNIT + offB[kh] + nt * 2048);
+      } else if (j == 2) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh) fa[mt][kh] = *(const bf16x8*)(sb + 1 * UNIT + offA[kh] + mt * 2048);
+      }
+      // stream unit 6 + ph: j=0 -> V3(t+1), j=1 -> V1(t+1), j=2 -> V0(t+2), j=3 -> V2(t+2)
+      if (j == 0) issue(t + 1, 2);
+      if (j == 1) issue(t + 1, 3);
+      if (j == 2) issue(t + 2, 0);
+      if (j == 3) issue(t + 2, 1);
+      wait_vm(2 * max(0, min(4, n_units - 3 - ph)));
+      __builtin_amdgcn_sched_barrier(0);
+      RAW_BARRIER();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- MFMA(ph) ----------------
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            if (j == 0) acc[0][mt][0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[nt][kh], fa[mt][kh], acc[0][mt][0][nt], 0, 0, 0);
+            if (j == 1) acc[0][mt][1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[nt][kh], fa[mt][kh], acc[0][mt][1][nt], 0, 0, 0);
+            if (j == 2) acc[1][mt][1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[nt][kh], fa[mt][kh], acc[1][mt][1][nt], 0, 0, 0);
+            if (j == 3) acc[1][mt][0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[nt][kh], fa[mt][kh], acc[1][mt][0][nt], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      RAW_BARRIER();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  (void)n_phase;
+  if (g == 0) RAW_BARRIER();   // balance the stagger barrier
+
+  // ---- epilogue: lane owns C[m][n .. n+3] ----
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + g * 128 + mh * 64 + mt * 16 + fr;
+      if (m >= p.M) continue;
+      if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          const int n = (n0 + wc * 64 + nh * 32) / 2 + fq * 4;
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float gt = rbf(acc[mh][mt][nh][0][e]), up = rbf(acc[mh][mt][nh][1][e]);
+            o[e] = f2bf(rbf(silu_f(gt)) * up);
+          }
+          *(u16x4*)(p.C + (size_t)m * p.ldc + n) = o;
+        }
+      } else {
+        size_t orow = (size_t)m;
+        const bf16_t* posrow = nullptr;
+        if constexpr (EPI == EPI_PATCH) {
+          const int f = m / p.np, pi = m - f * p.np;
+          orow = (size_t)m + f + 1;
+          posrow = p.pos + (size_t)(pi + 1) * p.N;
+        }
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + wc * 64 + nh * 32 + nt * 16 + fq * 4;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[mh][mt][nh][nt][e];
+            if (p.bias) {
+              const u16x4 b = *(const u16x4*)(p.bias + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+            if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+            }
+            if constexpr (EPI == EPI_LS_RESID) {
+              const u16x4 s = *(const u16x4*)(p.ls + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] * bf2f(s[e]));
+            }
+            if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) {
+              const u16x4 r = *(const u16x4*)(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rbf(bf2f(r[e]) + v[e]);
+            }
+            if constexpr (EPI == EPI_PATCH) {
+              const u16x4 ps = *(const u16x4*)(posrow + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] + bf2f(ps[e]));
+            }
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            *(u16x4*)(p.C + orow * p.ldc + n) = o;
+          }
+      }
+    }
+}
+
+template <int EPI>
+hipError_t launch256(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
+  hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(nbm * nbn), dim3(512), LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0 && a.M >= 1; }
+
+hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
+  switch (epi) {
+    case EPI_STORE: return launch256<EPI_STORE>(a, s);
+    case EPI_GELU: return launch256<EPI_GELU>(a, s);
+    case EPI_LS_RESID: return launch256<EPI_LS_RESID>(a, s);
+    case EPI_RESID: return launch256<EPI_RESID>(a, s);
+    case EPI_SWIGLU: return launch256<EPI_SWIGLU>(a, s);
+    case EPI_PATCH: return launch256<EPI_PATCH>(a, s);
+  }
+  return hipErrorInvalidValue;
+}

@@ -12,7 +12,7 @@
 
 namespace {
 
-enum { SK_STORE = 0, SK_RESID = 1, SK_SWIGLU = 2, SK_GELU = 3, SK_ARGMAX = 4 };
+enum { SK_STORE = 0, SK_RESID = 1, SK_SWIGLU = 2, SK_GELU = 3, SK_ARGMAX = 4, SK_RELU = 5 };
 
 __device__ __forceinline__ unsigned int ord_f32(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -132,6 +132,10 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
         }
+        if constexpr (EPI == SK_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         if constexpr (EPI == SK_RESID) {
           const u16x4 rr = *(const u16x4*)(resid + (size_t)r * ldr + n);
 #pragma unroll
@@ -162,33 +166,40 @@ __global__ void unpack_argmax_kernel(const unsigned long long* __restrict__ pack
 // ---- score head ------------------------------------------------------------------------------------------
 // x = hidden[:, -4, :] (post final norm); if ANY NaN is present in the batch slice the reference applies
 // nan_to_num(nan=0, posinf=1e9, neginf=-1e9) to every row (modeling_internvl_chat.py:469-473); then a chain
-// of Linear+ReLU with a bf16 rounding after each Linear (:82-94).
-__global__ __launch_bounds__(256) void score_head_kernel(const ScoreHeadArgs a) {
-  __shared__ float buf[2][4096];
+// of Linear+ReLU with a bf16 rounding after each Linear (:82-94).  The wide layers run on the skinny GEMM
+// (weights streamed once for all clips); the narrow tail (fan-in < 128) runs in one small kernel.
+__global__ __launch_bounds__(256) void score_guard_kernel(const bf16_t* __restrict__ x, int ldx, int B, int H,
+                                                          bf16_t* __restrict__ out) {
   __shared__ int any_nan;
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int H = a.dims[0];
   if (threadIdx.x == 0) any_nan = 0;
   __syncthreads();
   int nan_here = 0;
-  for (int i = threadIdx.x; i < a.B * H; i += 256) {
-    const float v = bf2f(a.x[(size_t)(i / H) * a.ldx + (i % H)]);
+  for (int i = threadIdx.x; i < B * H; i += 256) {
+    const float v = bf2f(x[(size_t)(i / H) * ldx + (i % H)]);
     nan_here |= (v != v);
   }
   if (nan_here) atomicOr(&any_nan, 1);
   __syncthreads();
   const bool fix = any_nan != 0;
-  for (int i = threadIdx.x; i < H; i += 256) {
-    float v = bf2f(a.x[(size_t)b * a.ldx + i]);
+  for (int i = threadIdx.x; i < B * H; i += 256) {
+    float v = bf2f(x[(size_t)(i / H) * ldx + (i % H)]);
     if (fix) {
       if (v != v) v = 0.f;
-      else if (isinf(v)) v = rbf(v > 0 ? 1e9f : -1e9f);
+      else if (isinf(v)) v = v > 0 ? 1e9f : -1e9f;
     }
-    buf[0][i] = v;
+    out[i] = f2bf(v);
   }
+}
+
+// remaining narrow layers: one workgroup per clip; activations ping-pong in LDS (all dims <= 1024 here)
+__global__ __launch_bounds__(256) void score_tail_kernel(const ScoreHeadArgs a, int first_layer) {
+  __shared__ float buf[2][1024];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d0 = a.dims[first_layer];
+  for (int i = threadIdx.x; i < d0; i += 256) buf[0][i] = bf2f(a.x[(size_t)b * a.ldx + i]);
   __syncthreads();
   int cur = 0;
-  for (int L = 0; L < a.n_layers; ++L) {
+  for (int L = first_layer; L < a.n_layers; ++L) {
     const int din = a.dims[L], dout = a.dims[L + 1];
     const bf16_t* w = a.w[L];
     const bf16_t* bb = a.b[L];
@@ -254,11 +265,39 @@ hipError_t aigv_launch_lm_head_argmax(const bf16_t* h, int R, int H, const bf16_
   return hipGetLastError();
 }
 
-hipError_t aigv_launch_score_head(const ScoreHeadArgs& a, hipStream_t s) {
+// scratch: 3 * B * max(dims) bf16 (guarded input + two ping-pong activations)
+hipError_t aigv_launch_score_head(const ScoreHeadArgs& a, bf16_t* scratch, hipStream_t s) {
   if (a.B <= 0) return hipSuccess;
-  if (a.n_layers < 1 || a.n_layers > 8) return hipErrorInvalidValue;
-  for (int i = 0; i <= a.n_layers; ++i)
-    if (a.dims[i] <= 0 || a.dims[i] > 4096) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(score_head_kernel, dim3(a.B), dim3(256), 0, s, a);
+  if (a.n_layers < 1 || a.n_layers > 8 || a.B > 64 || !scratch) return hipErrorInvalidValue;
+  int maxd = 0;
+  for (int i = 0; i <= a.n_layers; ++i) {
+    if (a.dims[i] <= 0) return hipErrorInvalidValue;
+    maxd = a.dims[i] > maxd ? a.dims[i] : maxd;
+  }
+  bf16_t* xg = scratch;
+  bf16_t* pp[2] = {scratch + (size_t)a.B * maxd, scratch + (size_t)2 * a.B * maxd};
+  hipLaunchKernelGGL(score_guard_kernel, dim3(1), dim3(256), 0, s, a.x, a.ldx, a.B, a.dims[0], xg);
+  const bf16_t* cur = xg;
+  int ld = a.dims[0], L = 0, flip = 0;
+  for (; L < a.n_layers; ++L) {
+    const int din = a.dims[L], dout = a.dims[L + 1];
+    if (din % 128 || dout % 4) break;
+    hipError_t e = launch_skinny<SK_RELU>(cur, ld, a.B, a.w[L], din, dout, din, a.b[L], nullptr, 0, pp[flip], dout, nullptr, s);
+    if (e != hipSuccess) return e;
+    cur = pp[flip];
+    ld = dout;
+    flip ^= 1;
+  }
+  if (L < a.n_layers) {
+    if (a.dims[L] > 1024) return hipErrorInvalidValue;
+    for (int i = L + 1; i <= a.n_layers; ++i)
+      if (a.dims[i] > 1024) return hipErrorInvalidValue;
+    ScoreHeadArgs t = a;
+    t.x = cur;
+    t.ldx = ld;
+    hipLaunchKernelGGL(score_tail_kernel, dim3(a.B), dim3(256), 0, s, t, L);
+  } else {
+    return hipErrorInvalidValue;   // the last layer (fan-out 1) always runs in the tail kernel
+  }
   return hipGetLastError();
 }

@@ -29,7 +29,9 @@ struct GemmArgs {
 };
 
 const char* aigv_gemm_check(const GemmArgs& a, int epi);   // nullptr if the shapes fit the kernel
-hipError_t aigv_launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+hipError_t aigv_launch_gemm(const GemmArgs& a, int epi, hipStream_t s);           // 128x128 tile kernel (gemm.hip)
+bool aigv_gemm256_supported(const GemmArgs& a);
+hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);        // 256x256 phase-interleaved kernel
 
 // ---- attention ------------------------------------------------------------------------------------
 // Packed varlen layout: sequence s occupies rows cu[s] .. cu[s+1]-1 of the token-major buffers.
@@ -91,7 +93,8 @@ struct ScoreHeadArgs {
   const bf16_t* w[8]; const bf16_t* b[8];
   float* score;                         // [B] (the bf16 result widened to fp32)
 };
-hipError_t aigv_launch_score_head(const ScoreHeadArgs& a, hipStream_t s);
+// scratch: 3 * B * max(dims) bf16; B <= 64 per call
+hipError_t aigv_launch_score_head(const ScoreHeadArgs& a, bf16_t* scratch, hipStream_t s);
 // KV-cache append for decode: copies the K/V slots of fused qkv rows into [n_seq, n_kv, cap, D] caches
 hipError_t aigv_launch_kv_store(const bf16_t* qkv, int ld, const int32_t* seq_of_tok, const int32_t* pos,
                                 bf16_t* kc, bf16_t* vc, int tokens, int n_groups, int g, int D, int cap,

@@ -128,6 +128,10 @@ int aigv_op_im2col(const void* frames, int n_frames, int channels, int image_siz
 int aigv_op_lm_head_argmax(const void* h, int rows, int hidden, const void* W, int vocab, void* scratch_u64,
                            int64_t* idx, float* val, void* stream);
 
+/* GEMM tile-kernel selection: mode 0 = cost model (default), 1 = always the 128x128 kernel, 2 = always the 256x256
+ * phase-interleaved kernel where N % 256 == 0; rate256 > 0 overrides the model's relative throughput of the 256 kernel. */
+int aigv_tune_gemm(int mode, double rate256);
+
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* When enabled every GEMM / attention launch of the hot path is bracketed by HIP events on the launch stream. */
 enum aigv_prof_class { AIGV_PROF_GEMM = 0, AIGV_PROF_ATTN_VIT = 1, AIGV_PROF_ATTN_LLM = 2, AIGV_PROF_SKINNY = 3,
