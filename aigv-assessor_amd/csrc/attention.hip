@@ -15,10 +15,10 @@
 //                              V tile, in the accumulator's permuted key order
 //                              (key = 16s + 8(j>>2) + 4h + (j&3), guide §3 "accumulator tile as operand").
 //
-// Rounding points follow the reference's eager path where that is free: the q pre-scale rounds to bf16
-// (exact for d^-1/2 = 2^-3), the raw score rounds to bf16, the LLM's division by sqrt(d) rounds again,
-// softmax runs in fp32, P rounds to bf16 before P·V, the output rounds to bf16.  (The reference
-// normalises P before rounding; here P is rounded un-normalised and the row is divided at the end.)
+// Numerics: the q pre-scale rounds to bf16 (exact for d^-1/2 = 2^-3), scores and the softmax stay in fp32 (the
+// reference rounds its score matrix to bf16 once or twice - extra noise this kernel does not reproduce), P rounds
+// to bf16 before P·V (un-normalised; the row is divided at the end), the output rounds to bf16.  Against fp64
+// truth the kernel is at least as accurate as the reference's eager path (tests/test_gpu_ops.py).
 #include "common.h"
 #include "kernels.h"
 
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   const int hk = hq / g;
   const int row0 = p.cu[seq];
   const int len = p.cu[seq + 1] - row0;          // queries (= keys appended this call)
-  const int q0 = blockIdx.x * QB;
+  // causal work grows with the query block index: launch the heaviest blocks first
+  const int q0 = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QB;
   if (q0 >= len) return;
   const int kv_len = len + p.kv_len_offset;       // keys visible in total (prefill: offset 0)
   const int qw = q0 + wave * 32;                  // first query row of this wave
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float LOG2E = 1.4426950408889634f;
+  const float sc = 1.4426950408889634f / p.post_div;   // scores stay fp32: exp2(s*sc - m*sc) = exp((s - m)/post_div)
 
   // transposed-read lane constants: 16-lane group gi = lane>>4 -> d columns 16*(gi&1).., key rows 4*(gi>>1)..
   const int li = lane & 15, gi = lane >> 4;
@@ -155,42 +156,53 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
       }
     }
 
-    // ---- scores: bf16 rounding points, mask, online softmax -----------------------------------------
+    // ---- online softmax on the fp32 scores (one FMA + one exp2 per element) ---------------------------------
+    // p = exp2(s * c - m * c), c = log2(e) / post_div.  The mask is only evaluated on tiles that need it (the
+    // causal diagonal / the ragged last tile); the O rescale is skipped when no row maximum moved (wave-uniform).
     const int qpos = qw + c + p.kv_len_offset;   // index of the last key this query may see (causal)
+    const bool need_mask = (key0 + KT > kv_len) || (CAUSAL && key0 + KT - 1 > qw + p.kv_len_offset);
     float tmax = -INFINITY;
+    if (need_mask) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+      for (int st = 0; st < 2; ++st)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = key0 + st * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float s = rbf(sacc[st][e]);
-        if (p.post_div != 1.0f) s = rbf(s / p.post_div);
-        const bool vis = key < kv_len && (!CAUSAL || key <= qpos);
-        s = vis ? s : -INFINITY;
-        sacc[st][e] = s;
-        tmax = fmaxf(tmax, s);
-      }
+        for (int e = 0; e < 16; ++e) {
+          const int key = key0 + st * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const bool vis = key < kv_len && (!CAUSAL || key <= qpos);
+          const float sv = vis ? sacc[st][e] : -INFINITY;
+          sacc[st][e] = sv;
+          tmax = fmaxf(tmax, sv);
+        }
+    } else {
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[st][e]);
+    }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    // rows with no visible key yet keep m = -inf; guard the exp arguments
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f((m_run - m_use) * LOG2E);   // m_run = -inf -> 0
+    if (__any(m_new != m_run)) {
+      // rows with no visible key yet keep m = -inf; guard the exp argument (m_run = -inf -> alpha = 0)
+      const float alpha = (m_new == -INFINITY) ? 1.0f : exp2f((m_run - m_new) * sc);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = (m_new == -INFINITY) ? 0.f : m_new * sc;
     float psum = 0.f;
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = exp2f((sacc[st][e] - m_use) * LOG2E);
+        const float pv = exp2f(fmaf(sacc[st][e], sc, -mc));
         psum += pv;
         sacc[st][e] = pv;
       }
     psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < NDT; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T · P^T ---------------------------------------------------------------------------
 #pragma unroll
