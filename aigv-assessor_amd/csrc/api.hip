@@ -184,19 +184,42 @@ int launch_one(aigv_ctx* c, const GemmArgs& a, int epi, bool use256, hipStream_t
   return 0;
 }
 
-// The first R*256 rows go to the 256x256 kernel, the remaining rows to the 128x128 kernel (rows are independent);
-// R is chosen so that the big kernel runs whole rounds and the ragged tail lands on the small tiles.
+int skinny_epi(int epi) {   // GEMM epilogue -> skinny-kernel epilogue (same rounding points); -1 if none
+  switch (epi) {
+    case EPI_STORE: return 0;
+    case EPI_GELU: return 3;
+    case EPI_LS_RESID: return 6;
+    case EPI_RESID: return 1;
+    case EPI_SWIGLU: return 2;
+  }
+  return -1;
+}
+// a <= 64-row remainder streamed through the skinny kernel costs ~ the weight bytes at HBM rate
+double cost_skinny(int rows, int N, int K) {
+  if (rows <= 0) return 0;
+  if (rows > 64 || K % 128) return 1e30;
+  return 0.15 + 3.0e-5 * N;
+}
+
+// The first R*256 rows go to the 256x256 kernel, the remaining rows to the 128x128 kernel or (<= 64 rows) to the
+// weight-streaming skinny kernel (rows are independent); R is chosen so that the big kernel runs whole rounds.
 int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
   const bool ok256 = aigv_gemm256_supported(a);
   if (g_gemm_mode == 1 || !ok256) return launch_one(c, a, epi, false, s);
   if (g_gemm_mode == 2) return launch_one(c, a, epi, true, s);
+  const int sk = skinny_epi(epi);
   double best = cost256(a.M, a.N);
   int bestR = -1;                               // -1: everything (ragged last tile included) on the 256 kernel
+  bool rem_skinny = false;
   if (epi != EPI_PATCH) {
     for (int R = 0; R * 256 <= a.M; ++R) {
-      const double cst = cost256(R * 256, a.N) + cost128(a.M - R * 256, a.N) + ((R > 0 && R * 256 < a.M) ? 0.02 : 0.0);
-      if (cst < best) { best = cst; bestR = R; }
+      const int rem = a.M - R * 256;
+      const double c_main = cost256(R * 256, a.N) + ((R > 0 && rem > 0) ? 0.02 : 0.0);
+      const double c128 = c_main + cost128(rem, a.N);
+      const double csk = (sk >= 0 && R > 0) ? c_main + cost_skinny(rem, a.N, a.K) : 1e30;
+      if (c128 < best) { best = c128; bestR = R; rem_skinny = false; }
+      if (csk < best) { best = csk; bestR = R; rem_skinny = true; }
     }
   } else if (cost128(a.M, a.N) < best) {
     bestR = 0;
@@ -213,6 +236,13 @@ int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
     bot.A = a.A + (size_t)Mmain * a.lda;
     bot.C = a.C + (size_t)Mmain * a.ldc;
     if (a.resid) bot.resid = a.resid + (size_t)Mmain * a.ldr;
+    if (rem_skinny) {
+      ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * bot.M * (double)a.N * a.K, 2.0 * (double)a.N * a.K, s);
+      hipError_t e = aigv_launch_skinny_gemm(bot.A, bot.lda, bot.M, bot.W, bot.ldw, bot.N, bot.K, bot.bias, bot.resid, bot.ldr,
+                                            bot.C, bot.ldc, sk, s, bot.ls);
+      if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "skinny remainder (M=%d N=%d K=%d): %s", bot.M, bot.N, bot.K, hipGetErrorString(e));
+      return 0;
+    }
     return launch_one(c, bot, epi, false, s);
   }
   return 0;
@@ -248,6 +278,8 @@ int need(aigv_ctx* c, const std::string& name, size_t elems, const bf16_t** out)
 }
 
 }  // namespace
+
+extern int g_gemm256_variant;
 
 // ==========================================================================================================
 extern "C" {
@@ -888,7 +920,13 @@ int aigv_op_lm_head_argmax(const void* h, int rows, int hidden, const void* W_, 
 
 // ---- measurement -----------------------------------------------------------------------------------------------
 int aigv_tune_gemm(int mode, double rate256) {
-  if (mode < 0 || mode > 2) return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_gemm: mode must be 0 (auto), 1 (128 tile) or 2 (256 tile)");
+  // mode = kernel choice (0 auto, 1 128-tile, 2 256-tile) + 16 * (256-kernel schedule variant 0..3, experiments)
+  // mode bits 4..6: 0 = keep the default schedule, 1 + v = select 256-kernel schedule variant v (0..3)
+  const int vsel = mode >> 4;
+  mode &= 15;
+  if (mode < 0 || mode > 2 || vsel < 0 || vsel > 4)
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_gemm: mode must be 0 (auto), 1 (128 tile) or 2 (256 tile)");
+  if (vsel > 0) g_gemm256_variant = vsel - 1;
   g_gemm_mode = mode;
   if (rate256 > 0) g_rate256 = rate256;
   return 0;

@@ -28,6 +28,8 @@
 //   WAR  unit X of tile t is last read in LOAD(4t+{0,0,1,2}) for {V0,V2,V3,V1}; its refill for tile t+2 is issued in
 //        LOAD(4t+{2,3,4,5}) - at least 3 intervals after the last reader's interval, whose ds_reads completed
 //        (lgkmcnt(0)) right after the barrier that ended it.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -41,6 +43,22 @@ constexpr int GROUP_M256 = 4;
 
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (saddr form): one VGPR per
+// stream instead of a 64-bit address pair, and invisible to hipcc's vmcnt bookkeeping (the schedule counts by hand).
+// M0 (the LDS destination base) is written in the same statement that uses it and restored afterwards.
+__device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory");
+}
+
 __device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uniform
   if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -49,7 +67,10 @@ __device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uni
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI>
+// VAR bit 0: balanced LDS reads (B(nh0) of the NEXT tile is read in phase j=3 into an alternate register set; waits
+//            become vmcnt(8,8,6,-)), steady-state tiles run without issue/wait branches
+// VAR bit 1: no s_setprio around the MFMA cluster
+template <int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -74,26 +95,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // ---- LDS-DMA source pointers: this wave fills unit rows 16*wave .. 16*wave+15 (two 8-row wave-instructions) ----
   // unit row r -> tile row:  V0: (r>>6)*128 + (r&63)   V1: +64   V2: (r>>5)*64 + (r&31)   V3: +32
   const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-  const bf16_t* src[4][2];   // [unit][instr], at k = 0
+  // wave-uniform tile bases (SGPRs) + 32-bit per-lane byte offsets: global_load_lds saddr + voffset, no 64-bit VALU
+  const char* tileA = (const char*)(p.A + (size_t)m0 * p.lda);
+  const char* tileW = (const char*)(p.W + (size_t)n0 * p.ldw);
+  unsigned off[4][2];   // [unit][instr], at k = 0
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = wave * 16 + i * 8 + lr;
     const int ra0 = (r >> 6) * 128 + (r & 63), rb0 = (r >> 5) * 64 + (r & 31);
-    src[0][i] = p.A + (size_t)min(m0 + ra0, p.M - 1) * p.lda + lc * 8;
-    src[1][i] = p.A + (size_t)min(m0 + ra0 + 64, p.M - 1) * p.lda + lc * 8;
-    src[2][i] = p.W + (size_t)(n0 + rb0) * p.ldw + lc * 8;
-    src[3][i] = p.W + (size_t)(n0 + rb0 + 32) * p.ldw + lc * 8;
+    off[0][i] = (unsigned)(min(m0 + ra0, p.M - 1) - m0) * (unsigned)p.lda * 2u + lc * 16;
+    off[1][i] = (unsigned)(min(m0 + ra0 + 64, p.M - 1) - m0) * (unsigned)p.lda * 2u + lc * 16;
+    off[2][i] = (unsigned)rb0 * (unsigned)p.ldw * 2u + lc * 16;
+    off[3][i] = (unsigned)(rb0 + 32) * (unsigned)p.ldw * 2u + lc * 16;
   }
   const int nk = p.K / TK;
   const int n_units = 4 * nk;
+  // one unit = two wave-instructions; `unit` and the LDS destination are compile-time / wave-uniform
+  const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem + wave * 2048;
+  auto dma = [&](int tile, int unit) {
+    const char* base = (unit < 2 ? tileA : tileW) + (size_t)tile * (TK * 2);
+    const unsigned dst = lds0 + (tile & 1) * BUF + unit * UNIT;
+    glds16_saddr(base, off[unit][0], dst);
+    glds16_saddr(base, off[unit][1], dst + 1024);
+  };
   // stream position o within a tile: 0 -> V0, 1 -> V2, 2 -> V3, 3 -> V1 (o is a compile-time constant at every call)
   auto issue = [&](int tile, int o) {
     if (tile >= nk) return;
-    const int unit = (o == 0) ? 0 : (o == 1) ? 2 : (o == 2) ? 3 : 1;
-    char* dst = smem + (tile & 1) * BUF + unit * UNIT + wave * 2048;
-    const int k0 = tile * TK;
-    glds16(src[unit][0] + k0, dst);
-    glds16(src[unit][1] + k0, dst + 1024);
+    dma(tile, (o == 0) ? 0 : (o == 1) ? 2 : (o == 2) ? 3 : 1);
   };
 
   // ---- fragment read offsets (bytes inside a unit) ----
@@ -115,74 +143,114 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];   // A(mh) [mt][kh]; B(nh0) / B(nh1) [nt][kh]
+  bf16x8 fa[4][2], fb0[2][2][2], fb1[2][2];   // A(mh) [mt][kh]; B(nh0) [set][nt][kh]; B(nh1) [nt][kh]
+  constexpr bool BAL = (VAR & 1) != 0;
+  constexpr bool PRIO = (VAR & 2) == 0;
+
+  auto read_b0 = [&](const char* sb, auto SET) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) fb0[decltype(SET)::value][nt][kh] = *(const bf16x8*)(sb + 2 * UNIT + offB[kh] + nt * 2048);
+  };
+  auto read_b1 = [&](const char* sb) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) fb1[nt][kh] = *(const bf16x8*)(sb + 3 * UNIT + offB[kh] + nt * 2048);
+  };
+  auto read_a = [&](const char* sb, int unit) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) fa[mt][kh] = *(const bf16x8*)(sb + unit * UNIT + offA[kh] + mt * 2048);
+  };
+  auto mfma16 = [&](auto J, auto SET) {
+    constexpr int j = decltype(J)::value, st = decltype(SET)::value;
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if constexpr (j == 0) acc[0][mt][0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[st][nt][kh], fa[mt][kh], acc[0][mt][0][nt], 0, 0, 0);
+          if constexpr (j == 1) acc[0][mt][1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[nt][kh], fa[mt][kh], acc[0][mt][1][nt], 0, 0, 0);
+          if constexpr (j == 2) acc[1][mt][1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[nt][kh], fa[mt][kh], acc[1][mt][1][nt], 0, 0, 0);
+          if constexpr (j == 3) acc[1][mt][0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[st][nt][kh], fa[mt][kh], acc[1][mt][0][nt], 0, 0, 0);
+        }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // one K-tile = 4 phases.  SET = register set holding this tile's B(nh0); STEADY = every issue of the tile is in range
+  auto tile_body = [&](int t, auto SET, auto STEADY) {
+    constexpr int st = decltype(SET)::value;
+    constexpr bool steady = decltype(STEADY)::value;
+    using NSET = std::integral_constant<int, st ^ 1>;
+    const char* sb = smem + (t & 1) * BUF;
+    const char* sbn = smem + ((t + 1) & 1) * BUF;
+    // after LOAD(p) the stream must have landed up to need(p); allowed in-flight units = min(6+p, n_units-1) - need(p)
+    auto wait_after = [&](int ph, int need) {
+      if constexpr (steady) { (void)ph; (void)need; }
+      else wait_vm(2 * max(0, min(6 + ph, n_units - 1) - need));
+    };
+#define PHASE_TAIL(J)                                 \
+    __builtin_amdgcn_sched_barrier(0);                \
+    RAW_BARRIER();                                    \
+    __builtin_amdgcn_sched_barrier(0);                \
+    mfma16(J{}, SET);                               \
+    __builtin_amdgcn_sched_barrier(0);                \
+    RAW_BARRIER();                                    \
+    __builtin_amdgcn_sched_barrier(0);
+    const int ph = 4 * t;
+    // ---- j = 0 ----
+    if constexpr (!BAL) { read_b0(sb, SET); __builtin_amdgcn_sched_barrier(0); }
+    read_a(sb, 0);
+    if constexpr (steady) dma(t + 1, 3); else issue(t + 1, 2);
+    if constexpr (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_after(ph, ph + 2);
+    PHASE_TAIL(I0)
+    // ---- j = 1 ----
+    read_b1(sb);
+    if constexpr (steady) dma(t + 1, 1); else issue(t + 1, 3);
+    if constexpr (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_after(ph + 1, ph + 3);
+    PHASE_TAIL(I1)
+    // ---- j = 2 ----
+    read_a(sb, 1);
+    if constexpr (steady) dma(t + 2, 0); else issue(t + 2, 0);
+    if constexpr (steady) { if constexpr (BAL) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else wait_after(ph + 2, BAL ? ph + 5 : ph + 4);
+    PHASE_TAIL(I2)
+    // ---- j = 3 ----
+    if constexpr (BAL) { if (steady || t + 1 < nk) read_b0(sbn, NSET{}); }
+    if constexpr (steady) dma(t + 2, 2); else issue(t + 2, 1);
+    if constexpr (steady) { if constexpr (!BAL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else wait_after(ph + 3, BAL ? ph + 4 : ph + 5);
+    PHASE_TAIL(I3)
+#undef PHASE_TAIL
+  };
 
   // ---- prologue: stream units 0..5, then make units 0,1 (V0, V2 of tile 0) visible ----
   issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3); issue(1, 0); issue(1, 1);
-  {
-    const int issued = min(6, n_units);
-    wait_vm(2 * max(0, issued - 2));
-  }
+  wait_vm(2 * max(0, min(6, n_units) - 2));
   RAW_BARRIER();
+  if constexpr (BAL) read_b0(smem, I0{});   // B(nh0) of tile 0; later tiles get theirs in the previous tile's phase 3
   if (g == 1) RAW_BARRIER();   // stagger: group 1 runs one barrier behind group 0
 
-  const int n_phase = 4 * nk;
-  for (int t = 0; t < nk; ++t) {
-    const char* sb = smem + (t & 1) * BUF;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ph = 4 * t + j;
-      // ---------------- LOAD(ph) ----------------
-      if (j == 0) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int kh = 0; kh < 2; ++kh) fb0[nt][kh] = *(const bf16x8*)(sb + 2 * UNIT + offB[kh] + nt * 2048);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int kh = 0; kh < 2; ++kh) fa[mt][kh] = *(const bf16x8*)(sb + 0 * UNIT + offA[kh] + mt * 2048);
-      } else if (j == 1) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int kh = 0; kh < 2; ++kh) fb1[nt][kh] = *(const bf16x8*)(sb + 3 * UNIT + offB[kh] + nt * 2048);
-      } else if (j == 2) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int kh = 0; kh < 2; ++kh) fa[mt][kh] = *(const bf16x8*)(sb + 1 * UNIT + offA[kh] + mt * 2048);
-      }
-      // stream unit 6 + ph: j=0 -> V3(t+1), j=1 -> V1(t+1), j=2 -> V0(t+2), j=3 -> V2(t+2)
-      if (j == 0) issue(t + 1, 2);
-      if (j == 1) issue(t + 1, 3);
-      if (j == 2) issue(t + 2, 0);
-      if (j == 3) issue(t + 2, 1);
-      wait_vm(2 * max(0, min(4, n_units - 3 - ph)));
-      __builtin_amdgcn_sched_barrier(0);
-      RAW_BARRIER();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---------------- MFMA(ph) ----------------
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            if (j == 0) acc[0][mt][0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[nt][kh], fa[mt][kh], acc[0][mt][0][nt], 0, 0, 0);
-            if (j == 1) acc[0][mt][1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[nt][kh], fa[mt][kh], acc[0][mt][1][nt], 0, 0, 0);
-            if (j == 2) acc[1][mt][1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[nt][kh], fa[mt][kh], acc[1][mt][1][nt], 0, 0, 0);
-            if (j == 3) acc[1][mt][0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[nt][kh], fa[mt][kh], acc[1][mt][0][nt], 0, 0, 0);
-          }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      RAW_BARRIER();
-      __builtin_amdgcn_sched_barrier(0);
-    }
+  using T = std::true_type;
+  using F = std::false_type;
+  int t = 0;
+  for (; t + 3 < nk; t += 2) {   // tiles t, t+1 issue units of tiles <= t+3: all in range
+    tile_body(t, I0{}, T{});
+    tile_body(t + 1, I1{}, T{});
   }
-  (void)n_phase;
+  for (; t < nk; t += 2) {
+    tile_body(t, I0{}, F{});
+    if (t + 1 < nk) tile_body(t + 1, I1{}, F{});
+  }
   if (g == 0) RAW_BARRIER();   // balance the stagger barrier
 
   // ---- epilogue: lane owns C[m][n .. n+3] ----
@@ -255,31 +323,43 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     }
 }
 
-template <int EPI>
+template <int EPI, int VAR>
 hipError_t launch256(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
-  hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(nbm * nbn), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, VAR>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, a);
   return hipGetLastError();
+}
+
+template <int VAR>
+hipError_t launch256v(const GemmArgs& a, int epi, hipStream_t s) {
+  switch (epi) {
+    case EPI_STORE: return launch256<EPI_STORE, VAR>(a, s);
+    case EPI_GELU: return launch256<EPI_GELU, VAR>(a, s);
+    case EPI_LS_RESID: return launch256<EPI_LS_RESID, VAR>(a, s);
+    case EPI_RESID: return launch256<EPI_RESID, VAR>(a, s);
+    case EPI_SWIGLU: return launch256<EPI_SWIGLU, VAR>(a, s);
+    case EPI_PATCH: return launch256<EPI_PATCH, VAR>(a, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace
 
+int g_gemm256_variant = 3;   // balanced LDS reads + no s_setprio: fastest in the interleaved A/B (profiles/r1_gemm_variants.txt)
+
 bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0 && a.M >= 1; }
 
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
-  switch (epi) {
-    case EPI_STORE: return launch256<EPI_STORE>(a, s);
-    case EPI_GELU: return launch256<EPI_GELU>(a, s);
-    case EPI_LS_RESID: return launch256<EPI_LS_RESID>(a, s);
-    case EPI_RESID: return launch256<EPI_RESID>(a, s);
-    case EPI_SWIGLU: return launch256<EPI_SWIGLU>(a, s);
-    case EPI_PATCH: return launch256<EPI_PATCH>(a, s);
+  switch (g_gemm256_variant) {
+    case 1: return launch256v<1>(a, epi, s);
+    case 2: return launch256v<2>(a, epi, s);
+    case 3: return launch256v<3>(a, epi, s);
+    default: return launch256v<0>(a, epi, s);
   }
-  return hipErrorInvalidValue;
 }

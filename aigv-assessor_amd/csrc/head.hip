@@ -12,7 +12,7 @@
 
 namespace {
 
-enum { SK_STORE = 0, SK_RESID = 1, SK_SWIGLU = 2, SK_GELU = 3, SK_ARGMAX = 4, SK_RELU = 5 };
+enum { SK_STORE = 0, SK_RESID = 1, SK_SWIGLU = 2, SK_GELU = 3, SK_ARGMAX = 4, SK_RELU = 5, SK_LS_RESID = 6 };
 
 __device__ __forceinline__ unsigned int ord_f32(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
                                                      const bf16_t* __restrict__ W, int ldw, int N, int K,
                                                      const bf16_t* __restrict__ bias, const bf16_t* __restrict__ resid,
                                                      int ldr, bf16_t* __restrict__ out, int ldo,
-                                                     unsigned long long* __restrict__ packed) {
+                                                     unsigned long long* __restrict__ packed,
+                                                     const bf16_t* __restrict__ ls) {
   constexpr int NS = (EPI == SK_SWIGLU) ? 2 : 1;   // W slabs per workgroup
   __shared__ float part[3][NS][RT][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -136,7 +137,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if constexpr (EPI == SK_RESID) {
+        if constexpr (EPI == SK_LS_RESID) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] * bf2f(ls[n + e]));
+        }
+        if constexpr (EPI == SK_RESID || EPI == SK_LS_RESID) {
           const u16x4 rr = *(const u16x4*)(resid + (size_t)r * ldr + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rbf(bf2f(rr[e]) + v[e]);
@@ -218,11 +223,11 @@ __global__ __launch_bounds__(256) void score_tail_kernel(const ScoreHeadArgs a, 
 template <int EPI>
 hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
                          const bf16_t* resid, int ldr, bf16_t* out, int ldo, unsigned long long* packed,
-                         hipStream_t s) {
+                         hipStream_t s, const bf16_t* ls = nullptr) {
   const int ns = (EPI == SK_SWIGLU) ? 2 : 1;
   const int blocks = (N + 16 * ns - 1) / (16 * ns);
   const int rt = (R + 15) / 16;
-#define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, EPI>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed)
+#define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, EPI>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls)
   switch (rt) {
     case 1: GO(1); break;
     case 2: GO(2); break;
@@ -236,10 +241,11 @@ hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int l
 
 }  // namespace
 
-// epi: 0 store(+bias) | 1 residual | 2 swiglu (16-row interleaved w1/w3, out is N/2 wide) | 3 gelu(+bias)
+// epi: 0 store(+bias) | 1 residual(+bias) | 2 swiglu (16-row interleaved w1/w3, out is N/2 wide) | 3 gelu(+bias)
+//      6 layer-scale + residual (+bias)
 hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K,
                                    const bf16_t* bias, const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi,
-                                   hipStream_t s) {
+                                   hipStream_t s, const bf16_t* ls) {
   if (R <= 0) return hipSuccess;
   if (R > 64 || K % 128 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return hipErrorInvalidValue;
   if (epi != SK_SWIGLU && N % 4) return hipErrorInvalidValue;
@@ -249,6 +255,9 @@ hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t
     case SK_RESID: return launch_skinny<SK_RESID>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
     case SK_SWIGLU: return launch_skinny<SK_SWIGLU>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
     case SK_GELU: return launch_skinny<SK_GELU>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
+    case SK_LS_RESID:
+      if (!ls || !resid) return hipErrorInvalidValue;
+      return launch_skinny<SK_LS_RESID>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s, ls);
   }
   return hipErrorInvalidValue;
 }

@@ -79,10 +79,10 @@ hipError_t aigv_launch_rope(bf16_t* qkv, int ld, const int32_t* pos, const bf16_
 // token embedding + visual/motion scatter: slot[t] < 0 -> tok_emb[ids[t]]; < n_vis -> vis[slot]; else motion
 hipError_t aigv_launch_embed(const int64_t* ids, const int32_t* slot, const bf16_t* emb, const bf16_t* vis,
                              const bf16_t* motion, int n_vis, bf16_t* out, int tokens, int H, hipStream_t s);
-// skinny (R <= 64) weight-streaming GEMM; epi: 0 store(+bias) 1 residual 2 swiglu 3 gelu(+bias)
+// skinny (R <= 64) weight-streaming GEMM; epi: 0 store(+bias) 1 residual 2 swiglu 3 gelu(+bias) 6 layer-scale+residual
 hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K,
                                    const bf16_t* bias, const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi,
-                                   hipStream_t s);
+                                   hipStream_t s, const bf16_t* ls = nullptr);
 // lm-head on R gathered rows + argmax over the vocabulary (first maximal index, bf16-rounded logits)
 hipError_t aigv_launch_lm_head_argmax(const bf16_t* h, int R, int H, const bf16_t* W, int V,
                                       unsigned long long* packed, int64_t* out_idx, float* out_val, hipStream_t s);

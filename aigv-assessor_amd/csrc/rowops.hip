@@ -51,6 +51,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 }
 
+// wave-per-row variant for rows of 512*CH elements (ViT hidden 1024 -> CH = 2): no LDS, no barriers, 4 rows per block
+template <int CH>
+__global__ __launch_bounds__(256) void layernorm_wave_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                             bf16_t* __restrict__ y, int ldy, int rows, float eps) {
+  constexpr int H = 512 * CH;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[CH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const u16x8 raw = *(const u16x8*)(x + (size_t)row * ldx + ((lane + c * 64) << 3));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[c][e] = bf2f(raw[e]); sum += v[c][e]; }
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (lane + c * 64) << 3;
+    const u16x8 ww = *(const u16x8*)(w + col);
+    const u16x8 bb = *(const u16x8*)(b + col);
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf((v[c][e] - mean) * rstd * bf2f(ww[e]) + bf2f(bb[e]));
+    *(u16x8*)(y + (size_t)row * ldy + col) = o;
+  }
+}
+
 // ---- RMSNorm: fp32 normalise -> bf16 -> * weight -> bf16 (modeling_internlm2.py:138-143) --------------
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, int ldx,
                                                       const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int ldy,
@@ -189,7 +225,9 @@ hipError_t aigv_launch_layernorm(const bf16_t* x, int ldx, const bf16_t* w, cons
                                  int rows, int H, float eps, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   if (H % 8 || H > MAXC * 256 * 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, b, y, ldy, H, eps);
+  if (H == 1024) hipLaunchKernelGGL(layernorm_wave_kernel<2>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, b, y, ldy, rows, eps);
+  else if (H == 2048) hipLaunchKernelGGL(layernorm_wave_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, b, y, ldy, rows, eps);
+  else hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, b, y, ldy, H, eps);
   return hipGetLastError();
 }
 

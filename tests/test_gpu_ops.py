@@ -114,6 +114,34 @@ def test_gemm_epilogues(lib, M, N, K, epi):
               atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
+@pytest.mark.parametrize("mode", [1, 2 + 16, 2 + 32, 2 + 48, 2 + 64, 0])
+@pytest.mark.parametrize("M,N,K,epi", [(1100, 512, 448, 0), (777, 256, 64, 1), (515, 768, 1024, 2), (300, 256, 192, 3),
+                                        (1029, 1024, 512, 4), (256, 256, 128, 0)])
+def test_gemm_tile_kernels_agree(lib, mode, M, N, K, epi):
+    """mode 1 = 128x128 kernel, 2 + 16*(1+v) = 256x256 phase-interleaved kernel with schedule variant v,
+    0 = cost-model split (256 main + 128/skinny tail)."""
+    from aigv_assessor_amd import native
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(BF)
+    W = (torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K))).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF) if epi in (0, 1, 2) else None
+    ls = (torch.rand(N, generator=g) + 0.5).to(BF) if epi == 2 else None
+    nout = N // 2 if epi == 4 else N
+    resid = torch.randn(M, nout, generator=g).to(BF) if epi in (2, 3) else None
+    want = gemm_ref(A, W, epi, bias, ls, resid)
+    dA, dW = dev(A), dev(W)
+    dC = torch.full((M, nout), float("nan"), dtype=BF, device="cuda")
+    db, dl, dr = (dev(t) if t is not None else None for t in (bias, ls, resid))
+    native.check(lib.aigv_tune_gemm(mode, 0.0))
+    try:
+        sync(lib.aigv_op_gemm(ptr(dA), K, ptr(dW), K, ptr(dC), nout, ptr(db), ptr(dl), ptr(dr), nout, None, 0, M, N, K, epi,
+                              None), lib)
+    finally:
+        native.check(lib.aigv_tune_gemm(0 + 64, 0.0))      # back to auto + the default schedule (variant 3)
+    ulp_check(dC, want, frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
+
+
 def test_gemm_identity_asymmetric(lib):
     """A = I with an asymmetric W catches a transposed C write (guide §3)."""
     from aigv_assessor_amd.native import ptr
