@@ -192,9 +192,16 @@ def main():
             gm = p["gemm"]
             if gm["launches"]:
                 ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+                traffic, tnote = None, None
+                tf = os.path.join(ROOT, "profiles", "r1_gemm_traffic.json")
+                if os.path.exists(tf):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (scripts/pmc_summary.py)
+                    tj = json.load(open(tf))
+                    traffic = tj["all_gemm"]["traffic_bytes_per_launch"]
+                    tnote = "L2<->fabric bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r1_gemm_traffic.json)"
                 line["roofline"] = {
                     "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                    "traffic": None, "kernel": "gemm_bf16_kernel (128x128x64 MFMA 16x16x32 bf16, all epilogues)",
+                    "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": gm["bytes"] / gm["launches"],
+                    "kernel": "bf16 MFMA GEMM (gemm256_kernel 256x256x64 phase-interleaved + gemm_bf16_kernel 128x128x64 / skinny tails, all epilogues)",
                     "launches": gm["launches"], "avg_launch_ms": gm["ms"] / gm["launches"],
                     "flops_per_launch": gm["flops"] / gm["launches"], "gemm_ms_per_step": gm["ms"] / args.steps,
                     "other_kernels_ms_per_step": {k: p[k]["ms"] / args.steps for k in ("attn_vit", "attn_llm", "skinny")},
