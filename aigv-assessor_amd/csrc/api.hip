@@ -918,6 +918,13 @@ int aigv_op_lm_head_argmax(const void* h, int rows, int hidden, const void* W_, 
   return 0;
 }
 
+int aigv_op_frame_ingest(const void* hwc_u8, int n_frames, int height, int width, const float* mean, const float* stdv,
+                         void* out_nchw, void* stream) {
+  HIPCHK(nullptr, aigv_launch_frame_ingest((const uint8_t*)hwc_u8, n_frames, height, width, mean, stdv, (bf16_t*)out_nchw,
+                                           (hipStream_t)stream));
+  return 0;
+}
+
 // ---- measurement -----------------------------------------------------------------------------------------------
 int aigv_tune_gemm(int mode, double rate256) {
   // mode = kernel choice (0 auto, 1 128-tile, 2 256-tile) + 16 * (256-kernel schedule variant 0..3, experiments)

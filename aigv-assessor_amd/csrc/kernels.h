@@ -99,3 +99,6 @@ hipError_t aigv_launch_score_head(const ScoreHeadArgs& a, bf16_t* scratch, hipSt
 hipError_t aigv_launch_kv_store(const bf16_t* qkv, int ld, const int32_t* seq_of_tok, const int32_t* pos,
                                 bf16_t* kc, bf16_t* vc, int tokens, int n_groups, int g, int D, int cap,
                                 hipStream_t s);
+// frame ingest: uint8 HWC RGB -> (u/255 - mean)/std -> bf16 NCHW (torchvision ToTensor + Normalize + bf16 cast)
+hipError_t aigv_launch_frame_ingest(const uint8_t* hwc, int n_frames, int H, int W, const float* mean, const float* stdv,
+                                    bf16_t* out, hipStream_t s);

@@ -330,6 +330,21 @@ class InternVLChatModel(nn.Module):
             pass
 
     # ---- hot path -----------------------------------------------------------------------------------------
+    def ingest_frames(self, frames_u8: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> torch.Tensor:
+        """uint8 [F, S, S, 3] RGB frames (already resized on the host) -> normalised bf16 NCHW ``pixel_values`` on the
+        GPU: the ToTensor + Normalize + bf16 cast of the reference's eval transform (dataset.py:267-274, stage2_eval.py:932)."""
+        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+            raise ValueError("frames must be uint8 [F, H, W, 3]")
+        lib = native.load()
+        if self.device.type != "cuda":
+            raise native.NativeError("the scorer hot path runs on an MI355X only (no CPU fallback)")
+        f = frames_u8.to(self.device).contiguous()
+        n, h, w, _ = f.shape
+        out = torch.empty((n, 3, h, w), dtype=torch.bfloat16, device=self.device)
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        native.check(lib.aigv_op_frame_ingest(f.data_ptr(), n, h, w, m3, s3, out.data_ptr(), native.stream_ptr()))
+        return out
+
     def vit_tokens(self, pixel_values: torch.Tensor) -> torch.Tensor:
         """InternViT -> drop cls -> pixel-shuffle: [F,3,S,S] -> [F, ntok, 4*Hv] pre-projector tokens (the
         frame-DP all-gather payload; modeling_internvl_chat.py:509-527)."""

@@ -128,6 +128,12 @@ int aigv_op_im2col(const void* frames, int n_frames, int channels, int image_siz
 int aigv_op_lm_head_argmax(const void* h, int rows, int hidden, const void* W, int vocab, void* scratch_u64,
                            int64_t* idx, float* val, void* stream);
 
+/* Frame ingest: uint8 [F,H,W,3] RGB frames already at the model resolution -> bf16 NCHW
+ * pixel_values = bf16((u/255 - mean[c]) / std[c])  (torchvision ToTensor + Normalize of dataset.py:267-274 and the
+ * bf16 cast of stage2_eval.py:932).  mean/std: HOST float[3]. */
+int aigv_op_frame_ingest(const void* hwc_u8, int n_frames, int height, int width, const float* mean, const float* stdv,
+                         void* out_nchw, void* stream);
+
 /* GEMM tile-kernel selection: mode 0 = cost model (default), 1 = always the 128x128 kernel, 2 = always the 256x256
  * phase-interleaved kernel where N % 256 == 0; rate256 > 0 overrides the model's relative throughput of the 256 kernel. */
 int aigv_tune_gemm(int mode, double rate256);

@@ -401,6 +401,21 @@ def greedy_generate(sd: SD, cfg, inputs_embeds: Tensor, attention_mask: Tensor, 
     return torch.stack(out, dim=1)
 
 
+IMAGENET_MEAN = (0.485, 0.456, 0.406)   # internvl/train/constants.py:10-11
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def normalize_frames_u8(frames_hwc: Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD, dtype=torch.bfloat16) -> Tensor:
+    """Eval transform after the resize (internvl/train/dataset.py:267-274): ToTensor = uint8 HWC -> float CHW / 255;
+    Normalize = (x - mean) / std in fp32 (torchvision semantics: sub_ then div_); cast to bf16 at the call site
+    (stage2_eval.py:932).  torchvision is absent here, so this restates its published definition (parity unpinned
+    by a run of the reference; the arithmetic is three fp32 ops)."""
+    x = frames_hwc.permute(0, 3, 1, 2).to(torch.float32).div(255)
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
+    return x.sub_(m).div_(s).to(dtype)
+
+
 LEVEL_WORDS = ("bad", "poor", "fair", "good", "excellent")
 
 

@@ -382,3 +382,18 @@ def test_lm_head_argmax_first_max_on_ties(lib, R, V, H):
     sync(lib.aigv_op_lm_head_argmax(ptr(dev(h2)), 3, H, ptr(dev(W)), V, ptr(scratch), ptr(idx), ptr(val), None), lib)
     l2 = rb(h2.float() @ W.float().t())
     assert torch.equal(idx.cpu()[:3], l2.argmax(-1))
+
+
+def test_frame_ingest_is_bit_exact(lib):
+    """uint8 HWC -> bf16 NCHW normalisation: three fp32 ops and one bf16 rounding -> identical to the oracle."""
+    import ctypes as C
+    from aigv_assessor_amd.native import ptr
+    from oracle import oracle as O
+    g = torch.Generator().manual_seed(5)
+    u = torch.randint(0, 256, (3, 28, 44, 3), generator=g, dtype=torch.uint8)
+    u[0, 0, 0] = torch.tensor([0, 255, 128], dtype=torch.uint8)
+    want = O.normalize_frames_u8(u)
+    out = torch.empty(3, 3, 28, 44, dtype=BF, device="cuda")
+    mean, std = (C.c_float * 3)(*O.IMAGENET_MEAN), (C.c_float * 3)(*O.IMAGENET_STD)
+    sync(lib.aigv_op_frame_ingest(ptr(dev(u)), 3, 28, 44, mean, std, ptr(out), None), lib)
+    assert torch.equal(out.cpu(), want)

@@ -121,3 +121,43 @@ def test_pack_and_config_roundtrip():
     assert c.llm_config.intermediate_size == 14336 and c.vision_config.num_hidden_layers == 24
     c26 = pkg.internvl2_26b()
     assert c26.vision_config.norm_type == "rms_norm" and c26.llm_config.hidden_size == 6144
+
+
+def test_lora_merge_matches_peft_rule():
+    from aigv_assessor_amd.weights import merge_lora_state_dict, strip_peft_names
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(48, 32, generator=g).to(torch.bfloat16)
+    a, b = torch.randn(8, 32, generator=g).to(torch.bfloat16), torch.randn(48, 8, generator=g).to(torch.bfloat16)
+    base = {"language_model.base_model.model.model.layers.0.attention.wo.base_layer.weight": w,
+            "language_model.base_model.model.model.norm.weight": torch.ones(32)}
+    lora = {"language_model.base_model.model.model.layers.0.attention.wo.lora_A.default.weight": a,
+            "language_model.base_model.model.model.layers.0.attention.wo.lora_B.default.weight": b}
+    out = merge_lora_state_dict(base, lora, alpha_over_r=2.0)
+    assert set(out) == {"language_model.model.layers.0.attention.wo.weight", "language_model.model.norm.weight"}
+    want = (w.float() + 2.0 * (b.float() @ a.float())).to(torch.bfloat16)
+    assert torch.equal(out["language_model.model.layers.0.attention.wo.weight"], want)
+    assert "x.weight" in strip_peft_names({"x.base_layer.weight": w})
+    with pytest.raises(KeyError):
+        merge_lora_state_dict(base, {k: v for k, v in lora.items() if "lora_A" in k})
+
+
+def test_eval_utils_follow_the_reference_driver(tmp_path):
+    from aigv_assessor_amd import eval_utils as E
+    labels = torch.tensor([-100, -100, 5, 6, 7, 92542])
+    logit = torch.tensor([1, 2, 3, 4, 5, 6])
+    assert E.answer_ids(labels, logit).tolist() == [3, 4, 5] == O.answer_slice(labels, logit, 92542).tolist()
+    for text in ("The static quality of the video is good.", "excellent", "bad poor", "n/a", "fairly poor"):
+        assert E.parse_level(text) == O.parse_level(text)
+    rows = [["a.mp4", "quality is good.", "good", 70.0, 0.71, 4], ["b.mp4", "quality is bad.", "poor", 20.0, 0.25, 2],
+            ["c.mp4", "quality is fair.", "fair", 50.0, 0.45, 3]]
+    m = E.save_and_evaluate(rows, str(tmp_path / "r.csv"))
+    assert abs(m["acc"] - 2 / 3) < 1e-9 and m["level_srcc"] > 0.99 and m["pred_score_plcc"] > 0.9
+    assert open(tmp_path / "r.csv").readline().strip() == "video_name,answer,output,mos,pred_score,level"
+
+
+def test_oracle_frame_normalisation_definition():
+    u = torch.randint(0, 256, (2, 4, 6, 3), generator=torch.Generator().manual_seed(1), dtype=torch.uint8)
+    y = O.normalize_frames_u8(u)
+    assert y.shape == (2, 3, 4, 6) and y.dtype == torch.bfloat16
+    x = u[1, 2, 3, 1].float() / 255
+    assert y[1, 1, 2, 3] == ((x - 0.456) / 0.224).to(torch.bfloat16)
