@@ -66,6 +66,9 @@ struct aigv_ctx {
   unsigned long long* l_packed = nullptr;
   bf16_t* l_score_ws = nullptr;
   bf16_t *kc = nullptr, *vc = nullptr;   // [layer][seq][kv head][cap][D]
+  float* dec_ws = nullptr;
+  int32_t *dec_pos = nullptr, *dec_seq = nullptr, *dec_kvlen = nullptr, *dec_slot = nullptr;   // device-side decode state
+  std::vector<int32_t> h_dec;
   std::vector<int32_t> h_pos, h_seq, h_rowidx, h_kvlen;
   int kv_seqs = 0;
   bool kv_valid = false;
@@ -365,6 +368,11 @@ int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out) {
       const size_t per = (size_t)k.llm_layers * k.max_seqs * k.llm_kv_heads * k.kv_capacity * c->head_dim;
       if ((rc = dalloc(c, &c->kc, per))) break;
       if ((rc = dalloc(c, &c->vc, per))) break;
+      if ((rc = dalloc(c, &c->dec_ws, aigv_attention_decode_ws_floats(k.max_seqs, k.llm_kv_heads, c->g, k.kv_capacity)))) break;
+      if ((rc = dalloc(c, &c->dec_pos, (size_t)k.max_seqs))) break;
+      if ((rc = dalloc(c, &c->dec_seq, (size_t)k.max_seqs))) break;
+      if ((rc = dalloc(c, &c->dec_kvlen, (size_t)k.max_seqs))) break;
+      if ((rc = dalloc(c, &c->dec_slot, (size_t)k.max_seqs))) break;
     }
     std::vector<int32_t> cu(k.vit_chunk + 1);
     for (int i = 0; i <= k.vit_chunk; ++i) cu[i] = i * c->S;
@@ -795,7 +803,16 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
   TRY(final_rows(c, score_rows, score, B, logit_rows, R, argmax, c->l_h, T, s));
   if (keep_kv) {
     c->h_kvlen.resize(B);
-    for (int b = 0; b < B; ++b) c->h_kvlen[b] = cu[b + 1] - cu[b];
+    c->h_dec.resize((size_t)4 * B);   // pos | seq | visible kv length | slot, uploaded once; advanced on the device
+    for (int b = 0; b < B; ++b) {
+      const int len = cu[b + 1] - cu[b];
+      c->h_kvlen[b] = len;
+      c->h_dec[b] = len; c->h_dec[B + b] = b; c->h_dec[2 * B + b] = len + 1; c->h_dec[3 * B + b] = -1;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dec_pos, c->h_dec.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->dec_seq, c->h_dec.data() + B, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->dec_kvlen, c->h_dec.data() + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->dec_slot, c->h_dec.data() + 3 * B, (size_t)B * 4, hipMemcpyHostToDevice, s));
     c->kv_seqs = B;
     c->kv_valid = true;
   } else {
@@ -815,30 +832,22 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
       return fail(c, AIGV_ERR_STATE, "clip %d: KV cache / RoPE table exhausted at %d tokens", b, c->h_kvlen[b]);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
-  // positions of the new tokens = current lengths; keys visible afterwards = length + 1
-  c->h_pos.assign(c->h_kvlen.begin(), c->h_kvlen.end());
-  c->h_seq.resize(B);
-  c->h_rowidx.resize(B);
-  std::vector<int32_t>& vis_len = c->h_rowidx;
-  for (int b = 0; b < B; ++b) { c->h_seq[b] = b; vis_len[b] = c->h_kvlen[b] + 1; }
-  HIPCHK(c, hipMemcpyAsync(c->l_pos, c->h_pos.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(c->l_seq, c->h_seq.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(c->l_kvlen, vis_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
-  // slot = -1 everywhere: plain token embeddings.  l_rowidx is reused as the int32 slot array.
-  std::vector<int32_t> neg(B, -1);
-  HIPCHK(c, hipMemcpyAsync(c->l_rowidx, neg.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipStreamSynchronize(s));  // `neg` and the host vectors above are about to be reused
-  HIPCHK(c, aigv_launch_embed(ids, c->l_rowidx, c->tok_emb, nullptr, nullptr, 0, c->l_h, B, H, s));
+  // positions of the new tokens (= current lengths) and the visible KV lengths live on the device (dec_pos, dec_kvlen)
+  // and are advanced by a one-block kernel at the end of the step: no host copies or syncs inside a decode step
+  int max_vis = 0;
+  for (int b = 0; b < B; ++b) max_vis = std::max(max_vis, c->h_kvlen[b] + 1);
+  HIPCHK(c, aigv_launch_embed(ids, c->dec_slot, c->tok_emb, nullptr, nullptr, 0, c->l_h, B, H, s));
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
   for (int li = 0; li < k.llm_layers; ++li) {
     const LlmLayer& L = c->llm[li];
     HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, B, H, k.rms_eps, nullptr, s));
     TRY(run_skinny(c, c->l_t, H, B, L.wqkv, H, c->qkv_out, H, nullptr, nullptr, 0, c->l_qkv, c->qkv_out, 0, s));
-    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, B, g + 1, g + 2, nkv, D, s));
-    HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, B,
+    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->dec_pos, c->rope_cos, c->rope_sin, B, g + 1, g + 2, nkv, D, s));
+    HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->dec_seq, c->dec_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, B,
                                    nkv, g, D, k.kv_capacity, s));
     HIPCHK(c, aigv_launch_attention_decode(c->l_qkv, c->qkv_out, (g + 2) * D, c->kc + li * kv_layer, c->vc + li * kv_layer,
-                                           c->l_kvlen, k.kv_capacity, c->l_ao, H, B, nkv, g, D, sqrtf((float)D), s));
+                                           c->dec_kvlen, k.kv_capacity, c->l_ao, H, B, nkv, g, D, sqrtf((float)D), max_vis,
+                                           c->dec_ws, s));
     TRY(run_skinny(c, c->l_ao, H, B, L.wo, H, H, H, nullptr, c->l_h, H, c->l_h, H, 1, s));
     HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, B, H, k.rms_eps, nullptr, s));
     TRY(run_skinny(c, c->l_t, H, B, L.w13, H, 2 * I, H, nullptr, nullptr, 0, c->l_ffn, I, 2, s));
@@ -846,6 +855,7 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
   }
   HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, c->final_norm, c->l_rows, H, B, H, k.rms_eps, nullptr, s));
   HIPCHK(c, aigv_launch_lm_head_argmax(c->l_rows, B, H, c->lm_head, k.vocab, c->l_packed, next, nullptr, s));
+  HIPCHK(c, aigv_launch_advance(c->dec_pos, c->dec_kvlen, B, s));
   for (int b = 0; b < B; ++b) c->h_kvlen[b] += 1;
   return 0;
 }

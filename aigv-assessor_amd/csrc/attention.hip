@@ -245,70 +245,121 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   }
 }
 
-// ---- decode attention: one query per sequence against a KV cache (HBM-bound) -----------------------------
-// grid = (kv heads, sequences); the g query heads of a kv group share each K/V row read.
-// cache layout [seq][kv head][cap][D]; query i of sequence s sees keys 0 .. kv_len-1.
-template <int D, int G>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int ldq, int q_group_stride,
-                                                          const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
-                                                          const int32_t* __restrict__ kv_lens, int cap,
-                                                          bf16_t* __restrict__ o, int ldo, float post_div) {
-  // each wave owns keys w, w+4, ...; lane owns 2 (D=128) contiguous dims; partial (m, l, acc) merged via LDS
-  constexpr int EPL = D / 64;
-  __shared__ float s_m[4][G], s_l[4][G], s_acc[4][G][D];
-  const int hk = blockIdx.x, seq = blockIdx.y, n_kv = gridDim.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ---- decode attention (q_len = 1 per sequence) against the KV cache: split-KV, two passes ------------------------
+// reference: InternLM2Attention.forward with a cache (modeling_internlm2.py:397-424).  The cache is tiny next to the
+// weights (131 KB per token per clip), so the kernel only has to be parallel and dependency-free:
+//   pass 1  grid (key chunks of 128, kv heads, sequences): scores of the G grouped query heads for 128 keys (two
+//           threads per key, 64 dims each), chunk-local softmax statistics, P.V partial sums for 128 dims
+//   pass 2  grid (kv heads, sequences): merge the chunk partials (max / sum rescale) and write bf16
+// Rounding points as the eager path: score -> bf16, / sqrt(d) -> bf16, softmax fp32, P -> bf16 (un-normalised).
+constexpr int DC = 128;   // keys per chunk
+
+template <int G>
+__global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* __restrict__ q, int ldq, int q_group_stride,
+                                                                  const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+                                                                  const int32_t* __restrict__ kv_lens, int cap, float post_div,
+                                                                  float* __restrict__ ws, int max_chunks) {
+  constexpr int D = 128;
+  __shared__ float sQ[G][D];
+  __shared__ float sS[G][DC];          // scores, then probabilities
+  __shared__ float sM[G], sL[G];
+  __shared__ float sAcc[4][G][D];
+  const int chunk = blockIdx.x, hk = blockIdx.y, seq = blockIdx.z, n_kv = gridDim.y;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int kv_len = kv_lens[seq];
-  float qv[G][EPL];
+  const int key0 = chunk * DC;
+  float* wbase = ws + ((((size_t)seq * n_kv + hk) * max_chunks + chunk) * G) * (D + 2);
+  if (key0 >= kv_len) return;                                       // pass 2 only visits chunks below kv_len
+  const int nkeys = min(DC, kv_len - key0);
+  for (int i = t; i < G * D; i += 256) sQ[i / D][i % D] = bf2f(q[(size_t)seq * ldq + (size_t)hk * q_group_stride + i]);
+  __syncthreads();
+  const bf16_t* kb = kc + (((size_t)seq * n_kv + hk) * cap + key0) * D;
+  const bf16_t* vb = vc + (((size_t)seq * n_kv + hk) * cap + key0) * D;
+  {  // scores: thread -> (key = t>>1, half = t&1)
+    const int kk = t >> 1, half = t & 1;
+    float dot[G];
 #pragma unroll
-  for (int j = 0; j < G; ++j)
+    for (int j2 = 0; j2 < G; ++j2) dot[j2] = 0.f;
+    if (kk < nkeys) {
 #pragma unroll
-    for (int e = 0; e < EPL; ++e)
-      qv[j][e] = bf2f(q[(size_t)seq * ldq + (size_t)hk * q_group_stride + j * D + lane * EPL + e]);
-  float m[G], l[G], acc[G][EPL];
+      for (int c8 = 0; c8 < 8; ++c8) {
+        const u16x8 raw = *(const u16x8*)(kb + (size_t)kk * D + half * 64 + c8 * 8);
 #pragma unroll
-  for (int j = 0; j < G; ++j) { m[j] = -INFINITY; l[j] = 0.f; for (int e = 0; e < EPL; ++e) acc[j][e] = 0.f; }
-  const bf16_t* kb = kc + ((size_t)seq * n_kv + hk) * cap * D;
-  const bf16_t* vb = vc + ((size_t)seq * n_kv + hk) * cap * D;
-  for (int key = wave; key < kv_len; key += 4) {
-    float kk[EPL], vv[EPL];
+        for (int e = 0; e < 8; ++e) {
+          const float kvv = bf2f(raw[e]);
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) { kk[e] = bf2f(kb[(size_t)key * D + lane * EPL + e]); vv[e] = bf2f(vb[(size_t)key * D + lane * EPL + e]); }
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) d += qv[j][e] * kk[e];
-      d = wave_sum(d);
-      float s = rbf(d);
-      if (post_div != 1.0f) s = rbf(s / post_div);
-      const float mn = fmaxf(m[j], s);
-      const float a = __expf(m[j] - mn), pv = __expf(s - mn);
-      l[j] = l[j] * a + pv;
-      const float pb = rbf(pv);
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) acc[j][e] = acc[j][e] * a + pb * vv[e];
-      m[j] = mn;
+          for (int j2 = 0; j2 < G; ++j2) dot[j2] += kvv * sQ[j2][half * 64 + c8 * 8 + e];
+        }
+      }
     }
-  }
 #pragma unroll
-  for (int j = 0; j < G; ++j) {
-    if (lane == 0) { s_m[wave][j] = m[j]; s_l[wave][j] = l[j]; }
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) s_acc[wave][j][lane * EPL + e] = acc[j][e];
+    for (int j2 = 0; j2 < G; ++j2) {
+      const float tot = dot[j2] + __shfl_xor(dot[j2], 1, 64);
+      if (half == 0) {
+        float sc = rbf(tot);
+        if (post_div != 1.0f) sc = rbf(sc / post_div);
+        sS[j2][kk] = kk < nkeys ? sc : -INFINITY;
+      }
+    }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < G * D; idx += 256) {
-    const int j = idx / D, d = idx % D;
-    float mm = -INFINITY;
-    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, s_m[w][j]);
-    float ll = 0.f, aa = 0.f;
-    for (int w = 0; w < 4; ++w) {
-      const float sc = (s_m[w][j] == -INFINITY) ? 0.f : __expf(s_m[w][j] - mm);
-      ll += s_l[w][j] * sc;
-      aa += s_acc[w][j][d] * sc;
+  for (int j2 = wave; j2 < G; j2 += 4) {   // chunk softmax statistics: one wave per head
+    const float a = sS[j2][lane], b = sS[j2][lane + 64];
+    const float m = wave_max(fmaxf(a, b));
+    const float pa = __expf(a - m), pb = __expf(b - m);
+    const float l = wave_sum(pa + pb);
+    sS[j2][lane] = rbf(pa);
+    sS[j2][lane + 64] = rbf(pb);
+    if (lane == 0) { sM[j2] = m; sL[j2] = l; }
+  }
+  __syncthreads();
+  {  // P.V: thread -> dims (2*d2, 2*d2+1), key slice = wave (32 keys)
+    const int d2 = lane;
+    float acc[G][2];
+#pragma unroll
+    for (int j2 = 0; j2 < G; ++j2) acc[j2][0] = acc[j2][1] = 0.f;
+    const int kbeg = wave * 32, kend = min(kbeg + 32, nkeys);
+    for (int kk = kbeg; kk < kend; ++kk) {
+      const uint32_t raw = *(const uint32_t*)(vb + (size_t)kk * D + 2 * d2);
+      const float v0 = bf2f((bf16_t)(raw & 0xffff)), v1 = bf2f((bf16_t)(raw >> 16));
+#pragma unroll
+      for (int j2 = 0; j2 < G; ++j2) {
+        const float pr = sS[j2][kk];
+        acc[j2][0] += pr * v0;
+        acc[j2][1] += pr * v1;
+      }
     }
-    o[(size_t)seq * ldo + (size_t)(hk * G + j) * D + d] = f2bf(ll > 0.f ? aa / ll : 0.f);
+#pragma unroll
+    for (int j2 = 0; j2 < G; ++j2) { sAcc[wave][j2][2 * d2] = acc[j2][0]; sAcc[wave][j2][2 * d2 + 1] = acc[j2][1]; }
+  }
+  __syncthreads();
+  for (int i = t; i < G * D; i += 256) {
+    const int j2 = i / D, d = i % D;
+    wbase[(size_t)j2 * (D + 2) + 2 + d] = (sAcc[0][j2][d] + sAcc[1][j2][d]) + (sAcc[2][j2][d] + sAcc[3][j2][d]);
+  }
+  if (t < G) { wbase[(size_t)t * (D + 2)] = sM[t]; wbase[(size_t)t * (D + 2) + 1] = sL[t]; }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __restrict__ ws, int max_chunks,
+                                                                const int32_t* __restrict__ kv_lens, bf16_t* __restrict__ o,
+                                                                int ldo) {
+  constexpr int D = 128;
+  const int hk = blockIdx.x, seq = blockIdx.y, n_kv = gridDim.x;
+  const int nch = (kv_lens[seq] + DC - 1) / DC;
+  const float* base = ws + (((size_t)seq * n_kv + hk) * max_chunks) * G * (D + 2);
+  for (int i = threadIdx.x; i < G * D; i += 256) {
+    const int j2 = i / D, d = i % D;
+    float M = -INFINITY;
+    for (int ch = 0; ch < nch; ++ch) M = fmaxf(M, base[((size_t)ch * G + j2) * (D + 2)]);
+    float L = 0.f, A = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+      const float* pp = base + ((size_t)ch * G + j2) * (D + 2);
+      const float sc = __expf(pp[0] - M);
+      L += pp[1] * sc;
+      A += pp[2 + d] * sc;
+    }
+    o[(size_t)seq * ldo + (size_t)(hk * G + j2) * D + d] = f2bf(L > 0.f ? A / L : 0.f);
   }
 }
 
@@ -337,12 +388,21 @@ hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s)
   return hipGetLastError();
 }
 
+size_t aigv_attention_decode_ws_floats(int n_seq, int n_kv, int g, int cap) {
+  return (size_t)n_seq * n_kv * ((cap + DC - 1) / DC) * g * (128 + 2);
+}
+
 hipError_t aigv_launch_attention_decode(const bf16_t* q, int ldq, int q_group_stride, const bf16_t* kc,
                                         const bf16_t* vc, const int32_t* kv_lens, int cap, bf16_t* o, int ldo,
-                                        int n_seq, int n_kv, int g, int head_dim, float post_div, hipStream_t s) {
-  if (head_dim != 128) return hipErrorInvalidValue;
-  dim3 grid(n_kv, n_seq);
-#define DEC(G) hipLaunchKernelGGL((attn_decode_kernel<128, G>), grid, dim3(256), 0, s, q, ldq, q_group_stride, kc, vc, kv_lens, cap, o, ldo, post_div)
+                                        int n_seq, int n_kv, int g, int head_dim, float post_div, int max_kv_len,
+                                        float* ws, hipStream_t s) {
+  if (head_dim != 128 || !ws || max_kv_len <= 0 || max_kv_len > cap) return hipErrorInvalidValue;
+  const int max_chunks = (cap + DC - 1) / DC;
+  dim3 grid1((max_kv_len + DC - 1) / DC, n_kv, n_seq), grid2(n_kv, n_seq);
+#define DEC(G)                                                                                                              \
+  hipLaunchKernelGGL((attn_decode_partial_kernel<G>), grid1, dim3(256), 0, s, q, ldq, q_group_stride, kc, vc, kv_lens, cap, \
+                     post_div, ws, max_chunks);                                                                              \
+  hipLaunchKernelGGL((attn_decode_merge_kernel<G>), grid2, dim3(256), 0, s, ws, max_chunks, kv_lens, o, ldo)
   switch (g) {
     case 1: DEC(1); break;
     case 2: DEC(2); break;

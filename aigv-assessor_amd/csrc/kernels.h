@@ -54,10 +54,13 @@ struct AttnArgs {
 };
 const char* aigv_attn_check(const AttnArgs& a, int head_dim);
 hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s);
-// decode: one query row per sequence (fused qkv row), KV cache [seq][kv head][cap][D]
+// decode: one query row per sequence (fused qkv row), KV cache [seq][kv head][cap][D]; split-KV two-pass kernel,
+// ws = aigv_attention_decode_ws_floats(...) floats of scratch
+size_t aigv_attention_decode_ws_floats(int n_seq, int n_kv, int g, int cap);
 hipError_t aigv_launch_attention_decode(const bf16_t* q, int ldq, int q_group_stride, const bf16_t* kc,
                                         const bf16_t* vc, const int32_t* kv_lens, int cap, bf16_t* o, int ldo,
-                                        int n_seq, int n_kv, int g, int head_dim, float post_div, hipStream_t s);
+                                        int n_seq, int n_kv, int g, int head_dim, float post_div, int max_kv_len,
+                                        float* ws, hipStream_t s);
 
 // ---- row-wise / elementwise ---------------------------------------------------------------------
 // LayerNorm over rows of length H (fp32 statistics, bf16 out).
@@ -102,3 +105,5 @@ hipError_t aigv_launch_kv_store(const bf16_t* qkv, int ld, const int32_t* seq_of
 // frame ingest: uint8 HWC RGB -> (u/255 - mean)/std -> bf16 NCHW (torchvision ToTensor + Normalize + bf16 cast)
 hipError_t aigv_launch_frame_ingest(const uint8_t* hwc, int n_frames, int H, int W, const float* mean, const float* stdv,
                                     bf16_t* out, hipStream_t s);
+// a[i] += 1, b[i] += 1 for i < n (decode bookkeeping kept on the device: positions and visible KV lengths)
+hipError_t aigv_launch_advance(int32_t* a, int32_t* b, int n, hipStream_t s);

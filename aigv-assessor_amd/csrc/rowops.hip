@@ -219,7 +219,18 @@ __global__ __launch_bounds__(256) void kv_store_kernel(const bf16_t* __restrict_
   }
 }
 
+__global__ void advance_kernel(int32_t* a, int32_t* b, int n) {
+  const int i = threadIdx.x;
+  if (i < n) { a[i] += 1; b[i] += 1; }
+}
+
 }  // namespace
+
+hipError_t aigv_launch_advance(int32_t* a, int32_t* b, int n, hipStream_t s) {
+  if (n <= 0 || n > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, s, a, b, n);
+  return hipGetLastError();
+}
 
 hipError_t aigv_launch_layernorm(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int ldy,
                                  int rows, int H, float eps, hipStream_t s) {

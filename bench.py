@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--model", default="8b", choices=["8b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event roofline measurement")
+    ap.add_argument("--force-dp", action="store_true", help="route a 1-GPU run through the frame/clip-DP scorer too (debug)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,7 +116,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or (args.force_dp and "RANK" in os.environ):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import aigv_assessor_amd as pkg
@@ -144,7 +145,7 @@ def main():
     ids, labels, am = toks["input_ids"], toks["labels"], toks["attention_mask"]
 
     def step():
-        if world == 1:
+        if world == 1 and not args.force_dp:
             return model(mos=None, pixel_values=pv, input_ids=ids, attention_mask=am, image_flags=flags, labels=labels,
                          motion_feature=motion)
         return score_clips_dp(model, pv, ids, am, flags, labels, motion)
@@ -211,7 +212,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, T, N)
             line["gpu_over_cpu"] = clips_per_s / line["cpu_baseline"]["value"]
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -248,3 +248,30 @@ def test_errors_are_loud():
     with pytest.raises(RuntimeError):                                 # SlowFast is an input
         model(pixel_values=synth.synthetic_frames(4, 224), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
               image_flags=torch.ones(4, 1, dtype=torch.long), labels=toks["labels"])
+
+
+def test_26b_widths_and_16_frames_smoke():
+    """BASELINE configs 3/4 plumbing at reduced depth: InternViT-6B widths (RMSNorm + QK-norm, 25 heads x 128) and
+    InternLM2-20B widths (48 q / 8 kv heads), 16 frames per clip -> N = 4281 tokens; parity vs the oracle on levels/score."""
+    cfg = pkg.internvl2_26b()
+    cfg.vision_config.num_hidden_layers = 1
+    cfg.llm_config.num_hidden_layers = 1
+    cfg.llm_config.vocab_size = 2048
+    cfg.vision_config.intermediate_size = 1280
+    cfg.llm_config.intermediate_size = 2048
+    cfg.score_dims = (256, 64, 16, 1)
+    B, T, seed = 1, 16, 12
+    sd = synth.make_state_dict(cfg, seed=seed, rich=True)
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    assert toks["input_ids"].shape[1] == 4281
+    pv = synth.synthetic_frames(B * T, 448, seed=seed)
+    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=seed)
+    flags = torch.ones(B * T, 1, dtype=torch.long)
+    ref = O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion,
+                         toks["img_context_token_id"], stage=2, return_intermediates=True)
+    model = make_model(cfg, sd)
+    model.img_context_token_id = toks["img_context_token_id"]
+    out = model(pixel_values=pv, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"], image_flags=flags,
+                labels=toks["labels"], motion_feature=motion)
+    check_levels(out, ref)
+    score_ok(out["score1"], ref["score1"])
