@@ -19,7 +19,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(uint
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// x * sigmoid(x) with hardware exp2 / rcp (about 3 ulp in fp32, i.e. ~2e-4 of the results round to the neighbouring
+// bf16 value relative to an exactly rounded evaluation - the same order as the vectorised CPU kernels' own exp error);
+// 6 VALU instructions instead of 27 for expf + IEEE division: the SwiGLU epilogue is VALU-bound
+__device__ __forceinline__ float silu_f(float x) {
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x);   // exp(-x); overflow -> inf -> rcp -> 0 -> x*0
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -70,6 +70,8 @@ __device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uni
 // VAR bit 0: balanced LDS reads (B(nh0) of the NEXT tile is read in phase j=3 into an alternate register set; waits
 //            become vmcnt(8,8,6,-)), steady-state tiles run without issue/wait branches
 // VAR bit 1: no s_setprio around the MFMA cluster
+// VAR bit 2: epilogue staged through LDS: each wave transposes its tile so that global loads/stores are 16 B per lane
+//            over whole 128-B row segments (half the store instructions of the 8-B-per-lane direct form)
 template <int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -253,6 +255,94 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   }
   if (g == 0) RAW_BARRIER();   // balance the stagger barrier
 
+  if constexpr ((VAR & 4) != 0) {
+    // ---- LDS-staged epilogue ------------------------------------------------------------------------------------
+    // All DMA has landed (the tail waits reach vmcnt(0)) and every wave is past its last fragment read (final barriers), so
+    // the tile buffers are free.  Each wave owns 64 rows x 144 B of LDS (row padded by 16 B: ds_write_b64 of the MFMA layout
+    // and ds_read_b128 of the row layout stay 16-B aligned and at most 2-way conflicted).  Stage 1 applies the part of the
+    // epilogue that is a function of the accumulator only (bias, rounding, GELU, layer-scale, SwiGLU) and writes bf16;
+    // stage 2 re-reads whole row segments, adds residual / position rows and stores 16 B per lane.
+    constexpr int ROWP = 144;
+    constexpr int OC = (EPI == EPI_SWIGLU) ? 32 : 64;       // output columns per wave
+    constexpr int CPR = OC / 8;                             // 16-B chunks per staged row
+    char* st = smem + wave * (64 * ROWP);
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        char* rowp = st + (mt * 16 + fr) * ROWP;
+        if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) {
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float gt = rbf(acc[mh][mt][nh][0][e]), up = rbf(acc[mh][mt][nh][1][e]);
+              o[e] = f2bf(rbf(silu_f(gt)) * up);
+            }
+            *(u16x4*)(rowp + (nh * 16 + fq * 4) * 2) = o;
+          }
+        } else {
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int cl = nh * 32 + nt * 16 + fq * 4;       // column inside the wave's 64
+              const int n = n0 + wc * 64 + cl;
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[mh][mt][nh][nt][e];
+              if (p.bias) {
+                const u16x4 b = *(const u16x4*)(p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+              if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+              }
+              if constexpr (EPI == EPI_LS_RESID) {
+                const u16x4 sc = *(const u16x4*)(p.ls + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] * bf2f(sc[e]));
+              }
+              u16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+              *(u16x4*)(rowp + cl * 2) = o;
+            }
+        }
+      }
+      // stage 2: lane -> (row = i*RPI + lane / CPR, chunk = lane % CPR)
+      constexpr int RPI = 64 / CPR;                          // rows per wave-instruction (8 or 16)
+#pragma unroll
+      for (int i = 0; i < 64 / RPI; ++i) {
+        const int r = i * RPI + lane / CPR, ch = lane % CPR;
+        const int m = m0 + g * 128 + mh * 64 + r;
+        u16x8 val = *(const u16x8*)(st + r * ROWP + ch * 16);
+        if (m < p.M) {
+          const int n = (EPI == EPI_SWIGLU ? (n0 + wc * 64) / 2 : n0 + wc * 64) + ch * 8;
+          size_t orow = (size_t)m;
+          if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) {
+            const u16x8 rr = *(const u16x8*)(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = f2bf(bf2f(rr[e]) + bf2f(val[e]));
+          }
+          if constexpr (EPI == EPI_PATCH) {
+            const int f = m / p.np, pi = m - f * p.np;
+            orow = (size_t)m + f + 1;
+            const u16x8 ps = *(const u16x8*)(p.pos + (size_t)(pi + 1) * p.N + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = f2bf(bf2f(val[e]) + bf2f(ps[e]));
+          }
+          *(u16x8*)(p.C + orow * p.ldc + n) = val;
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane owns C[m][n .. n+3] ----
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
@@ -351,15 +441,15 @@ hipError_t launch256v(const GemmArgs& a, int epi, hipStream_t s) {
 
 }  // namespace
 
-int g_gemm256_variant = 3;   // balanced LDS reads + no s_setprio: fastest in the interleaved A/B (profiles/r1_gemm_variants.txt)
+int g_gemm256_variant = 1;   // balanced reads + no s_setprio + LDS-staged epilogue: fastest in interleaved A/B (profiles/r1_gemm_variants.txt)
 
 bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0 && a.M >= 1; }
 
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
   switch (g_gemm256_variant) {
-    case 1: return launch256v<1>(a, epi, s);
-    case 2: return launch256v<2>(a, epi, s);
-    case 3: return launch256v<3>(a, epi, s);
-    default: return launch256v<0>(a, epi, s);
+    case 0: return launch256v<0>(a, epi, s);   // first schedule (unbalanced reads, setprio)
+    case 1: return launch256v<7>(a, epi, s);   // balanced + no setprio + LDS-staged epilogue
+    case 2: return launch256v<4>(a, epi, s);   // first schedule + LDS-staged epilogue
+    default: return launch256v<3>(a, epi, s);  // balanced + no setprio, direct epilogue
   }
 }
