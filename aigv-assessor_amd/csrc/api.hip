@@ -711,7 +711,7 @@ static int final_rows(aigv_ctx* c, const int32_t* score_rows, float* score, int 
     if (v < 0 || v >= total_rows) return fail(c, AIGV_ERR_ARG, "output row index %d outside 0..%d", v, total_rows - 1);
   const int n = (int)c->h_rowidx.size();
   if (n == 0) return 0;
-  HIPCHK(c, hipMemcpyAsync(c->l_rowidx, c->h_rowidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, aigv_launch_write_ints(c->h_rowidx.data(), n, c->l_rowidx, s));
   // final RMSNorm only on the rows that are consumed (modeling_internlm2.py:984)
   HIPCHK(c, aigv_launch_rmsnorm(hidden, H, c->final_norm, c->l_rows, H, n, H, k.rms_eps, c->l_rowidx, s));
   for (int b0 = 0; b0 < nS; b0 += 64) {
@@ -754,13 +754,9 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
   hipStream_t s = (hipStream_t)stream;
   const int H = k.llm_hidden, I = k.llm_inter, D = c->head_dim, g = c->g, nkv = k.llm_kv_heads;
 
-  c->h_pos.resize(T);
-  c->h_seq.resize(T);
-  for (int b = 0; b < B; ++b)
-    for (int t = cu[b]; t < cu[b + 1]; ++t) { c->h_pos[t] = t - cu[b]; c->h_seq[t] = b; }
-  HIPCHK(c, hipMemcpyAsync(c->l_pos, c->h_pos.data(), (size_t)T * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(c->l_seq, c->h_seq.data(), (size_t)T * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(c->l_cu, cu, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
+  if (B + 1 > AIGV_SMALL_INTS) return fail(c, AIGV_ERR_ARG, "at most %d clips per prefill call", AIGV_SMALL_INTS - 1);
+  // positions / sequence ids / cu_seqlens are produced on the device from cu passed as a kernel argument
+  HIPCHK(c, aigv_launch_seqpos(cu, B, c->l_pos, c->l_seq, c->l_cu, T, s));
 
   HIPCHK(c, aigv_launch_embed(ids, slot, c->tok_emb, (const bf16_t*)vis, (const bf16_t*)motion, n_vis, c->l_h, T, H, s));
   double attn_flops = 0;
@@ -809,10 +805,10 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       c->h_kvlen[b] = len;
       c->h_dec[b] = len; c->h_dec[B + b] = b; c->h_dec[2 * B + b] = len + 1; c->h_dec[3 * B + b] = -1;
     }
-    HIPCHK(c, hipMemcpyAsync(c->dec_pos, c->h_dec.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->dec_seq, c->h_dec.data() + B, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->dec_kvlen, c->h_dec.data() + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->dec_slot, c->h_dec.data() + 3 * B, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, aigv_launch_write_ints(c->h_dec.data(), B, c->dec_pos, s));
+    HIPCHK(c, aigv_launch_write_ints(c->h_dec.data() + B, B, c->dec_seq, s));
+    HIPCHK(c, aigv_launch_write_ints(c->h_dec.data() + 2 * B, B, c->dec_kvlen, s));
+    HIPCHK(c, aigv_launch_write_ints(c->h_dec.data() + 3 * B, B, c->dec_slot, s));
     c->kv_seqs = B;
     c->kv_valid = true;
   } else {

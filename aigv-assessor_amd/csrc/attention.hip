@@ -3,8 +3,8 @@
 //   D = 128 causal GQA : InternLM2 prefill attention       (reference: modeling_internlm2.py:355-440 / flash :444-614)
 //
 // Work split: grid = (q blocks of 128 rows, q heads, sequences); 4 waves per workgroup, each wave owns
-// 32 query rows; the workgroup streams 64-key K/V tiles through LDS (register-staged: the loads of tile
-// t+1 are issued before the MFMAs of tile t and written to LDS after them).
+// 32 query rows; the workgroup streams 64-key K/V tiles through a double-buffered LDS ring filled by LDS-DMA
+// (global_load_lds, 16 B/lane): tile t+1 is in flight while tile t is multiplied; one barrier per tile.
 //
 // MFMA formulation ("key on the row, query on the lane"):
 //   S^T[key, q] = K · Q^T      v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128, XOR-swizzled),
@@ -50,9 +50,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int NLD = KT * CPR / 256;        // chunks per thread per operand tile (2 for D=64, 4 for D=128)
   constexpr int NKS = D / 16;                // k-steps of the S^T product
   constexpr int NDT = D / 32;                // 32-row tiles of O^T
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT * ROWB];
-  char* sK = smem;
-  char* sV = smem + KT * ROWB;
+  // two K/V buffers, filled by LDS-DMA (no staging registers, no ds_write pass): tile t+1 is in flight while tile t is used
+  __shared__ __attribute__((aligned(16))) char smem[4 * KT * ROWB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -94,27 +93,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   const bf16_t* kbase = p.k + (size_t)row0 * p.ldk + (size_t)hk * p.kv_head_stride;
   const bf16_t* vbase = p.v + (size_t)row0 * p.ldv + (size_t)hk * p.kv_head_stride;
 
-  u16x8 kreg[NLD], vreg[NLD];
-  auto gload = [&](int kt) {
+  // LDS-DMA staging: a wave-instruction writes 1 KB = RPI rows linearly, so the bank swizzles are applied to the per-lane
+  // SOURCE chunk (the same XOR the fragment reads apply).  Keys past kv_len re-read the last valid row (masked later).
+  constexpr int RPI = 1024 / ROWB;            // rows per wave-instruction (8 for D=64, 4 for D=128)
+  constexpr int IPW = KT / RPI / 4;           // wave-instructions per wave per operand (2 / 4)
+  const int s_r = lane / CPR, s_c = lane % CPR;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
+  auto stage = [&](int kt, int buf) {
+    const unsigned dK = lds0 + buf * (2 * KT * ROWB), dV = dK + KT * ROWB;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + i * 256, r = idx / CPR, ch = idx % CPR;
-      const int key = kt * KT + r;
-      if (key < kv_len) {
-        kreg[i] = *(const u16x8*)(kbase + (size_t)key * p.ldk + ch * 8);
-        vreg[i] = *(const u16x8*)(vbase + (size_t)key * p.ldv + ch * 8);
-      } else {
-        kreg[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        vreg[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + i * 256, r = idx / CPR, ch = idx % CPR;
-      *(u16x8*)(sK + r * ROWB + Lay<D>::kchunk(r, ch) * 16) = kreg[i];
-      *(u16x8*)(sV + r * ROWB + Lay<D>::vchunk(r, ch) * 16) = vreg[i];
+    for (int i = 0; i < IPW; ++i) {
+      const int ins = wave_u * IPW + i;
+      const int r = ins * RPI + s_r;
+      const int key = min(kt * KT + r, kv_len - 1);
+      glds16_asm(kbase + (size_t)key * p.ldk + Lay<D>::kchunk(r, s_c) * 8, dK + ins * 1024);
+      glds16_asm(vbase + (size_t)key * p.ldv + Lay<D>::vchunk(r, s_c) * 8, dV + ins * 1024);
     }
   };
 
@@ -131,12 +125,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   const int tr_key = 4 * (gi >> 1) + (li >> 2);       // + 32*st + 16*s + 8*jh
   const int tr_dcol = 16 * (gi & 1) + 4 * (li & 3);   // + 32*dt
 
-  gload(0);
+  stage(0, 0);
   for (int kt = 0; kt < n_tiles; ++kt) {
-    __syncthreads();
-    lstore();
-    __syncthreads();
-    if (kt + 1 < n_tiles) gload(kt + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile kt landed for every wave; everyone is done reading the other buffer
+    if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+    const char* sK = smem + (kt & 1) * (2 * KT * ROWB);
+    const char* sV = sK + KT * ROWB;
 
     const int key0 = kt * KT;
     // wave-uniform skip of tiles that are entirely in this wave's causal future
@@ -183,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     const float m_new = fmaxf(m_run, tmax);
     if (__any(m_new != m_run)) {
       // rows with no visible key yet keep m = -inf; guard the exp argument (m_run = -inf -> alpha = 0)
-      const float alpha = (m_new == -INFINITY) ? 1.0f : exp2f((m_run - m_new) * sc);
+      const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m_run - m_new) * sc);
       l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < NDT; ++i)
@@ -197,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = exp2f(fmaf(sacc[st][e], sc, -mc));
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], sc, -mc));   // raw v_exp_f32: p underflows to 0, no fix-up needed
         psum += pv;
         sacc[st][e] = pv;
       }
@@ -209,10 +204,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        u16x8 pr;
+        typedef __attribute__((ext_vector_type(8))) float f32x8;
+        f32x8 pw;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pr[j] = f2bf(sacc[st][8 * s2 + j]);
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pr);
+        for (int j = 0; j < 8; ++j) pw[j] = sacc[st][8 * s2 + j];
+        const bf16x8 pf = __builtin_convertvector(pw, bf16x8);   // four v_cvt_pk_bf16_f32
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
           const int dcol = 32 * dt + tr_dcol;

@@ -55,3 +55,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
+
+// The same LDS-DMA issued from inline asm (per-lane 64-bit source address): hipcc does not see it, so it neither counts it
+// in its vmcnt bookkeeping nor inserts a conservative vmcnt(0) in front of later LDS reads - the caller owns the wait
+// (s_waitcnt vmcnt(N) + barrier before the data is read).  M0 = LDS destination base, saved and restored.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_wave_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_wave_base)
+      : "memory");
+}

@@ -107,3 +107,10 @@ hipError_t aigv_launch_frame_ingest(const uint8_t* hwc, int n_frames, int H, int
                                     bf16_t* out, hipStream_t s);
 // a[i] += 1, b[i] += 1 for i < n (decode bookkeeping kept on the device: positions and visible KV lengths)
 hipError_t aigv_launch_advance(int32_t* a, int32_t* b, int n, hipStream_t s);
+// small host int arrays passed by value as kernel arguments (no memcpy, no implicit host/stream sync)
+#define AIGV_SMALL_INTS 256
+struct SmallInts { int32_t v[AIGV_SMALL_INTS]; };
+// pos[t] = t - cu[seq(t)], seq[t], and a device copy of cu[0..n_seq]
+hipError_t aigv_launch_seqpos(const int32_t* cu_host, int n_seq, int32_t* pos, int32_t* seq, int32_t* cu_dev, int tokens,
+                              hipStream_t s);
+hipError_t aigv_launch_write_ints(const int32_t* host, int n, int32_t* dst, hipStream_t s);

@@ -219,12 +219,50 @@ __global__ __launch_bounds__(256) void kv_store_kernel(const bf16_t* __restrict_
   }
 }
 
+// Host bookkeeping arrays travel as KERNEL ARGUMENTS (<= 4 KB), not as memcpys: a pageable hipMemcpyAsync makes the
+// host wait for the stream, which would stop the CPU from running ahead of the GPU.
+__global__ __launch_bounds__(256) void seqpos_kernel(const SmallInts cu, int n_seq, int32_t* __restrict__ pos,
+                                                     int32_t* __restrict__ seq, int32_t* __restrict__ cu_out, int tokens) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t <= n_seq) cu_out[t] = cu.v[t];
+  if (t >= tokens) return;
+  int b = 0;
+  while (b + 1 < n_seq && t >= cu.v[b + 1]) ++b;
+  pos[t] = t - cu.v[b];
+  seq[t] = b;
+}
+
+__global__ void write_ints_kernel(const SmallInts src, int n, int32_t* __restrict__ dst) {
+  const int i = threadIdx.x;
+  if (i < n) dst[i] = src.v[i];
+}
+
 __global__ void advance_kernel(int32_t* a, int32_t* b, int n) {
   const int i = threadIdx.x;
   if (i < n) { a[i] += 1; b[i] += 1; }
 }
 
 }  // namespace
+
+hipError_t aigv_launch_seqpos(const int32_t* cu_host, int n_seq, int32_t* pos, int32_t* seq, int32_t* cu_dev, int tokens,
+                              hipStream_t s) {
+  if (n_seq <= 0 || n_seq + 1 > AIGV_SMALL_INTS || tokens <= 0) return hipErrorInvalidValue;
+  SmallInts a{};
+  for (int i = 0; i <= n_seq; ++i) a.v[i] = cu_host[i];
+  hipLaunchKernelGGL(seqpos_kernel, dim3((tokens + 255) / 256), dim3(256), 0, s, a, n_seq, pos, seq, cu_dev, tokens);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_write_ints(const int32_t* host, int n, int32_t* dst, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  for (int off = 0; off < n; off += AIGV_SMALL_INTS) {
+    SmallInts a{};
+    const int m = n - off < AIGV_SMALL_INTS ? n - off : AIGV_SMALL_INTS;
+    for (int i = 0; i < m; ++i) a.v[i] = host[off + i];
+    hipLaunchKernelGGL(write_ints_kernel, dim3(1), dim3(AIGV_SMALL_INTS), 0, s, a, m, dst + off);
+  }
+  return hipGetLastError();
+}
 
 hipError_t aigv_launch_advance(int32_t* a, int32_t* b, int n, hipStream_t s) {
   if (n <= 0 || n > 1024) return hipErrorInvalidValue;

@@ -415,8 +415,11 @@ class InternVLChatModel(nn.Module):
         T = cu[-1]
         lib, ctx = self._native(n_tokens=T, n_clips=b, out_rows=len(logit_rows), kv_cap=kv_cap)
         dev = self.device
-        ids_d = ids_packed.to(device=dev, dtype=torch.long).contiguous()
-        slot_d = slot.to(device=dev, dtype=torch.int32).contiguous()
+        def up(t, dt):   # host index arrays go up through pinned memory without blocking the host
+            t = t.to(dt).contiguous()
+            return t if t.is_cuda else t.pin_memory().to(dev, non_blocking=True)
+        ids_d = up(ids_packed, torch.long)
+        slot_d = up(slot, torch.int32)
         score = torch.empty(b, dtype=torch.float32, device=dev) if score_rows is not None else None
         amax = torch.empty(max(len(logit_rows), 1), dtype=torch.long, device=dev)
         cu_a = native.i32_array(cu)
@@ -488,14 +491,16 @@ class InternVLChatModel(nn.Module):
             visual_tokens = self.vit_tokens(pixel_values)
         vit_embeds = self.project(visual_tokens)                       # [F, ntok, H]
         if flags_h is not None and int(keep.numel()) != n_frames:
-            vit_embeds = vit_embeds[keep.to(dev)]
+            vit_embeds = vit_embeds[keep.pin_memory().to(dev, non_blocking=True)]
         vit_embeds = vit_embeds.reshape(-1, H)
         motion = self.motion_embed(motion_feature)
         score, amax = self._prefill(ids_packed, slot, cu, vit_embeds, n_vis, motion, score_rows, logit_rows)
+        def up(t):   # host -> device through pinned memory, never blocking the host (keeps the CPU ahead of the GPU)
+            return t if t.is_cuda else t.contiguous().pin_memory().to(dev, non_blocking=True)
         logit = torch.full((B * (N - 1),), -1, dtype=torch.long, device=dev)
         if len(logit_rows):
-            logit.index_copy_(0, want.reshape(-1).nonzero().flatten().to(dev), amax)   # index list built on the host: no sync
-        out = {"label": labels_h[..., 1:].contiguous().view(-1).to(dev), "logit": logit.view(-1)}
+            logit.index_copy_(0, up(want.reshape(-1).nonzero().flatten()), amax)   # index list built on the host: no sync
+        out = {"label": up(labels_h[..., 1:].contiguous().view(-1)), "logit": logit.view(-1)}
         if self.stage == 2:
             score1 = score.to(torch.bfloat16)       # the head computes in bf16; the value is exact in fp32
             out["score1"] = score1
