@@ -180,6 +180,41 @@ double cost256(int M, int N) {   // one workgroup per CU; a round = 256 tiles of
   return (double)((tiles + 255) / 256) * 2.0 / g_rate256;
 }
 
+// fp32 scratch for split-K tails (one per process, grown on demand; tails are a few hundred rows)
+float* g_splitk_ws = nullptr;
+size_t g_splitk_floats = 0;
+constexpr size_t SPLITK_MAX_FLOATS = (size_t)32 << 20;   // 128 MB
+
+// a tail that fills at most one workgroup per CU is latency-bound on its K loop: split K over k_slices workgroups
+int tail_slices(const GemmArgs& a, int epi) {
+  if (epi == EPI_PATCH || g_gemm_mode != 0) return 1;
+  const long tiles = (long)((a.M + 127) / 128) * (a.N / 128);
+  const int nk = a.K / 64;
+  if (tiles > 256 || nk < 32) return 1;
+  int S = (int)(512 / tiles);
+  if (S > 4) S = 4;
+  while (S > 1 && (nk % S || (size_t)S * a.M * a.N > SPLITK_MAX_FLOATS)) --S;
+  return S;
+}
+
+int launch_tail128(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
+  const int S = tail_slices(a, epi);
+  if (S < 2) {
+    ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * a.M * (double)a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N), s);
+    HIPCHK(c, aigv_launch_gemm(a, epi, s));
+    return 0;
+  }
+  const size_t need = (size_t)S * a.M * a.N;
+  if (need > g_splitk_floats) {
+    if (g_splitk_ws) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(g_splitk_ws)); g_splitk_ws = nullptr; g_splitk_floats = 0; }
+    HIPCHK(c, hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
+    g_splitk_floats = need;
+  }
+  ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * a.M * (double)a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N), s);
+  HIPCHK(c, aigv_launch_gemm_splitk(a, epi, S, g_splitk_ws, s));
+  return 0;
+}
+
 int launch_one(aigv_ctx* c, const GemmArgs& a, int epi, bool use256, hipStream_t s) {
   ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N), s);
@@ -246,7 +281,7 @@ int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
       if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "skinny remainder (M=%d N=%d K=%d): %s", bot.M, bot.N, bot.K, hipGetErrorString(e));
       return 0;
     }
-    return launch_one(c, bot, epi, false, s);
+    return launch_tail128(c, bot, epi, s);
   }
   return 0;
 }
@@ -863,6 +898,16 @@ int aigv_op_gemm(const void* A, int lda, const void* W_, int ldw, void* C, int l
   a.bias = (const bf16_t*)bias; a.ls = (const bf16_t*)ls; a.resid = (const bf16_t*)resid; a.ldr = ldr;
   a.pos = (const bf16_t*)pos; a.np = np;
   return run_gemm(nullptr, a, epi, (hipStream_t)stream);
+}
+
+int aigv_op_gemm_splitk(const void* A, int lda, const void* W_, int ldw, void* C, int ldc, const void* bias, const void* ls,
+                        const void* resid, int ldr, int M, int N, int K, int epi, int k_slices, void* ws_f32, void* stream) {
+  GemmArgs a = gemm_args((const bf16_t*)A, lda, (const bf16_t*)W_, ldw, (bf16_t*)C, ldc, M, N, K);
+  a.bias = (const bf16_t*)bias; a.ls = (const bf16_t*)ls; a.resid = (const bf16_t*)resid; a.ldr = ldr;
+  if (const char* m = aigv_gemm_check(a, epi)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
+  hipError_t e = aigv_launch_gemm_splitk(a, epi, k_slices, (float*)ws_f32, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "split-K gemm: %s", hipGetErrorString(e));
+  return 0;
 }
 
 int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W_, int ldw, int N, int K, const void* bias,

@@ -90,12 +90,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
-  stage(0, 0);
+  // split-K (EPI_PARTIAL): blockIdx.y picks the K slice
+  const int nk = (EPI == EPI_PARTIAL) ? p.K / BK / p.k_slices : p.K / BK;
+  const int kbase = (EPI == EPI_PARTIAL) ? (int)blockIdx.y * nk * BK : 0;
+  stage(0, kbase);
   for (int t = 0; t < nk; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile t landed for every wave; everyone is done reading the other buffer
-    if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+    if (t + 1 < nk) stage((t + 1) & 1, kbase + (t + 1) * BK);
     const char* sA = smem + (t & 1) * STAGE_BYTES;
     const char* sW = sA + TILE_BYTES;
 #pragma unroll
@@ -118,7 +120,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + fr;
     if (m >= p.M) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
+    if constexpr (EPI == EPI_PARTIAL) {
+      float* slab = p.part + ((size_t)blockIdx.y * p.M + m) * p.N;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(slab + n0 + wn * 64 + j * 16 + fq * 4) = acc[i][j];
+    } else if constexpr (EPI == EPI_SWIGLU) {
       // W rows are interleaved in 16-row blocks: even block = w1 (gate), odd block = w3 (up)
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
@@ -194,6 +200,73 @@ hipError_t launch(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- split-K finalize: sum the slabs in slice order, then the same epilogues as the GEMM kernels ------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs p, const float* __restrict__ part, int S) {
+  const int nq = p.N / 4;                       // float4 groups per row
+  const size_t total = (size_t)p.M * nq, slab = (size_t)p.M * p.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / nq), n = (int)(i - (size_t)m * nq) * 4;
+    f32x4 a = *(const f32x4*)(part + (size_t)m * p.N + n);
+    for (int sidx = 1; sidx < S; ++sidx) {
+      const f32x4 b = *(const f32x4*)(part + sidx * slab + (size_t)m * p.N + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += b[e];
+    }
+    if constexpr (EPI == EPI_SWIGLU) {
+      // 16-row interleave: columns [32b, 32b+16) gate, [32b+16, 32b+32) up -> output column 16b + (n % 16)
+      const int blk = n >> 5, within = n & 31;
+      if (within >= 16) continue;               // the gate thread also reads its up partner
+      f32x4 u = *(const f32x4*)(part + (size_t)m * p.N + n + 16);
+      for (int sidx = 1; sidx < S; ++sidx) {
+        const f32x4 b = *(const f32x4*)(part + sidx * slab + (size_t)m * p.N + n + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] += b[e];
+      }
+      u16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(silu_f(rbf(a[e]))) * rbf(u[e]));
+      *(u16x4*)(p.C + (size_t)m * p.ldc + blk * 16 + within) = o;
+    } else {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = a[e];
+      if (p.bias) {
+        const u16x4 b = *(const u16x4*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+      if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+      }
+      if constexpr (EPI == EPI_LS_RESID) {
+        const u16x4 sc = *(const u16x4*)(p.ls + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] * bf2f(sc[e]));
+      }
+      if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) {
+        const u16x4 r = *(const u16x4*)(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(bf2f(r[e]) + v[e]);
+      }
+      u16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+      *(u16x4*)(p.C + (size_t)m * p.ldc + n) = o;
+    }
+  }
+}
+
+template <int EPI>
+void launch_finalize(const GemmArgs& a, const float* part, int S, hipStream_t s) {
+  const size_t total = (size_t)a.M * (a.N / 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(gemm_finalize_kernel<EPI>, dim3(blocks), dim3(256), 0, s, a, part, S);
+}
+
 }  // namespace
 
 const char* aigv_gemm_check(const GemmArgs& a, int epi) {
@@ -208,6 +281,31 @@ const char* aigv_gemm_check(const GemmArgs& a, int epi) {
   if (epi == EPI_SWIGLU && a.ldc < a.N / 2) return "gemm: swiglu output is N/2 wide";
   if (epi < 0 || epi >= EPI_COUNT) return "gemm: unknown epilogue";
   return nullptr;
+}
+
+hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s) {
+  if (k_slices < 2 || (a.K / BK) % k_slices || !ws || epi == EPI_PATCH || epi >= EPI_COUNT) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * STAGE_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  GemmArgs b = a;
+  b.part = ws;
+  b.k_slices = k_slices;
+  const int nbm = (a.M + BM - 1) / BM, nbn = a.N / BN;
+  hipLaunchKernelGGL(gemm_bf16_kernel<EPI_PARTIAL>, dim3(nbm * nbn, k_slices), dim3(256), 2 * STAGE_BYTES, s, b);
+  switch (epi) {
+    case EPI_STORE: launch_finalize<EPI_STORE>(a, ws, k_slices, s); break;
+    case EPI_GELU: launch_finalize<EPI_GELU>(a, ws, k_slices, s); break;
+    case EPI_LS_RESID: launch_finalize<EPI_LS_RESID>(a, ws, k_slices, s); break;
+    case EPI_RESID: launch_finalize<EPI_RESID>(a, ws, k_slices, s); break;
+    case EPI_SWIGLU: launch_finalize<EPI_SWIGLU>(a, ws, k_slices, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t aigv_launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {

@@ -13,7 +13,8 @@ enum GemmEpilogue {
   EPI_RESID = 3,     // C = bf16(resid + bf16(acc + bias?))
   EPI_SWIGLU = 4,    // W = 16-row interleave of (w1, w3); C[M, N/2] = bf16(bf16(silu(bf16(g))) * bf16(u))
   EPI_PATCH = 5,     // patch-embed: C[m + m/np + 1] = bf16(bf16(acc + bias) + pos[m % np + 1])
-  EPI_COUNT = 6
+  EPI_COUNT = 6,
+  EPI_PARTIAL = 6    // internal (split-K tails): fp32 partial sums of K slice blockIdx.y -> part[slice][M][N]
 };
 
 struct GemmArgs {
@@ -26,10 +27,15 @@ struct GemmArgs {
   const bf16_t* pos;            // [np+1, N] position table (EPI_PATCH)
   int M, N, K;
   int np;                       // patches per frame (EPI_PATCH)
+  float* part;                  // EPI_PARTIAL: fp32 slabs [k_slices][M][N]
+  int k_slices;                 // EPI_PARTIAL: grid.y; each slice covers K / k_slices (a multiple of 64)
 };
 
 const char* aigv_gemm_check(const GemmArgs& a, int epi);   // nullptr if the shapes fit the kernel
 hipError_t aigv_launch_gemm(const GemmArgs& a, int epi, hipStream_t s);           // 128x128 tile kernel (gemm.hip)
+// split-K for latency-bound tails: k_slices x the tiles of the 128 kernel write fp32 slabs, then one pass sums them in a
+// fixed order and applies epilogue `epi` (deterministic; ws holds k_slices*M*N floats)
+hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s);
 bool aigv_gemm256_supported(const GemmArgs& a);
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);        // 256x256 phase-interleaved kernel
 

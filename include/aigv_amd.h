@@ -110,6 +110,10 @@ int aigv_decode_step(aigv_ctx* ctx, const int64_t* ids, int64_t* next, void* str
 /* C = epilogue(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch */
 int aigv_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
                  const void* resid, int ldr, const void* pos, int np, int M, int N, int K, int epi, void* stream);
+/* the split-K form used for latency-bound row tails: k_slices x tiles write fp32 slabs into ws_f32 (k_slices*M*N floats),
+ * one pass sums them in slice order and applies the epilogue (epi 0..4) */
+int aigv_op_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
+                        const void* resid, int ldr, int M, int N, int K, int epi, int k_slices, void* ws_f32, void* stream);
 int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W, int ldw, int N, int K, const void* bias,
                         const void* resid, int ldr, void* out, int ldo, int epi, void* stream);
 int aigv_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H,

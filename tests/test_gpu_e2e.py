@@ -275,3 +275,41 @@ def test_26b_widths_and_16_frames_smoke():
                 labels=toks["labels"], motion_feature=motion)
     check_levels(out, ref)
     score_ok(out["score1"], ref["score1"])
+
+
+def test_full_size_8b_properties():
+    """BASELINE.json full size (InternVL2-8B widths and depth, 8 frames x 448 px, N = 2177): the oracle cannot run this in
+    seconds, so check size-independent properties of the product path: determinism, batch invariance (two clips scored
+    together == each scored alone, bit for bit), frame-DP equivalence through score_clips_dp, answer rows filled."""
+    from aigv_assessor_amd.dist_utils import score_clips_dp
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    cfg = pkg.internvl2_8b()
+    dev = torch.device("cuda", 0)
+    model = InternVLChatModel(cfg, device=dev, max_clips=2, max_frames=16, max_tokens=2 * synth.canonical_len(cfg, 8))
+    model.load_state_dict(synth.make_state_dict(cfg, seed=3, device=dev, rich=True))
+    B, T = 2, 8
+    toks = synth.canonical_tokens(cfg, B, T, seed=3)
+    model.img_context_token_id = toks["img_context_token_id"]
+    model.eval()
+    pv = synth.synthetic_frames(B * T, 448, seed=3, device=dev)
+    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=3, device=dev)
+    flags = torch.ones(B * T, 1, dtype=torch.long)
+
+    def run(sl_c, sl_f):
+        return model(pixel_values=pv[sl_f], input_ids=toks["input_ids"][sl_c], attention_mask=toks["attention_mask"][sl_c],
+                     image_flags=flags[sl_f], labels=toks["labels"][sl_c], motion_feature=motion[sl_c])
+    both = run(slice(0, 2), slice(0, 16))
+    again = run(slice(0, 2), slice(0, 16))
+    assert torch.equal(both["score1"], again["score1"]) and torch.equal(both["logit"], again["logit"])      # deterministic
+    n1 = toks["input_ids"].shape[1] - 1
+    assert n1 == 2176
+    for b in range(2):
+        one = run(slice(b, b + 1), slice(8 * b, 8 * b + 8))
+        assert torch.equal(one["score1"], both["score1"][b:b + 1])
+        assert torch.equal(one["logit"], both["logit"][b * n1:(b + 1) * n1])
+    want = (toks["labels"][:, 1:] != -100).reshape(-1)
+    lg = both["logit"].cpu()
+    assert (lg[want] >= 0).all() and (lg[want] < cfg.llm_config.vocab_size).all() and (lg[~want] == -1).all()
+    assert torch.isfinite(both["score1"].float()).all() and (both["score1"].float() >= 0).all()      # ReLU head
+    dp = score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion)
+    assert torch.equal(dp["score1"], both["score1"]) and torch.equal(dp["logit"], both["logit"])

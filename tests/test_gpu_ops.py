@@ -142,6 +142,27 @@ def test_gemm_tile_kernels_agree(lib, mode, M, N, K, epi):
     ulp_check(dC, want, frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
+@pytest.mark.parametrize("M,N,K,epi,S", [(516, 512, 2048, 3, 2), (200, 256, 3072, 0, 3), (4, 1024, 4096, 4, 4), (300, 384, 1024, 2, 2),
+                                          (130, 256, 512, 1, 4)])
+def test_gemm_splitk_tail(lib, M, N, K, epi, S):
+    """Split-K tail path: fp32 slabs + fixed-order finalize with the same epilogues."""
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(BF)
+    W = (torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K))).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF) if epi in (0, 1, 2) else None
+    ls = (torch.rand(N, generator=g) + 0.5).to(BF) if epi == 2 else None
+    nout = N // 2 if epi == 4 else N
+    resid = torch.randn(M, nout, generator=g).to(BF) if epi in (2, 3) else None
+    want = gemm_ref(A, W, epi, bias, ls, resid)
+    dC = torch.full((M, nout), float("nan"), dtype=BF, device="cuda")
+    ws = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+    db, dl, dr = (dev(t) if t is not None else None for t in (bias, ls, resid))
+    sync(lib.aigv_op_gemm_splitk(ptr(dev(A)), K, ptr(dev(W)), K, ptr(dC), nout, ptr(db), ptr(dl), ptr(dr), nout, M, N, K, epi, S,
+                                 ptr(ws), None), lib)
+    ulp_check(dC, want, frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
+
+
 def test_gemm_identity_asymmetric(lib):
     """A = I with an asymmetric W catches a transposed C write (guide §3)."""
     from aigv_assessor_amd.native import ptr
