@@ -446,10 +446,12 @@ int g_gemm256_variant = 1;   // balanced reads + no s_setprio + LDS-staged epilo
 bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0 && a.M >= 1; }
 
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
+  // schedule variants kept for in-process A/B (scripts/gemm_bench.py, profiles/r1_gemm_variants.txt):
+  //   1 (default) balanced reads + no s_setprio + LDS-staged epilogue;  3: the same with the direct 8-B epilogue;
+  //   0: first schedule (12/4/8/0 reads, s_setprio pairs, direct epilogue)
   switch (g_gemm256_variant) {
-    case 0: return launch256v<0>(a, epi, s);   // first schedule (unbalanced reads, setprio)
-    case 1: return launch256v<7>(a, epi, s);   // balanced + no setprio + LDS-staged epilogue
-    case 2: return launch256v<4>(a, epi, s);   // first schedule + LDS-staged epilogue
-    default: return launch256v<3>(a, epi, s);  // balanced + no setprio, direct epilogue
+    case 0: return launch256v<0>(a, epi, s);
+    case 3: return launch256v<3>(a, epi, s);
+    default: return launch256v<7>(a, epi, s);
   }
 }

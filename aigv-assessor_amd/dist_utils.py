@@ -78,7 +78,7 @@ def even_split(n: int, world: int) -> List[Tuple[int, int]]:
 
 def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
     """All-gather along dim 0 with per-rank row counts (equal counts take the single-buffer fast path)."""
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local
     tail = tuple(local.shape[1:])

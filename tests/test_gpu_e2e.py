@@ -298,15 +298,31 @@ def test_full_size_8b_properties():
     def run(sl_c, sl_f):
         return model(pixel_values=pv[sl_f], input_ids=toks["input_ids"][sl_c], attention_mask=toks["attention_mask"][sl_c],
                      image_flags=flags[sl_f], labels=toks["labels"][sl_c], motion_feature=motion[sl_c])
+    from aigv_assessor_amd import native
+    lib = native.load()
     both = run(slice(0, 2), slice(0, 16))
     again = run(slice(0, 2), slice(0, 16))
     assert torch.equal(both["score1"], again["score1"]) and torch.equal(both["logit"], again["logit"])      # deterministic
     n1 = toks["input_ids"].shape[1] - 1
     assert n1 == 2176
+    # Batch invariance.  The default GEMM dispatch sends row ranges to different tile kernels (256 main / 128 + split-K or
+    # skinny tails) depending on M, and those sum over K in different orders, so a clip scored alone agrees with the batch
+    # only to bf16 noise (32 random-weight layers amplify a last-bit difference).  With ONE kernel for every row
+    # (aigv_tune_gemm mode 1) the per-row arithmetic is independent of the batch and the results must be bit-identical.
     for b in range(2):
         one = run(slice(b, b + 1), slice(8 * b, 8 * b + 8))
-        assert torch.equal(one["score1"], both["score1"][b:b + 1])
-        assert torch.equal(one["logit"], both["logit"][b * n1:(b + 1) * n1])
+        d = (one["score1"].float() - both["score1"][b:b + 1].float()).abs().item()
+        print(f"clip {b}: alone {one['score1'].item():.4f} vs in batch {both['score1'][b].item():.4f}")
+        assert d <= 0.06
+    native.check(lib.aigv_tune_gemm(1, 0.0))
+    try:
+        both1 = run(slice(0, 2), slice(0, 16))
+        for b in range(2):
+            one = run(slice(b, b + 1), slice(8 * b, 8 * b + 8))
+            assert torch.equal(one["score1"], both1["score1"][b:b + 1])
+            assert torch.equal(one["logit"], both1["logit"][b * n1:(b + 1) * n1])
+    finally:
+        native.check(lib.aigv_tune_gemm(0, 0.0))
     want = (toks["labels"][:, 1:] != -100).reshape(-1)
     lg = both["logit"].cpu()
     assert (lg[want] >= 0).all() and (lg[want] < cfg.llm_config.vocab_size).all() and (lg[~want] == -1).all()

@@ -114,7 +114,7 @@ def test_gemm_epilogues(lib, M, N, K, epi):
               atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
-@pytest.mark.parametrize("mode", [1, 2 + 16, 2 + 32, 2 + 48, 2 + 64, 0])
+@pytest.mark.parametrize("mode", [1, 2 + 16, 2 + 32, 2 + 64, 0])
 @pytest.mark.parametrize("M,N,K,epi", [(1100, 512, 448, 0), (777, 256, 64, 1), (515, 768, 1024, 2), (300, 256, 192, 3),
                                         (1029, 1024, 512, 4), (256, 256, 128, 0)])
 def test_gemm_tile_kernels_agree(lib, mode, M, N, K, epi):
