@@ -318,6 +318,7 @@ int need(aigv_ctx* c, const std::string& name, size_t elems, const bf16_t** out)
 }  // namespace
 
 extern int g_gemm256_variant;
+extern int g_attn_waves;
 
 // ==========================================================================================================
 extern "C" {
@@ -977,6 +978,12 @@ int aigv_op_frame_ingest(const void* hwc_u8, int n_frames, int height, int width
 }
 
 // ---- measurement -----------------------------------------------------------------------------------------------
+int aigv_tune_attention(int waves) {
+  if (waves != 0 && waves != 4 && waves != 8) return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_attention: waves must be 0, 4 or 8, got %d", waves);
+  g_attn_waves = waves;
+  return 0;
+}
+
 int aigv_tune_gemm(int mode, double rate256) {
   // mode = kernel choice (0 auto, 1 128-tile, 2 256-tile) + 16 * (256-kernel schedule variant 0..3, experiments)
   // mode bits 4..6: 0 = keep the default schedule, 1 + v = select 256-kernel schedule variant v (0..3)

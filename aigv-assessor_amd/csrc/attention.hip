@@ -26,7 +26,6 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-constexpr int QB = 128;   // query rows per workgroup
 constexpr int KT = 64;    // keys per tile
 
 template <int D> struct Lay;
@@ -43,15 +42,18 @@ template <> struct Lay<128> {
   __device__ static int vchunk(int row, int ch) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)); }
 };
 
-template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+// NW = waves per workgroup (32 query rows each).  More waves share one K/V tile: the LDS-DMA issue cost per wave and tile
+// (the dominant overhead next to the MFMAs) halves going from 4 to 8 waves.
+// NB = K/V ring depth: tile t is multiplied while tiles t+1 .. t+NB-2 are in flight behind a counted vmcnt.
+template <int D, bool CAUSAL, int NW, int NB>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) {
+  constexpr int QB = NW * 32;                // query rows per workgroup
   constexpr int ROWB = Lay<D>::ROWB;
   constexpr int CPR = D / 8;                 // 16-byte chunks per row
-  constexpr int NLD = KT * CPR / 256;        // chunks per thread per operand tile (2 for D=64, 4 for D=128)
   constexpr int NKS = D / 16;                // k-steps of the S^T product
   constexpr int NDT = D / 32;                // 32-row tiles of O^T
-  // two K/V buffers, filled by LDS-DMA (no staging registers, no ds_write pass): tile t+1 is in flight while tile t is used
-  __shared__ __attribute__((aligned(16))) char smem[4 * KT * ROWB];
+  // ring of NB K/V buffers filled by LDS-DMA (no staging registers, no ds_write pass)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -96,19 +98,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   // LDS-DMA staging: a wave-instruction writes 1 KB = RPI rows linearly, so the bank swizzles are applied to the per-lane
   // SOURCE chunk (the same XOR the fragment reads apply).  Keys past kv_len re-read the last valid row (masked later).
   constexpr int RPI = 1024 / ROWB;            // rows per wave-instruction (8 for D=64, 4 for D=128)
-  constexpr int IPW = KT / RPI / 4;           // wave-instructions per wave per operand (2 / 4)
+  constexpr int IPW = KT / RPI / NW;          // wave-instructions per wave per operand
   const int s_r = lane / CPR, s_c = lane % CPR;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
-  auto stage = [&](int kt, int buf) {
-    const unsigned dK = lds0 + buf * (2 * KT * ROWB), dV = dK + KT * ROWB;
+  // per-lane 32-bit source offsets inside a tile (loop invariant); the tile base advances as a scalar
+  unsigned koff[IPW], voff[IPW];
 #pragma unroll
-    for (int i = 0; i < IPW; ++i) {
-      const int ins = wave_u * IPW + i;
-      const int r = ins * RPI + s_r;
-      const int key = min(kt * KT + r, kv_len - 1);
-      glds16_asm(kbase + (size_t)key * p.ldk + Lay<D>::kchunk(r, s_c) * 8, dK + ins * 1024);
-      glds16_asm(vbase + (size_t)key * p.ldv + Lay<D>::vchunk(r, s_c) * 8, dV + ins * 1024);
+  for (int i = 0; i < IPW; ++i) {
+    const int r = (wave_u * IPW + i) * RPI + s_r;
+    koff[i] = (unsigned)r * (unsigned)p.ldk * 2u + Lay<D>::kchunk(r, s_c) * 16;
+    voff[i] = (unsigned)r * (unsigned)p.ldv * 2u + Lay<D>::vchunk(r, s_c) * 16;
+  }
+  auto stage = [&](int kt, int buf) {
+    const unsigned dK = lds0 + buf * (2 * KT * ROWB) + wave_u * IPW * 1024, dV = dK + KT * ROWB;
+    const char* kb = (const char*)(kbase + (size_t)kt * KT * p.ldk);
+    const char* vb = (const char*)(vbase + (size_t)kt * KT * p.ldv);
+    if (kt * KT + KT <= kv_len) {
+#pragma unroll
+      for (int i = 0; i < IPW; ++i) {
+        glds16_saddr(kb, koff[i], dK + i * 1024);
+        glds16_saddr(vb, voff[i], dV + i * 1024);
+      }
+    } else {          // ragged last tile: rows past kv_len re-read the last valid row
+#pragma unroll
+      for (int i = 0; i < IPW; ++i) {
+        const int r = (wave_u * IPW + i) * RPI + s_r;
+        const int rr = min(r, kv_len - 1 - kt * KT);
+        glds16_saddr(kb, (unsigned)rr * (unsigned)p.ldk * 2u + Lay<D>::kchunk(r, s_c) * 16, dK + i * 1024);
+        glds16_saddr(vb, (unsigned)rr * (unsigned)p.ldv * 2u + Lay<D>::vchunk(r, s_c) * 16, dV + i * 1024);
+      }
     }
   };
 
@@ -125,12 +144,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   const int tr_key = 4 * (gi >> 1) + (li >> 2);       // + 32*st + 16*s + 8*jh
   const int tr_dcol = 16 * (gi & 1) + 4 * (li & 3);   // + 32*dt
 
-  stage(0, 0);
+  // each wave issues 2*IPW LDS-DMA instructions per tile; nothing else in the loop touches vmcnt
+#pragma unroll
+  for (int t0 = 0; t0 < NB - 1; ++t0)
+    if (t0 < n_tiles) stage(t0, t0);
   for (int kt = 0; kt < n_tiles; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // tile kt landed for every wave; everyone is done reading the other buffer
-    if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-    const char* sK = smem + (kt & 1) * (2 * KT * ROWB);
+    // tile kt must have landed; up to NB-2 younger tiles may stay in flight
+    const int younger = min(NB - 2, n_tiles - 1 - kt);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * IPW) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile kt visible to every wave; everyone is done reading buffer (kt-1) % NB, which is refilled now
+    if (kt + NB - 1 < n_tiles) stage(kt + NB - 1, (kt + NB - 1) % NB);
+    const char* sK = smem + (kt % NB) * (2 * KT * ROWB);
     const char* sV = sK + KT * ROWB;
 
     const int key0 = kt * KT;
@@ -372,16 +398,34 @@ const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
   return nullptr;
 }
 
-hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
-  dim3 grid((a.max_len + QB - 1) / QB, a.n_heads, a.n_seq);
-  if (head_dim == 64) {
-    if (a.causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, s, a);
-  } else {
-    if (a.causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, s, a);
+int g_attn_waves = 0;   // 0 = per-shape default, 4 / 8 = forced (A/B experiments)
+
+template <int D, bool CAUSAL, int NW>
+static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
+  constexpr int NB = 2;   // measured: a 3-deep ring costs a resident workgroup per CU and loses to 2 buffers at higher occupancy
+  constexpr int LDS = NB * 2 * KT * (D * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, CAUSAL, NW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
   }
+  dim3 grid((a.max_len + NW * 32 - 1) / (NW * 32), a.n_heads, a.n_seq);
+  hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, NW, NB>), grid, dim3(NW * 64), LDS, s, a);
   return hipGetLastError();
+}
+
+hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
+  // 8 waves (256 query rows) when the sequences are long enough to fill such blocks; ViT's 1025-row frames waste less
+  // with 128-row blocks
+  // 4 waves (128 query rows) per workgroup; 8 only pay for one very long causal sequence (fewer, fatter K/V streams)
+  const int nw = g_attn_waves ? g_attn_waves : ((a.causal && a.max_len >= 4096) ? 8 : 4);
+  if (head_dim == 64) {
+    if (a.causal) return nw == 8 ? launch_attn<64, true, 8>(a, s) : launch_attn<64, true, 4>(a, s);
+    return nw == 8 ? launch_attn<64, false, 8>(a, s) : launch_attn<64, false, 4>(a, s);
+  }
+  if (a.causal) return nw == 8 ? launch_attn<128, true, 8>(a, s) : launch_attn<128, true, 4>(a, s);
+  return nw == 8 ? launch_attn<128, false, 8>(a, s) : launch_attn<128, false, 4>(a, s);
 }
 
 size_t aigv_attention_decode_ws_floats(int n_seq, int n_kv, int g, int cap) {

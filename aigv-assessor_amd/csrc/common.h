@@ -71,3 +71,20 @@ __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_wave_b
       : "v"(gsrc), "s"(lds_wave_base)
       : "memory");
 }
+
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (saddr form): one VGPR per
+// stream instead of a 64-bit address pair, and invisible to hipcc's vmcnt bookkeeping (the schedule counts by hand).
+// M0 (the LDS destination base) is written in the same statement that uses it and restored afterwards.
+__device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr)
+      : "memory");
+}
+

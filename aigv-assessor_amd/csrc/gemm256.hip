@@ -43,22 +43,6 @@ constexpr int GROUP_M256 = 4;
 
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (saddr form): one VGPR per
-// stream instead of a 64-bit address pair, and invisible to hipcc's vmcnt bookkeeping (the schedule counts by hand).
-// M0 (the LDS destination base) is written in the same statement that uses it and restored afterwards.
-__device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_addr)
-      : "memory");
-}
-
 __device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uniform
   if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");

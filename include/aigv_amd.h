@@ -141,6 +141,8 @@ int aigv_op_frame_ingest(const void* hwc_u8, int n_frames, int height, int width
 /* GEMM tile-kernel selection: mode 0 = cost model (default), 1 = always the 128x128 kernel, 2 = always the 256x256
  * phase-interleaved kernel where N % 256 == 0; rate256 > 0 overrides the model's relative throughput of the 256 kernel. */
 int aigv_tune_gemm(int mode, double rate256);
+/* Waves per prefill-attention workgroup: 0 = per-shape default, 4 or 8 = forced (32 query rows per wave). */
+int aigv_tune_attention(int waves);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* When enabled every GEMM / attention launch of the hot path is bracketed by HIP events on the launch stream. */
