@@ -19,6 +19,27 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(uint
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// The same GELU, x * 0.5 * (1 + erf(x / sqrt 2)), for the GEMM epilogues (VALU-bound there: libm erff is ~38 instructions
+// with both of its branches live in a wave, this is 15).  With a = min(|x|, 6):
+//   Phi(-a) = 2^-(1 + a R(a)),  R = degree-7 fit of (-log2 Phi(-a) - 1) / a on [0, 6]  (one polynomial, one v_exp_f32)
+//   erf(a / sqrt 2) = 1 - 2 Phi(-a), sign copied from x; the final (1 + erf) keeps the reference formula's cancellation
+// Checked over ALL bf16 inputs against torch's CPU bf16 GELU (tests/test_gpu_ops.py): identical bf16 results except for
+// a handful of last-place differences, the deep negative tail (x < -4, |gelu| < 3e-5, where the reference's own 1 + erf has
+// lost its digits) and outputs below the smallest normal.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float a = fminf(fabsf(x), 6.0f);
+  float r = 2.128495187e-07f;
+  r = fmaf(r, a, -3.116951266e-06f);
+  r = fmaf(r, a, -1.507227055e-05f);
+  r = fmaf(r, a, 7.047377466e-04f);
+  r = fmaf(r, a, -7.908032378e-03f);
+  r = fmaf(r, a, 5.311047467e-02f);
+  r = fmaf(r, a, 4.590370103e-01f);
+  r = fmaf(r, a, 1.151112778e+00f);
+  const float h = __builtin_amdgcn_exp2f(fmaf(-r, a, -1.0f));   // Phi(-a)
+  const float e = copysignf(fmaf(-2.0f, h, 1.0f), x);            // erf(x / sqrt 2)
+  return (x * 0.5f) * (1.0f + e);
+}
 // x * sigmoid(x) with hardware exp2 / rcp (about 3 ulp in fp32, i.e. ~2e-4 of the results round to the neighbouring
 // bf16 value relative to an exactly rounded evaluation - the same order as the vectorised CPU kernels' own exp error);
 // 6 VALU instructions instead of 27 for expf + IEEE division: the SwiGLU epilogue is VALU-bound

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);  // the Linear's bf16 output
         if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+          for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_fast(v[e]));
         }
         if constexpr (EPI == EPI_LS_RESID) {
           const u16x4 s = *(const u16x4*)(p.ls + n);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs p, co
       for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
       if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+        for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_fast(v[e]));
       }
       if constexpr (EPI == EPI_LS_RESID) {
         const u16x4 sc = *(const u16x4*)(p.ls + n);

@@ -38,7 +38,9 @@ namespace {
 constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int UNIT = 128 * 128;            // bytes per unit (128 rows x 64 bf16)
 constexpr int BUF = 4 * UNIT;              // one K-tile
-constexpr int LDS_BYTES = 2 * BUF;         // 128 KB
+constexpr int STAGE_ROWP = 144;            // residual epilogue: 16 staged rows x 144 B per wave, outside the K ring
+constexpr int STAGE_BYTES = 16 * STAGE_ROWP;
+constexpr int LDS_BYTES = 2 * BUF + 8 * STAGE_BYTES;   // 128 KB ring + 18 KB
 constexpr int GROUP_M256 = 4;
 
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
@@ -108,6 +110,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   auto issue = [&](int tile, int o) {
     if (tile >= nk) return;
     dma(tile, (o == 0) ? 0 : (o == 1) ? 2 : (o == 2) ? 3 : 1);
+  };
+
+  // ---- residual prefetch (EPI_RESID / EPI_LS_RESID with the staged epilogue) ----
+  // The wave's 128 x 64 residual sub-tile goes through LDS-DMA as two 8 KB halves (64 rows x 128 B, 16-B chunk XOR (row & 7)
+  // on the source side): half mh = 0 into the K buffer the last tile does not use, issued from that tile's phases 1 and 2
+  // (its units were last read >= 3 intervals earlier, the refill rule of the header); half mh = 1 into the last tile's own
+  // buffer once the K loop has drained.  The HBM latency of the residual is then hidden behind MFMA work / the first half.
+  constexpr bool RESID_PF = ((VAR & 4) != 0) && (EPI == EPI_RESID || EPI == EPI_LS_RESID);
+  const char* rtile = RESID_PF ? (const char*)(p.resid + (size_t)m0 * p.ldr + n0 + wc * 64) : nullptr;
+  auto resid_dma = [&](int mh, int i0, int cnt) {   // instructions i0 .. i0+cnt-1 of half mh (8 rows each)
+    const int buf = (mh == 0) ? ((nk - 1) & 1) ^ 1 : ((nk - 1) & 1);
+    const unsigned dst = (unsigned)(size_t)(LDS_AS char*)smem + buf * BUF + wave * 8192;
+#pragma unroll
+    for (int i = i0; i < i0 + cnt; ++i) {
+      const int r = i * 8 + lr;                                            // row inside the half
+      const int row = min(m0 + g * 128 + mh * 64 + r, p.M - 1) - m0;       // clamp: rows past M are never stored
+      glds16_saddr(rtile, (unsigned)row * (unsigned)p.ldr * 2u + (unsigned)(((lane & 7) ^ (r & 7)) * 16), dst + i * 1024);
+    }
   };
 
   // ---- fragment read offsets (bytes inside a unit) ----
@@ -199,22 +219,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     if constexpr (steady) dma(t + 1, 3); else issue(t + 1, 2);
     if constexpr (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_after(ph, ph + 2);
     PHASE_TAIL(I0)
+    // the last tile of a residual epilogue: the K stream has nothing left to issue; phases 1 and 2 issue the first residual half
+    // instead (4 LDS-DMA each).  The stream itself has fully landed after phase 1's wait (vmcnt(4) = only those 4 younger).
+    const bool last_r = RESID_PF && !steady && (t == nk - 1);
     // ---- j = 1 ----
     read_b1(sb);
     if constexpr (steady) dma(t + 1, 1); else issue(t + 1, 3);
-    if constexpr (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_after(ph + 1, ph + 3);
+    if constexpr (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (last_r) { resid_dma(0, 0, 4); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else wait_after(ph + 1, ph + 3);
     PHASE_TAIL(I1)
     // ---- j = 2 ----
     read_a(sb, 1);
     if constexpr (steady) dma(t + 2, 0); else issue(t + 2, 0);
     if constexpr (steady) { if constexpr (BAL) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (last_r) resid_dma(0, 4, 4);
     else wait_after(ph + 2, BAL ? ph + 5 : ph + 4);
     PHASE_TAIL(I2)
     // ---- j = 3 ----
     if constexpr (BAL) { if (steady || t + 1 < nk) read_b0(sbn, NSET{}); }
     if constexpr (steady) dma(t + 2, 2); else issue(t + 2, 1);
     if constexpr (steady) { if constexpr (!BAL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else wait_after(ph + 3, BAL ? ph + 4 : ph + 5);
+    else if (!last_r) wait_after(ph + 3, BAL ? ph + 4 : ph + 5);
     PHASE_TAIL(I3)
 #undef PHASE_TAIL
   };
@@ -239,6 +265,80 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   }
   if (g == 0) RAW_BARRIER();   // balance the stagger barrier
 
+  if constexpr (RESID_PF) {
+    // ---- residual epilogue: residual from LDS (prefetched), output staged 16 rows at a time in the wave's private region ----
+    // No compiler-visible global LOAD may appear here: hipcc would wait for it with a vmcnt that also drains the residual DMA
+    // still in flight.  The per-column bias / layer-scale vectors are therefore loaded by inline asm as well and tied to the wait.
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    // (the asm outputs are defined by exactly one asm statement each - no zero-init, no conditional: a phi would let the
+    //  compiler copy a register the load has not written yet)
+    u32x2 bcol[2][2], scol[2][2];
+    const bool has_bias = p.bias != nullptr;
+    const bf16_t* bvec = has_bias ? p.bias : p.W;   // without a bias: any readable address, the values are not used
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wc * 64 + nh * 32 + nt * 16 + fq * 4;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bcol[nh][nt]) : "v"(bvec + n) : "memory");
+        if constexpr (EPI == EPI_LS_RESID) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(scol[nh][nt]) : "v"(p.ls + n) : "memory");
+      }
+    resid_dma(1, 0, 8);
+    // everything older than the 8 DMA just issued has landed: bias, layer-scale, residual half 0
+    if constexpr (EPI == EPI_LS_RESID)
+      asm volatile("s_waitcnt vmcnt(8)"
+                   : "+v"(bcol[0][0]), "+v"(bcol[0][1]), "+v"(bcol[1][0]), "+v"(bcol[1][1]), "+v"(scol[0][0]), "+v"(scol[0][1]),
+                     "+v"(scol[1][0]), "+v"(scol[1][1])
+                   :
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(bcol[0][0]), "+v"(bcol[0][1]), "+v"(bcol[1][0]), "+v"(bcol[1][1]) : : "memory");
+    char* st = smem + 2 * BUF + wave * STAGE_BYTES;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      // half 1: its 8 DMA are older than the 8 stores of half 0, so at most 8 outstanding operations means they have landed
+      if (mh == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      const char* rl = smem + ((mh == 0) ? (((nk - 1) & 1) ^ 1) : ((nk - 1) & 1)) * BUF + wave * 8192;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int cl = nh * 32 + nt * 16 + fq * 4;
+            const int r = mt * 16 + fr;
+            const u16x4 rr = *(const u16x4*)(rl + r * 128 + (((cl >> 3) ^ (r & 7)) * 16) + (fq & 1) * 8);
+            const u16x4 b = __builtin_bit_cast(u16x4, bcol[nh][nt]);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[mh][mt][nh][nt][e];
+            if (has_bias) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+            if constexpr (EPI == EPI_LS_RESID) {
+              const u16x4 sc = __builtin_bit_cast(u16x4, scol[nh][nt]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] * bf2f(sc[e]));
+            }
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(rr[e]) + v[e]);
+            *(u16x4*)(st + fr * STAGE_ROWP + cl * 2) = o;
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = i * 8 + (lane >> 3), ch = lane & 7;
+          const int m = m0 + g * 128 + mh * 64 + mt * 16 + r;
+          const u16x8 val = *(const u16x8*)(st + r * STAGE_ROWP + ch * 16);
+          if (m < p.M) *(u16x8*)(p.C + (size_t)m * p.ldc + n0 + wc * 64 + ch * 8) = val;
+        }
+      }
+    }
+    return;
+  }
   if constexpr ((VAR & 4) != 0) {
     // ---- LDS-staged epilogue ------------------------------------------------------------------------------------
     // All DMA has landed (the tail waits reach vmcnt(0)) and every wave is past its last fragment read (final barriers), so
@@ -250,6 +350,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     constexpr int OC = (EPI == EPI_SWIGLU) ? 32 : 64;       // output columns per wave
     constexpr int CPR = OC / 8;                             // 16-B chunks per staged row
     char* st = smem + wave * (64 * ROWP);
+    // per-column operands depend on (nh, nt, fq) only: loaded once, not once per row block
+    u16x4 bcol[2][2], scol[2][2];
+    if constexpr (EPI != EPI_SWIGLU) {
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int n = n0 + wc * 64 + nh * 32 + nt * 16 + fq * 4;
+          bcol[nh][nt] = p.bias ? *(const u16x4*)(p.bias + n) : u16x4{0, 0, 0, 0};
+          if constexpr (EPI == EPI_LS_RESID) scol[nh][nt] = *(const u16x4*)(p.ls + n);
+        }
+    }
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
@@ -272,25 +384,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
               const int cl = nh * 32 + nt * 16 + fq * 4;       // column inside the wave's 64
-              const int n = n0 + wc * 64 + cl;
               float v[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = acc[mh][mt][nh][nt][e];
-              if (p.bias) {
-                const u16x4 b = *(const u16x4*)(p.bias + n);
+              if (p.bias) {   // wave-uniform
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+                for (int e = 0; e < 4; ++e) v[e] += bf2f(bcol[nh][nt][e]);
               }
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
               if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+                for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_fast(v[e]));
               }
               if constexpr (EPI == EPI_LS_RESID) {
-                const u16x4 sc = *(const u16x4*)(p.ls + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] * bf2f(sc[e]));
+                for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] * bf2f(scol[nh][nt][e]));
               }
               u16x4 o;
 #pragma unroll
@@ -371,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
             if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+              for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_fast(v[e]));
             }
             if constexpr (EPI == EPI_LS_RESID) {
               const u16x4 s = *(const u16x4*)(p.ls + n);

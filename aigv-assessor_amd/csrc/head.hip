@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
         for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
         if constexpr (EPI == SK_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+          for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_fast(v[e]));
         }
         if constexpr (EPI == SK_RELU) {
 #pragma unroll

@@ -163,6 +163,42 @@ def test_gemm_splitk_tail(lib, M, N, K, epi, S):
     ulp_check(dC, want, frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gelu_epilogue_over_all_bf16_inputs(lib, mode):
+    """The epilogue's GELU (one polynomial + one exp2 instead of libm erff) against torch's CPU bf16 GELU - the
+    reference's op (modeling_intern_vit.py:243 ACT2FN['gelu'], modeling_internvl_chat.py:85 nn.GELU) - on EVERY bf16
+    input: the GELU argument is a bf16 value, so this is the whole domain.  A one-hot W makes C = gelu(A) exactly.
+    Tolerance: identical bf16 results except <= 12 one-ulp differences for 2^-60 <= |x| <= 4 and x > 4; for
+    x < -4 (|gelu| < 1.3e-4, where the reference's own 1 + erf has cancelled to a few bits) 2^-17 absolute."""
+    from aigv_assessor_amd import native
+    from aigv_assessor_amd.native import ptr
+    bits = torch.arange(65536, dtype=torch.int32)
+    x = (bits << 16).view(torch.float32)
+    x = torch.where(torch.isfinite(x), x, torch.zeros_like(x)).to(BF)
+    A = x.reshape(1024, 64)
+    W = torch.zeros(256, 64)
+    W[torch.arange(64), torch.arange(64)] = 1.0
+    dC = torch.empty(1024, 256, dtype=BF, device="cuda")
+    native.check(lib.aigv_tune_gemm(mode, 0.0))
+    try:
+        sync(lib.aigv_op_gemm(ptr(dev(A)), 64, ptr(dev(W.to(BF))), 64, ptr(dC), 256, None, None, None, 0, None, 0, 1024, 256, 64, 1, None), lib)
+    finally:
+        native.check(lib.aigv_tune_gemm(0, 0.0))
+    got = dC.cpu()[:, :64].reshape(-1).float()
+    assert torch.equal(dC.cpu()[:, 64:].float(), torch.zeros(1024, 192))
+    want = torch.nn.functional.gelu(x).float()
+    xf = x.float()
+    main = ((xf.abs() >= 2.0 ** -60) & (xf >= -4.0) & (xf.abs() < 1e38)) | (xf == 0)
+    diff = (got - want).abs()
+    ulp = want.abs().clamp_min(1e-38).log2().floor().exp2() * 2.0 ** -7
+    assert int((diff[main] != 0).sum()) <= 12, int((diff[main] != 0).sum())
+    assert bool((diff[main] <= ulp[main]).all())
+    tail = (xf < -4.0) & torch.isfinite(xf)
+    assert float(diff[tail].max()) <= 2.0 ** -17
+    tiny = (xf.abs() < 2.0 ** -60) & (xf != 0)          # results far below bf16's useful range: 0.5 x either way or flushed
+    assert float(diff[tiny].max()) <= 2.0 ** -60
+
+
 def test_gemm_identity_asymmetric(lib):
     """A = I with an asymmetric W catches a transposed C write (guide §3)."""
     from aigv_assessor_amd.native import ptr
