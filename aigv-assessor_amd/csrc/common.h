@@ -48,6 +48,36 @@ __device__ __forceinline__ float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// ---- two-at-a-time forms for the GEMM epilogues (VALU-bound): gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at
+// the rate of their scalar forms, and v_cvt_pk_bf16_f32 rounds two values per instruction.  Per component these are the
+// same IEEE operations as the scalar helpers above - results are bit-identical to them.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf2(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t)); }
+__device__ __forceinline__ f32x2 unpack_bf2(uint32_t p) { return f32x2{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2 rbf2(f32x2 v) { return unpack_bf2(pack_bf2(v)); }
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  const f32x2 a = f32x2{fminf(fabsf(x.x), 6.0f), fminf(fabsf(x.y), 6.0f)};
+  f32x2 r = (f32x2)(2.128495187e-07f);
+  r = __builtin_elementwise_fma(r, a, (f32x2)(-3.116951266e-06f));
+  r = __builtin_elementwise_fma(r, a, (f32x2)(-1.507227055e-05f));
+  r = __builtin_elementwise_fma(r, a, (f32x2)(7.047377466e-04f));
+  r = __builtin_elementwise_fma(r, a, (f32x2)(-7.908032378e-03f));
+  r = __builtin_elementwise_fma(r, a, (f32x2)(5.311047467e-02f));
+  r = __builtin_elementwise_fma(r, a, (f32x2)(4.590370103e-01f));
+  r = __builtin_elementwise_fma(r, a, (f32x2)(1.151112778e+00f));
+  const f32x2 t = __builtin_elementwise_fma(-r, a, (f32x2)(-1.0f));
+  const f32x2 h = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  f32x2 e = __builtin_elementwise_fma((f32x2)(-2.0f), h, (f32x2)(1.0f));
+  e = f32x2{copysignf(e.x, x.x), copysignf(e.y, x.y)};
+  return (x * 0.5f) * (e + 1.0f);
+}
+__device__ __forceinline__ f32x2 silu2(f32x2 x) {
+  const f32x2 t = x * -1.4426950408889634f;
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+  return x * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -307,26 +307,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           for (int nt = 0; nt < 2; ++nt) {
             const int cl = nh * 32 + nt * 16 + fq * 4;
             const int r = mt * 16 + fr;
-            const u16x4 rr = *(const u16x4*)(rl + r * 128 + (((cl >> 3) ^ (r & 7)) * 16) + (fq & 1) * 8);
-            const u16x4 b = __builtin_bit_cast(u16x4, bcol[nh][nt]);
-            float v[4];
+            const u32x2 rr = *(const u32x2*)(rl + r * 128 + (((cl >> 3) ^ (r & 7)) * 16) + (fq & 1) * 8);
+            u32x2 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[mh][mt][nh][nt][e];
-            if (has_bias) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+            for (int h = 0; h < 2; ++h) {   // element pairs (0,1), (2,3): packed fp32 math, one cvt_pk per rounding point
+              f32x2 v = f32x2{acc[mh][mt][nh][nt][2 * h], acc[mh][mt][nh][nt][2 * h + 1]};
+              if (has_bias) v += unpack_bf2(bcol[nh][nt][h]);
+              v = rbf2(v);
+              if constexpr (EPI == EPI_LS_RESID) v = rbf2(v * unpack_bf2(scol[nh][nt][h]));
+              o[h] = pack_bf2(unpack_bf2(rr[h]) + v);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
-            if constexpr (EPI == EPI_LS_RESID) {
-              const u16x4 sc = __builtin_bit_cast(u16x4, scol[nh][nt]);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] * bf2f(sc[e]));
-            }
-            u16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(rr[e]) + v[e]);
-            *(u16x4*)(st + fr * STAGE_ROWP + cl * 2) = o;
+            *(u32x2*)(st + fr * STAGE_ROWP + cl * 2) = o;
           }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -338,8 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       }
     }
     return;
-  }
-  if constexpr ((VAR & 4) != 0) {
+  } else if constexpr ((VAR & 4) != 0) {
     // ---- LDS-staged epilogue ------------------------------------------------------------------------------------
     // All DMA has landed (the tail waits reach vmcnt(0)) and every wave is past its last fragment read (final barriers), so
     // the tile buffers are free.  Each wave owns 64 rows x 144 B of LDS (row padded by 16 B: ds_write_b64 of the MFMA layout
@@ -350,16 +340,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     constexpr int OC = (EPI == EPI_SWIGLU) ? 32 : 64;       // output columns per wave
     constexpr int CPR = OC / 8;                             // 16-B chunks per staged row
     char* st = smem + wave * (64 * ROWP);
-    // per-column operands depend on (nh, nt, fq) only: loaded once, not once per row block
-    u16x4 bcol[2][2], scol[2][2];
+    // per-column bias depends on (nh, nt, fq) only: loaded once, not once per row block.  (EPI_RESID / EPI_LS_RESID take the
+    // prefetching epilogue above when VAR has bit 2, so this path carries no layer-scale.)
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    static_assert(EPI != EPI_RESID && EPI != EPI_LS_RESID, "residual epilogues use the prefetching path");
+    u32x2 bcol[2][2];
     if constexpr (EPI != EPI_SWIGLU) {
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const int n = n0 + wc * 64 + nh * 32 + nt * 16 + fq * 4;
-          bcol[nh][nt] = p.bias ? *(const u16x4*)(p.bias + n) : u16x4{0, 0, 0, 0};
-          if constexpr (EPI == EPI_LS_RESID) scol[nh][nt] = *(const u16x4*)(p.ls + n);
+          bcol[nh][nt] = p.bias ? *(const u32x2*)(p.bias + n) : u32x2{0u, 0u};
         }
     }
 #pragma unroll
@@ -367,16 +359,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         char* rowp = st + (mt * 16 + fr) * ROWP;
+        // element pairs (0,1), (2,3): packed fp32 math, one v_cvt_pk_bf16_f32 per rounding point
         if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh) {
-            u16x4 o;
+            u32x2 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float gt = rbf(acc[mh][mt][nh][0][e]), up = rbf(acc[mh][mt][nh][1][e]);
-              o[e] = f2bf(rbf(silu_f(gt)) * up);
+            for (int h = 0; h < 2; ++h) {
+              const f32x2 gt = rbf2(f32x2{acc[mh][mt][nh][0][2 * h], acc[mh][mt][nh][0][2 * h + 1]});
+              const f32x2 up = rbf2(f32x2{acc[mh][mt][nh][1][2 * h], acc[mh][mt][nh][1][2 * h + 1]});
+              o[h] = pack_bf2(rbf2(silu2(gt)) * up);
             }
-            *(u16x4*)(rowp + (nh * 16 + fq * 4) * 2) = o;
+            *(u32x2*)(rowp + (nh * 16 + fq * 4) * 2) = o;
           }
         } else {
 #pragma unroll
@@ -384,27 +378,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
               const int cl = nh * 32 + nt * 16 + fq * 4;       // column inside the wave's 64
-              float v[4];
+              u32x2 o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[mh][mt][nh][nt][e];
-              if (p.bias) {   // wave-uniform
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bf2f(bcol[nh][nt][e]);
+              for (int h = 0; h < 2; ++h) {
+                f32x2 v = f32x2{acc[mh][mt][nh][nt][2 * h], acc[mh][mt][nh][nt][2 * h + 1]};
+                if (p.bias) v += unpack_bf2(bcol[nh][nt][h]);   // wave-uniform branch
+                if constexpr (EPI == EPI_GELU) v = gelu_fast2(rbf2(v));
+                o[h] = pack_bf2(v);
               }
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
-              if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_fast(v[e]));
-              }
-              if constexpr (EPI == EPI_LS_RESID) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] * bf2f(scol[nh][nt][e]));
-              }
-              u16x4 o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-              *(u16x4*)(rowp + cl * 2) = o;
+              *(u32x2*)(rowp + cl * 2) = o;
             }
         }
       }
@@ -418,11 +400,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         if (m < p.M) {
           const int n = (EPI == EPI_SWIGLU ? (n0 + wc * 64) / 2 : n0 + wc * 64) + ch * 8;
           size_t orow = (size_t)m;
-          if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) {
-            const u16x8 rr = *(const u16x8*)(p.resid + (size_t)m * p.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) val[e] = f2bf(bf2f(rr[e]) + bf2f(val[e]));
-          }
           if constexpr (EPI == EPI_PATCH) {
             const int f = m / p.np, pi = m - f * p.np;
             orow = (size_t)m + f + 1;
