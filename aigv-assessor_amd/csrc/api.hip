@@ -161,65 +161,60 @@ struct ProfScope {
   }
 };
 
-// ---- GEMM dispatch: pick the tile kernel by a wave-quantisation cost model ------------------------------------
+// ---- GEMM dispatch: split the rows over the tile kernels by a wave-quantisation cost model -----------------------
 // g_gemm_mode: 0 = auto, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel (where its shape rules allow)
 int g_gemm_mode = 0;
-double g_rate256 = 1.46;   // measured throughput of the 256 kernel relative to the 128 kernel at full occupancy
+// Model constants, microseconds on one MI355X (scripts/gemm_overhead.py: time vs K at fixed M, N):
+//   a full round of the 256 kernel (256 tiles, one per CU) takes nk * kt256 + fix256; a full round of the 128 kernel
+//   (512 tiles, two co-resident workgroups per CU) nk * KT128 + FIX128, a last round of <= 256 tiles LONE128 of that.
+double g_rate256 = 1.46;                 // throughput of the 256 kernel relative to the 128 kernel: kt256 = 2 * KT128 / rate
+constexpr double KT128 = 0.95, FIX128 = 6.0, LONE128 = 0.70, FIX256 = 9.0, LAUNCH_GAP = 2.0;
+double kt256() { return 2.0 * KT128 / g_rate256; }
 
-// Costs in units of "one full round of the 128x128 kernel" (512 tiles: 256 CUs x 2 co-resident workgroups).
-double g_lone128 = 0.70;   // a last round that fills at most one workgroup per CU runs faster per tile
-double cost128(int M, int N) {
-  if (M <= 0) return 0;
-  const long tiles = (long)((M + 127) / 128) * (N / 128);
-  const long full = tiles / 512, part = tiles % 512;
-  return (double)full + (part == 0 ? 0.0 : part <= 256 ? g_lone128 : 1.0);
+double t256(long row_tiles, int N, int nk) {
+  if (row_tiles <= 0) return 0;
+  const long tiles = row_tiles * (N / 256);
+  return (double)((tiles + 255) / 256) * (nk * kt256() + FIX256);
 }
-double cost256(int M, int N) {   // one workgroup per CU; a round = 256 tiles of 4x the work at g_rate256 x the speed
-  if (M <= 0) return 0;
-  const long tiles = (long)((M + 255) / 256) * (N / 256);
-  return (double)((tiles + 255) / 256) * 2.0 / g_rate256;
+double t128_blocks(long blocks, double nk_each) {
+  const double rt = nk_each * KT128 + FIX128;
+  const long full = blocks / 512, part = blocks % 512;
+  return full * rt + (part == 0 ? 0.0 : part <= 256 ? LONE128 * rt : rt);
 }
+double t128(int rows, int N, int nk) { return rows <= 0 ? 0 : t128_blocks((long)((rows + 127) / 128) * (N / 128), nk); }
+// slabs read once + the bf16 result (and residual) at ~3 TB/s, plus the launch
+double t_finalize(long rows, int N, int S) { return (double)rows * N * (4.0 * S + 4.0) / 3.0e6 + 3.0; }
 
-// fp32 scratch for split-K tails (one per process, grown on demand; tails are a few hundred rows)
+// fp32 scratch for split-K slices (one per process, grown on demand; one launch stream per process)
 float* g_splitk_ws = nullptr;
 size_t g_splitk_floats = 0;
-constexpr size_t SPLITK_MAX_FLOATS = (size_t)32 << 20;   // 128 MB
+constexpr size_t SPLITK_MAX_FLOATS = (size_t)64 << 20;   // 256 MB
+constexpr int SPLITS[] = {2, 3, 4, 6, 8};
 
-// a tail that fills at most one workgroup per CU is latency-bound on its K loop: split K over k_slices workgroups
-int tail_slices(const GemmArgs& a, int epi) {
-  if (epi == EPI_PATCH || g_gemm_mode != 0) return 1;
-  const long tiles = (long)((a.M + 127) / 128) * (a.N / 128);
-  const int nk = a.K / 64;
-  if (tiles > 256 || nk < 32) return 1;
-  int S = (int)(512 / tiles);
-  if (S > 4) S = 4;
-  while (S > 1 && (nk % S || (size_t)S * a.M * a.N > SPLITK_MAX_FLOATS)) --S;
-  return S;
-}
-
-int launch_tail128(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
-  const int S = tail_slices(a, epi);
-  if (S < 2) {
-    ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * a.M * (double)a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N), s);
-    HIPCHK(c, aigv_launch_gemm(a, epi, s));
-    return 0;
+// rows that do not fill whole rounds are latency-bound on their K loop: split K over S workgroups per tile (fp32 slabs +
+// a fixed-order finalize pass).  Best S for the 128 kernel / for `row_tiles` x 256 rows on the 256 kernel; S = 1: no split.
+double best_split128(int rows, int N, int nk, int epi, int* S_out) {
+  *S_out = 1;
+  double best = t128(rows, N, nk);
+  if (epi == EPI_PATCH) return best;
+  const long tiles = (long)((rows + 127) / 128) * (N / 128);
+  for (int S : SPLITS) {
+    if (nk % S || nk / S < 4 || (size_t)S * rows * N > SPLITK_MAX_FLOATS) continue;
+    const double t = t128_blocks(tiles * S, (double)nk / S) + t_finalize(rows, N, S) + LAUNCH_GAP;
+    if (t < best) { best = t; *S_out = S; }
   }
-  const size_t need = (size_t)S * a.M * a.N;
-  if (need > g_splitk_floats) {
-    if (g_splitk_ws) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(g_splitk_ws)); g_splitk_ws = nullptr; g_splitk_floats = 0; }
-    HIPCHK(c, hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
-    g_splitk_floats = need;
-  }
-  ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * a.M * (double)a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N), s);
-  HIPCHK(c, aigv_launch_gemm_splitk(a, epi, S, g_splitk_ws, s));
-  return 0;
+  return best;
 }
-
-int launch_one(aigv_ctx* c, const GemmArgs& a, int epi, bool use256, hipStream_t s) {
-  ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * a.M * (double)a.N * a.K,
-               2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N), s);
-  HIPCHK(c, use256 ? aigv_launch_gemm256(a, epi, s) : aigv_launch_gemm(a, epi, s));
-  return 0;
+double best_split256(long row_tiles, int N, int nk, int* S_out) {
+  *S_out = 0;
+  double best = 1e30;
+  for (int S : SPLITS) {
+    if (nk % S || nk / S < 4 || (size_t)S * row_tiles * 256 * N > SPLITK_MAX_FLOATS) continue;
+    const long blocks = row_tiles * (N / 256) * S;
+    const double t = (double)((blocks + 255) / 256) * ((double)nk / S * kt256() + FIX256) + t_finalize(row_tiles * 256, N, S) + LAUNCH_GAP;
+    if (t < best) { best = t; *S_out = S; }
+  }
+  return best;
 }
 
 int skinny_epi(int epi) {   // GEMM epilogue -> skinny-kernel epilogue (same rounding points); -1 if none
@@ -233,55 +228,102 @@ int skinny_epi(int epi) {   // GEMM epilogue -> skinny-kernel epilogue (same rou
   return -1;
 }
 // a <= 64-row remainder streamed through the skinny kernel costs ~ the weight bytes at HBM rate
-double cost_skinny(int rows, int N, int K) {
+double t_skinny(int rows, int N, int K) {
   if (rows <= 0) return 0;
   if (rows > 64 || K % 128) return 1e30;
-  return 0.15 + 3.0e-5 * N;
+  return (double)N * K * 2.0 / 4.5e6 + 4.0;
 }
 
-// The first R*256 rows go to the 256x256 kernel, the remaining rows to the 128x128 kernel or (<= 64 rows) to the
-// weight-streaming skinny kernel (rows are independent); R is chosen so that the big kernel runs whole rounds.
+#define GEMM_PROF(c, a, s) ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * (a).M * (double)(a).N * (a).K, \
+                                       2.0 * ((double)(a).M * (a).K + (double)(a).N * (a).K + (double)(a).M * (a).N), s)
+
+int launch_one(aigv_ctx* c, const GemmArgs& a, int epi, bool use256, hipStream_t s) {
+  GEMM_PROF(c, a, s);
+  HIPCHK(c, use256 ? aigv_launch_gemm256(a, epi, s) : aigv_launch_gemm(a, epi, s));
+  return 0;
+}
+
+int launch_splitk(aigv_ctx* c, const GemmArgs& a, int epi, int S, bool tile256, hipStream_t s) {
+  const size_t need = (size_t)S * a.M * a.N;
+  if (need > g_splitk_floats) {
+    if (g_splitk_ws) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(g_splitk_ws)); g_splitk_ws = nullptr; g_splitk_floats = 0; }
+    HIPCHK(c, hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
+    g_splitk_floats = need;
+  }
+  GEMM_PROF(c, a, s);
+  HIPCHK(c, aigv_launch_gemm_splitk(a, epi, S, g_splitk_ws, s, tile256));
+  return 0;
+}
+
+GemmArgs row_slice(const GemmArgs& a, int row0, int rows) {
+  GemmArgs b = a;
+  b.M = rows;
+  b.A = a.A + (size_t)row0 * a.lda;
+  b.C = a.C + (size_t)row0 * a.ldc;
+  if (a.resid) b.resid = a.resid + (size_t)row0 * a.ldr;
+  return b;
+}
+
+// Rows are independent, so the GEMM is cut into up to three row bands, each on the kernel that wastes least:
+//   top:  R x 256 rows on the 256x256 kernel, R chosen so that it runs whole rounds
+//   mid:  Q x 256 rows on the 256x256 kernel with split-K (a partial round made of K slices)
+//   last: the remaining rows on the weight-streaming skinny kernel (<= 64 rows) or the 128x128 kernel (plain or split-K)
 int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
   const bool ok256 = aigv_gemm256_supported(a);
   if (g_gemm_mode == 1 || !ok256) return launch_one(c, a, epi, false, s);
   if (g_gemm_mode == 2) return launch_one(c, a, epi, true, s);
-  const int sk = skinny_epi(epi);
-  double best = cost256(a.M, a.N);
-  int bestR = -1;                               // -1: everything (ragged last tile included) on the 256 kernel
-  bool rem_skinny = false;
-  if (epi != EPI_PATCH) {
-    for (int R = 0; R * 256 <= a.M; ++R) {
-      const int rem = a.M - R * 256;
-      const double c_main = cost256(R * 256, a.N) + ((R > 0 && rem > 0) ? 0.02 : 0.0);
-      const double c128 = c_main + cost128(rem, a.N);
-      const double csk = (sk >= 0 && R > 0) ? c_main + cost_skinny(rem, a.N, a.K) : 1e30;
-      if (c128 < best) { best = c128; bestR = R; rem_skinny = false; }
-      if (csk < best) { best = csk; bestR = R; rem_skinny = true; }
-    }
-  } else if (cost128(a.M, a.N) < best) {
-    bestR = 0;
+  const int nk = a.K / 64, sk = skinny_epi(epi);
+  const int full_tiles = a.M / 256;
+  // everything (a ragged last tile included) on the 256 kernel
+  double best = t256((a.M + 255) / 256, a.N, nk);
+  int bR = -1, bQ = 0, bS256 = 0, bS128 = 1, b_last = 0;   // b_last: 0 none, 1 skinny, 2 the 128 kernel
+  if (epi == EPI_PATCH) {
+    if (t128(a.M, a.N, nk) < best) return launch_one(c, a, epi, false, s);
+    return launch_one(c, a, epi, true, s);
   }
-  if (bestR < 0) return launch_one(c, a, epi, true, s);
-  if (bestR == 0) return launch_one(c, a, epi, false, s);
-  const int Mmain = bestR * 256;
-  GemmArgs top = a;
-  top.M = Mmain;
-  TRY(launch_one(c, top, epi, true, s));
-  if (Mmain < a.M) {
-    GemmArgs bot = a;
-    bot.M = a.M - Mmain;
-    bot.A = a.A + (size_t)Mmain * a.lda;
-    bot.C = a.C + (size_t)Mmain * a.ldc;
-    if (a.resid) bot.resid = a.resid + (size_t)Mmain * a.ldr;
-    if (rem_skinny) {
+  for (int R = 0; R <= full_tiles; ++R) {
+    for (int Q = 0; Q <= 8 && R + Q <= full_tiles; ++Q) {
+      const int rem = a.M - (R + Q) * 256;
+      int S256 = 0, S128 = 1, last = 0;
+      double t = t256(R, a.N, nk);
+      if (Q > 0) {
+        const double tm = best_split256(Q, a.N, nk, &S256);
+        if (!S256) continue;
+        t += tm;
+      }
+      if (rem > 0) {
+        const double tk = best_split128(rem, a.N, nk, epi, &S128);
+        const double ts = sk >= 0 ? t_skinny(rem, a.N, a.K) : 1e30;
+        last = ts < tk ? 1 : 2;
+        t += ts < tk ? ts : tk;
+      }
+      const int launches = (R > 0) + (Q > 0) + (rem > 0);
+      t += LAUNCH_GAP * (launches - 1);
+      if (t < best) { best = t; bR = R; bQ = Q; bS256 = S256; bS128 = S128; b_last = last; }
+    }
+  }
+  if (bR < 0) return launch_one(c, a, epi, true, s);
+  int row = 0;
+  if (bR > 0) {
+    TRY(launch_one(c, row_slice(a, 0, bR * 256), epi, true, s));
+    row = bR * 256;
+  }
+  if (bQ > 0) {
+    TRY(launch_splitk(c, row_slice(a, row, bQ * 256), epi, bS256, true, s));
+    row += bQ * 256;
+  }
+  if (row < a.M) {
+    const GemmArgs bot = row_slice(a, row, a.M - row);
+    if (b_last == 1) {
       ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * bot.M * (double)a.N * a.K, 2.0 * (double)a.N * a.K, s);
       hipError_t e = aigv_launch_skinny_gemm(bot.A, bot.lda, bot.M, bot.W, bot.ldw, bot.N, bot.K, bot.bias, bot.resid, bot.ldr,
                                             bot.C, bot.ldc, sk, s, bot.ls);
       if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "skinny remainder (M=%d N=%d K=%d): %s", bot.M, bot.N, bot.K, hipGetErrorString(e));
       return 0;
     }
-    return launch_tail128(c, bot, epi, s);
+    if (bS128 > 1) return launch_splitk(c, bot, epi, bS128, false, s);
+    return launch_one(c, bot, epi, false, s);
   }
   return 0;
 }
@@ -908,6 +950,16 @@ int aigv_op_gemm_splitk(const void* A, int lda, const void* W_, int ldw, void* C
   if (const char* m = aigv_gemm_check(a, epi)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   hipError_t e = aigv_launch_gemm_splitk(a, epi, k_slices, (float*)ws_f32, (hipStream_t)stream);
   if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "split-K gemm: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int aigv_op_gemm_splitk256(const void* A, int lda, const void* W_, int ldw, void* C, int ldc, const void* bias, const void* ls,
+                           const void* resid, int ldr, int M, int N, int K, int epi, int k_slices, void* ws_f32, void* stream) {
+  GemmArgs a = gemm_args((const bf16_t*)A, lda, (const bf16_t*)W_, ldw, (bf16_t*)C, ldc, M, N, K);
+  a.bias = (const bf16_t*)bias; a.ls = (const bf16_t*)ls; a.resid = (const bf16_t*)resid; a.ldr = ldr;
+  if (const char* m = aigv_gemm_check(a, epi)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
+  hipError_t e = aigv_launch_gemm_splitk(a, epi, k_slices, (float*)ws_f32, (hipStream_t)stream, true);
+  if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "split-K gemm (256 tile): %s", hipGetErrorString(e));
   return 0;
 }
 

@@ -283,8 +283,23 @@ const char* aigv_gemm_check(const GemmArgs& a, int epi) {
   return nullptr;
 }
 
-hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s) {
+hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s, bool tile256) {
   if (k_slices < 2 || (a.K / BK) % k_slices || !ws || epi == EPI_PATCH || epi >= EPI_COUNT) return hipErrorInvalidValue;
+  if (tile256) {
+    GemmArgs b = a;
+    b.part = ws;
+    b.k_slices = k_slices;
+    hipError_t e = aigv_launch_gemm256_partial(b, s);
+    if (e != hipSuccess) return e;
+    switch (epi) {
+      case EPI_STORE: launch_finalize<EPI_STORE>(a, ws, k_slices, s); break;
+      case EPI_GELU: launch_finalize<EPI_GELU>(a, ws, k_slices, s); break;
+      case EPI_LS_RESID: launch_finalize<EPI_LS_RESID>(a, ws, k_slices, s); break;
+      case EPI_RESID: launch_finalize<EPI_RESID>(a, ws, k_slices, s); break;
+      case EPI_SWIGLU: launch_finalize<EPI_SWIGLU>(a, ws, k_slices, s); break;
+    }
+    return hipGetLastError();
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -84,8 +84,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // unit row r -> tile row:  V0: (r>>6)*128 + (r&63)   V1: +64   V2: (r>>5)*64 + (r&31)   V3: +32
   const int lr = lane >> 3, lc = (lane & 7) ^ lr;
   // wave-uniform tile bases (SGPRs) + 32-bit per-lane byte offsets: global_load_lds saddr + voffset, no 64-bit VALU
-  const char* tileA = (const char*)(p.A + (size_t)m0 * p.lda);
-  const char* tileW = (const char*)(p.W + (size_t)n0 * p.ldw);
+  // split-K (EPI_PARTIAL): blockIdx.y picks the K slice
+  const int nk = (EPI == EPI_PARTIAL) ? p.K / TK / p.k_slices : p.K / TK;
+  const size_t kbase = (EPI == EPI_PARTIAL) ? (size_t)blockIdx.y * nk * TK : 0;
+  const char* tileA = (const char*)(p.A + (size_t)m0 * p.lda + kbase);
+  const char* tileW = (const char*)(p.W + (size_t)n0 * p.ldw + kbase);
   unsigned off[4][2];   // [unit][instr], at k = 0
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -96,7 +99,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     off[2][i] = (unsigned)rb0 * (unsigned)p.ldw * 2u + lc * 16;
     off[3][i] = (unsigned)(rb0 + 32) * (unsigned)p.ldw * 2u + lc * 16;
   }
-  const int nk = p.K / TK;
   const int n_units = 4 * nk;
   // one unit = two wave-instructions; `unit` and the LDS destination are compile-time / wave-uniform
   const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem + wave * 2048;
@@ -265,7 +267,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   }
   if (g == 0) RAW_BARRIER();   // balance the stagger barrier
 
-  if constexpr (RESID_PF) {
+  if constexpr (EPI == EPI_PARTIAL) {
+    // ---- split-K slice: fp32 partial sums into slab blockIdx.y ([M][N], the layout gemm_finalize_kernel sums) ----
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + g * 128 + mh * 64 + mt * 16 + fr;
+        if (m >= p.M) continue;
+        float* row = p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n0 + wc * 64 + fq * 4;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) *(f32x4*)(row + nh * 32 + nt * 16) = acc[mh][mt][nh][nt];
+      }
+    return;
+  } else if constexpr (RESID_PF) {
     // ---- residual epilogue: residual from LDS (prefetched), output staged 16 rows at a time in the wave's private region ----
     // No compiler-visible global LOAD may appear here: hipcc would wait for it with a vmcnt that also drains the residual DMA
     // still in flight.  The per-column bias / layer-scale vectors are therefore loaded by inline asm as well and tied to the wait.
@@ -514,6 +531,21 @@ hipError_t launch256v(const GemmArgs& a, int epi, hipStream_t s) {
 int g_gemm256_variant = 1;   // balanced reads + no s_setprio + LDS-staged epilogue: fastest in interleaved A/B (profiles/r1_gemm_variants.txt)
 
 bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0 && a.M >= 1; }
+
+// split-K slices of the 256 kernel: grid.y = a.k_slices workgroups per tile, each writes fp32 partial sums of its K range into
+// a.part[slice][M][N] (summed in slice order by gemm_finalize_kernel, gemm.hip)
+hipError_t aigv_launch_gemm256_partial(const GemmArgs& a, hipStream_t s) {
+  if (!aigv_gemm256_supported(a) || a.k_slices < 1 || (a.K / TK) % a.k_slices || !a.part) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_PARTIAL, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
+  hipLaunchKernelGGL((gemm256_kernel<EPI_PARTIAL, 7>), dim3(nbm * nbn, a.k_slices), dim3(512), LDS_BYTES, s, a);
+  return hipGetLastError();
+}
 
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
   // schedule variants kept for in-process A/B (scripts/gemm_bench.py, profiles/r1_gemm_variants.txt):

@@ -35,7 +35,9 @@ const char* aigv_gemm_check(const GemmArgs& a, int epi);   // nullptr if the sha
 hipError_t aigv_launch_gemm(const GemmArgs& a, int epi, hipStream_t s);           // 128x128 tile kernel (gemm.hip)
 // split-K for latency-bound tails: k_slices x the tiles of the 128 kernel write fp32 slabs, then one pass sums them in a
 // fixed order and applies epilogue `epi` (deterministic; ws holds k_slices*M*N floats)
-hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s);
+// (tile256: the slices come from the 256x256 kernel - needs N % 256 == 0)
+hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s, bool tile256 = false);
+hipError_t aigv_launch_gemm256_partial(const GemmArgs& a, hipStream_t s);   // a.part / a.k_slices filled in
 bool aigv_gemm256_supported(const GemmArgs& a);
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);        // 256x256 phase-interleaved kernel
 

@@ -114,6 +114,9 @@ int aigv_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ld
  * one pass sums them in slice order and applies the epilogue (epi 0..4) */
 int aigv_op_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
                         const void* resid, int ldr, int M, int N, int K, int epi, int k_slices, void* ws_f32, void* stream);
+/* the same with the slices computed by the 256x256 kernel (N % 256 == 0): whole row tiles that would not fill a round */
+int aigv_op_gemm_splitk256(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
+                           const void* resid, int ldr, int M, int N, int K, int epi, int k_slices, void* ws_f32, void* stream);
 int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W, int ldw, int N, int K, const void* bias,
                         const void* resid, int ldr, void* out, int ldo, int epi, void* stream);
 int aigv_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H,

@@ -143,9 +143,11 @@ def test_gemm_tile_kernels_agree(lib, mode, M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K,epi,S", [(516, 512, 2048, 3, 2), (200, 256, 3072, 0, 3), (4, 1024, 4096, 4, 4), (300, 384, 1024, 2, 2),
-                                          (130, 256, 512, 1, 4)])
+                                          (130, 256, 512, 1, 4), (512, 512, 2048, 3, -8), (768, 256, 1536, 0, -3), (300, 1024, 1024, 4, -2),
+                                          (256, 768, 4096, 2, -4), (513, 256, 768, 1, -6)])
 def test_gemm_splitk_tail(lib, M, N, K, epi, S):
-    """Split-K tail path: fp32 slabs + fixed-order finalize with the same epilogues."""
+    """Split-K tail path: fp32 slabs + fixed-order finalize with the same epilogues.  S < 0: |S| slices from the 256x256
+    kernel (whole row tiles that would not fill a round), S > 0: from the 128x128 kernel."""
     from aigv_assessor_amd.native import ptr
     g = torch.Generator().manual_seed(M + N + K + epi)
     A = (torch.randn(M, K, generator=g) * 0.5).to(BF)
@@ -156,10 +158,10 @@ def test_gemm_splitk_tail(lib, M, N, K, epi, S):
     resid = torch.randn(M, nout, generator=g).to(BF) if epi in (2, 3) else None
     want = gemm_ref(A, W, epi, bias, ls, resid)
     dC = torch.full((M, nout), float("nan"), dtype=BF, device="cuda")
-    ws = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+    ws = torch.empty(abs(S) * M * N, dtype=torch.float32, device="cuda")
     db, dl, dr = (dev(t) if t is not None else None for t in (bias, ls, resid))
-    sync(lib.aigv_op_gemm_splitk(ptr(dev(A)), K, ptr(dev(W)), K, ptr(dC), nout, ptr(db), ptr(dl), ptr(dr), nout, M, N, K, epi, S,
-                                 ptr(ws), None), lib)
+    op = lib.aigv_op_gemm_splitk if S > 0 else lib.aigv_op_gemm_splitk256
+    sync(op(ptr(dev(A)), K, ptr(dev(W)), K, ptr(dC), nout, ptr(db), ptr(dl), ptr(dr), nout, M, N, K, epi, abs(S), ptr(ws), None), lib)
     ulp_check(dC, want, frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
