@@ -268,61 +268,80 @@ GemmArgs row_slice(const GemmArgs& a, int row0, int rows) {
 //   top:  R x 256 rows on the 256x256 kernel, R chosen so that it runs whole rounds
 //   mid:  Q x 256 rows on the 256x256 kernel with split-K (a partial round made of K slices)
 //   last: the remaining rows on the weight-streaming skinny kernel (<= 64 rows) or the 128x128 kernel (plain or split-K)
-int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
-  if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
-  const bool ok256 = aigv_gemm256_supported(a);
-  if (g_gemm_mode == 1 || !ok256) return launch_one(c, a, epi, false, s);
-  if (g_gemm_mode == 2) return launch_one(c, a, epi, true, s);
-  const int nk = a.K / 64, sk = skinny_epi(epi);
-  const int full_tiles = a.M / 256;
-  // everything (a ragged last tile included) on the 256 kernel
-  double best = t256((a.M + 255) / 256, a.N, nk);
-  int bR = -1, bQ = 0, bS256 = 0, bS128 = 1, b_last = 0;   // b_last: 0 none, 1 skinny, 2 the 128 kernel
+struct GemmPlan {
+  int top_tiles = 0;      // R; -1: the whole problem (ragged last tile included) in one launch of the 256 kernel
+  int mid_tiles = 0;      // Q
+  int mid_slices = 0;     // split-K factor of the mid band
+  int last_rows = 0;
+  int last_kind = 0;      // 0 none, 1 skinny, 2 the 128 kernel
+  int last_slices = 1;    // split-K factor of the last band on the 128 kernel (1: plain)
+  double est_us = 0;
+};
+
+GemmPlan plan_gemm(int M, int N, int K, int epi) {
+  GemmPlan pl;
+  const int nk = K / 64, sk = skinny_epi(epi);
+  const bool ok256 = (N % 256 == 0);
+  if (g_gemm_mode == 1 || !ok256) { pl.last_rows = M; pl.last_kind = 2; pl.est_us = t128(M, N, nk); return pl; }
+  pl.top_tiles = -1;
+  pl.est_us = t256((M + 255) / 256, N, nk);
+  if (g_gemm_mode == 2) return pl;
   if (epi == EPI_PATCH) {
-    if (t128(a.M, a.N, nk) < best) return launch_one(c, a, epi, false, s);
-    return launch_one(c, a, epi, true, s);
+    if (t128(M, N, nk) < pl.est_us) { pl = GemmPlan(); pl.last_rows = M; pl.last_kind = 2; pl.est_us = t128(M, N, nk); }
+    return pl;
   }
+  const int full_tiles = M / 256;
   for (int R = 0; R <= full_tiles; ++R) {
     for (int Q = 0; Q <= 8 && R + Q <= full_tiles; ++Q) {
-      const int rem = a.M - (R + Q) * 256;
+      const int rem = M - (R + Q) * 256;
       int S256 = 0, S128 = 1, last = 0;
-      double t = t256(R, a.N, nk);
+      double t = t256(R, N, nk);
       if (Q > 0) {
-        const double tm = best_split256(Q, a.N, nk, &S256);
+        const double tm = best_split256(Q, N, nk, &S256);
         if (!S256) continue;
         t += tm;
       }
       if (rem > 0) {
-        const double tk = best_split128(rem, a.N, nk, epi, &S128);
-        const double ts = sk >= 0 ? t_skinny(rem, a.N, a.K) : 1e30;
+        const double tk = best_split128(rem, N, nk, epi, &S128);
+        const double ts = sk >= 0 ? t_skinny(rem, N, K) : 1e30;
         last = ts < tk ? 1 : 2;
+        if (last == 1) S128 = 1;
         t += ts < tk ? ts : tk;
       }
-      const int launches = (R > 0) + (Q > 0) + (rem > 0);
-      t += LAUNCH_GAP * (launches - 1);
-      if (t < best) { best = t; bR = R; bQ = Q; bS256 = S256; bS128 = S128; b_last = last; }
+      t += LAUNCH_GAP * ((R > 0) + (Q > 0) + (rem > 0) - 1);
+      if (t < pl.est_us) {
+        pl.est_us = t; pl.top_tiles = R; pl.mid_tiles = Q; pl.mid_slices = S256; pl.last_rows = rem; pl.last_kind = last;
+        pl.last_slices = S128;
+      }
     }
   }
-  if (bR < 0) return launch_one(c, a, epi, true, s);
+  return pl;
+}
+
+int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
+  if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
+  const GemmPlan pl = plan_gemm(a.M, a.N, a.K, epi);
+  if (pl.top_tiles < 0) return launch_one(c, a, epi, true, s);
   int row = 0;
-  if (bR > 0) {
-    TRY(launch_one(c, row_slice(a, 0, bR * 256), epi, true, s));
-    row = bR * 256;
+  if (pl.top_tiles > 0) {
+    TRY(launch_one(c, row_slice(a, 0, pl.top_tiles * 256), epi, true, s));
+    row = pl.top_tiles * 256;
   }
-  if (bQ > 0) {
-    TRY(launch_splitk(c, row_slice(a, row, bQ * 256), epi, bS256, true, s));
-    row += bQ * 256;
+  if (pl.mid_tiles > 0) {
+    TRY(launch_splitk(c, row_slice(a, row, pl.mid_tiles * 256), epi, pl.mid_slices, true, s));
+    row += pl.mid_tiles * 256;
   }
   if (row < a.M) {
     const GemmArgs bot = row_slice(a, row, a.M - row);
-    if (b_last == 1) {
+    if (pl.last_kind == 1) {
+      const int sk = skinny_epi(epi);
       ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * bot.M * (double)a.N * a.K, 2.0 * (double)a.N * a.K, s);
       hipError_t e = aigv_launch_skinny_gemm(bot.A, bot.lda, bot.M, bot.W, bot.ldw, bot.N, bot.K, bot.bias, bot.resid, bot.ldr,
                                             bot.C, bot.ldc, sk, s, bot.ls);
       if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "skinny remainder (M=%d N=%d K=%d): %s", bot.M, bot.N, bot.K, hipGetErrorString(e));
       return 0;
     }
-    if (bS128 > 1) return launch_splitk(c, bot, epi, bS128, false, s);
+    if (pl.last_slices > 1) return launch_splitk(c, bot, epi, pl.last_slices, false, s);
     return launch_one(c, bot, epi, false, s);
   }
   return 0;
@@ -1030,6 +1049,16 @@ int aigv_op_frame_ingest(const void* hwc_u8, int n_frames, int height, int width
 }
 
 // ---- measurement -----------------------------------------------------------------------------------------------
+int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us) {
+  if (!plan || M <= 0 || N <= 0 || K <= 0 || N % 128 || K % 64 || epi < 0 || epi >= EPI_COUNT)
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_plan_gemm: bad problem M=%d N=%d K=%d epi=%d", M, N, K, epi);
+  const GemmPlan pl = plan_gemm(M, N, K, epi);
+  plan[0] = pl.top_tiles; plan[1] = pl.mid_tiles; plan[2] = pl.mid_slices; plan[3] = pl.last_rows; plan[4] = pl.last_kind;
+  plan[5] = pl.last_slices;
+  if (est_us) *est_us = pl.est_us;
+  return 0;
+}
+
 int aigv_tune_attention(int waves) {
   if (waves != 0 && waves != 4 && waves != 8) return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_attention: waves must be 0, 4 or 8, got %d", waves);
   g_attn_waves = waves;

@@ -48,6 +48,49 @@ def test_no_cpu_fallback_and_loud_errors(built):
             model.extract_feature(torch.zeros(1, 3, 224, 224))
 
 
+def test_gemm_row_band_planner(built):
+    """Host logic of the GEMM dispatch (no GPU): the bands cover every row exactly once, split factors divide the K-tile
+    count, forced modes are honoured, and the headline LLM shapes get whole rounds on the 256 kernel."""
+    lib = native.load()
+
+    def plan(M, N, K, epi):
+        p, est = (ctypes.c_int * 6)(), ctypes.c_double()
+        native.check(lib.aigv_plan_gemm(M, N, K, epi, p, ctypes.byref(est)))
+        return list(p), est.value
+
+    shapes = [(8708, 28672, 4096, 4), (8708, 4096, 14336, 3), (8708, 4096, 4096, 3), (8708, 6144, 4096, 0), (32800, 3072, 1024, 0),
+              (32800, 4096, 1024, 1), (32800, 1024, 4096, 2), (2177, 4096, 14336, 3), (1, 128, 64, 0), (300, 256, 128, 1), (515, 384, 1024, 2),
+              (4354, 6144, 6144, 0), (8192, 4096, 4096, 5), (70, 512, 192, 4)]
+    for M, N, K, epi in shapes:
+        (top, mid, ms, last, kind, ls), est = plan(M, N, K, epi)
+        assert est > 0
+        if top < 0:
+            assert N % 256 == 0 and (mid, last, kind) == (0, 0, 0)
+            continue
+        assert top * 256 + mid * 256 + last == M, (M, N, K, top, mid, last)
+        assert (kind == 0) == (last == 0)
+        if top or mid:
+            assert N % 256 == 0
+        if mid:
+            assert ms >= 2 and (K // 64) % ms == 0
+        if kind == 1:
+            assert last <= 64 and ls == 1 and epi != 5
+        if ls > 1:
+            assert kind == 2 and (K // 64) % ls == 0 and epi != 5
+    # 4 clips x 2177 tokens: the 256 kernel runs whole rounds of 256 tiles (w2: 32 row tiles x 16 = 2 rounds, the next 2 row tiles
+    # as one round of 8 K slices), never the 2.125-round launch
+    (top, mid, ms, last, kind, ls), _ = plan(8708, 4096, 14336, 3)
+    assert (top * 16) % 256 == 0 and mid * 16 * ms <= 256 and top + mid == 34
+    try:
+        native.check(lib.aigv_tune_gemm(1, 0.0))
+        assert plan(8708, 4096, 4096, 3)[0] == [0, 0, 0, 8708, 2, 1]
+        native.check(lib.aigv_tune_gemm(2, 0.0))
+        assert plan(8708, 4096, 4096, 3)[0][0] == -1
+    finally:
+        native.check(lib.aigv_tune_gemm(0, 0.0))
+    assert lib.aigv_plan_gemm(100, 100, 64, 0, (ctypes.c_int * 6)(), None) != 0      # N % 128
+
+
 def test_product_path_never_imports_the_oracle():
     for root, _, files in os.walk(os.path.join(ROOT, "aigv-assessor_amd")):
         for f in files:
