@@ -57,13 +57,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const int seq = blockIdx.z, hq = blockIdx.y;
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs, so the linear id is remapped (bijectively) to
+  // give each XCD a contiguous run of (sequence, head, query block) - the query blocks of one head, and the heads of one GQA
+  // group, then stream the same K/V through ONE L2 instead of eight.
+  const int nqb = (p.max_len + QB - 1) / QB;
+  int v;
+  {
+    const int total = (int)gridDim.x, bid = blockIdx.x, xcd = bid & 7, q8 = total >> 3, r8 = total & 7;
+    v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  }
+  const int qb = v % nqb, hq = (v / nqb) % p.n_heads, seq = v / (nqb * p.n_heads);
   const int g = p.n_heads / p.n_kv_heads;
   const int hk = hq / g;
   const int row0 = p.cu[seq];
   const int len = p.cu[seq + 1] - row0;          // queries (= keys appended this call)
   // causal work grows with the query block index: launch the heaviest blocks first
-  const int q0 = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * QB;
+  const int q0 = (CAUSAL ? nqb - 1 - qb : qb) * QB;
   if (q0 >= len) return;
   const int kv_len = len + p.kv_len_offset;       // keys visible in total (prefill: offset 0)
   const int qw = q0 + wave * 32;                  // first query row of this wave
@@ -160,8 +169,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     const char* sV = sK + KT * ROWB;
 
     const int key0 = kt * KT;
-    // wave-uniform skip of tiles that are entirely in this wave's causal future
+    // wave-uniform skips: tiles entirely in this wave's causal future; waves whose 32 query rows all lie past the sequence
+    // (1025 = 8 x 128 + 1 rows per ViT frame: three of the last workgroup's four waves).  Such a wave still stages its share
+    // of every tile and joins the barriers, but leaves its SIMD's issue slots to the co-resident workgroups.
     if (CAUSAL && key0 > qw + 31 + p.kv_len_offset) continue;
+    if (qw >= len) continue;
 
     // ---- S^T = K · Q^T -------------------------------------------------------------------------
     f32x16 sacc[2];
@@ -202,7 +214,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    if (__any(m_new != m_run)) {
+    // Lazy rescale: the running reference m_run only moves when some row's maximum has grown by more than 2^8 in the exp2
+    // domain (a new row maximum turns up in almost every tile, a jump of 8 octaves almost never after the first).  Until
+    // then p = exp2((s - m_run) * c) may exceed 1 (< 2^8): harmless in fp32 / bf16, and the final division by l uses the
+    // same reference, so the result is the same softmax.  (NaN-safe: -inf - -inf compares false -> no move, mc = 0.)
+    if (__any((m_new - m_run) * sc > 8.0f)) {
       // rows with no visible key yet keep m = -inf; guard the exp argument (m_run = -inf -> alpha = 0)
       const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m_run - m_new) * sc);
       l_run *= alpha;
@@ -212,16 +228,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
         for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
       m_run = m_new;
     }
-    const float mc = (m_new == -INFINITY) ? 0.f : m_new * sc;
-    float psum = 0.f;
+    const float mc = (m_run == -INFINITY) ? 0.f : m_run * sc;
+    // element pairs: one v_pk_fma_f32 and one v_pk_add_f32 per two scores (the loop is VALU-issue-bound: SQ counters in
+    // profiles/r1_attn_sq.txt); raw v_exp_f32: p underflows to 0, no fix-up needed
+    f32x2 psum2 = f32x2{0.f, 0.f};
+    const f32x2 sc2 = f32x2{sc, sc}, nmc2 = f32x2{-mc, -mc};
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], sc, -mc));   // raw v_exp_f32: p underflows to 0, no fix-up needed
-        psum += pv;
-        sacc[st][e] = pv;
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2 t = __builtin_elementwise_fma(f32x2{sacc[st][e], sacc[st][e + 1]}, sc2, nmc2);
+        const f32x2 pv = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        psum2 += pv;
+        sacc[st][e] = pv.x;
+        sacc[st][e + 1] = pv.y;
       }
+    float psum = psum2.x + psum2.y;
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
 
@@ -410,8 +432,8 @@ static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid((a.max_len + NW * 32 - 1) / (NW * 32), a.n_heads, a.n_seq);
-  hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, NW, NB>), grid, dim3(NW * 64), LDS, s, a);
+  const int nqb = (a.max_len + NW * 32 - 1) / (NW * 32);
+  hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, NW, NB>), dim3(nqb * a.n_heads * a.n_seq), dim3(NW * 64), LDS, s, a);
   return hipGetLastError();
 }
 

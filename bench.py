@@ -93,6 +93,31 @@ def cpu_baseline(cfg, T, N, budget_s=30.0):
     }
 
 
+def device_calibration(dev):
+    """One fixed launch (8192^3 bf16 GEMM, this library's 256x256 kernel, plain store) timed after the run: MI355X devices
+    of this pool differ by up to ~12 % on identical MFMA-bound binaries (MI355X_MICROARCH.md, DVFS give-back item 5), so
+    numbers from different boxes are only comparable next to this figure.  Not part of `value`."""
+    from aigv_assessor_amd import native
+    from aigv_assessor_amd.native import ptr
+    lib = native.load()
+    n = 8192
+    A = (torch.randn(n, n, device=dev) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(n, n, device=dev) / 90.0).to(torch.bfloat16)
+    C = torch.empty(n, n, dtype=torch.bfloat16, device=dev)
+    call = lambda: native.check(lib.aigv_op_gemm(ptr(A), n, ptr(W), n, ptr(C), n, None, None, None, 0, None, 0, n, n, n, 0, None))
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    return {"gemm_8192_cubed_tflops": 2.0 * n ** 3 / (ms * 1e-3) / 1e12, "ms": ms,
+            "note": "same binary on other boxes of the pool: 1460-1680 TFLOP/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +248,8 @@ def main():
                     "other_kernels_ms_per_step": {k: p[k]["ms"] / args.steps for k in ("attn_vit", "attn_llm", "skinny")},
                     "attn_tflops": {k: (p[k]["flops"] / (p[k]["ms"] * 1e-3) / 1e12 if p[k]["ms"] else None) for k in ("attn_vit", "attn_llm")},
                 }
+        if prof:
+            line["device_calibration"] = device_calibration(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, T, N)
             line["gpu_over_cpu"] = clips_per_s / line["cpu_baseline"]["value"]

@@ -1,10 +1,11 @@
+"""Attention microbenchmark on the headline shapes: python scripts/attn_bench.py"""
 import math, sys, torch
 sys.path.insert(0, '.')
 from aigv_assessor_amd import native
 from aigv_assessor_amd.native import ptr
 lib = native.load()
 BF = torch.bfloat16
-def run(name, d, causal, h, hk, lens, iters=20, dbg=0):
+def run(name, d, causal, h, hk, lens, iters=60):
     T = sum(lens); g = h // hk
     ld = hk * (g + 2) * d
     qkv = torch.randn(T, ld, device='cuda').to(BF)
@@ -13,7 +14,7 @@ def run(name, d, causal, h, hk, lens, iters=20, dbg=0):
     base = qkv.data_ptr()
     pre = d ** -0.5 if not causal else 1.0
     post = 1.0 if not causal else math.sqrt(d)
-    call = lambda: native.check(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(cu), len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal) | dbg, post, pre, None))
+    call = lambda: native.check(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(cu), len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal), post, pre, None))
     for _ in range(3): call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -22,11 +23,8 @@ def run(name, d, causal, h, hk, lens, iters=20, dbg=0):
     us = e0.elapsed_time(e1) / iters * 1e3
     fl = sum(4.0 * (L * (L + 1) / 2 if causal else L * L) * d * h for L in lens)
     print(f"{name}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s", flush=True)
-for rep in range(2):
-    for nw in (4, 8):
-        native.check(lib.aigv_tune_attention(nw))
-        run(f"nw={nw} vit  d64  32x1025 h16", 64, False, 16, 16, [1025] * 32)
-        run(f"nw={nw} vit  d64  32x1024 h16", 64, False, 16, 16, [1024] * 32)
-        run(f"nw={nw} llm  d128 4x2177 h32/8", 128, True, 32, 8, [2177] * 4)
-        run(f"nw={nw} llm  d128 1x4281 h32/8", 128, True, 32, 8, [4281])
-native.check(lib.aigv_tune_attention(0))
+for rep in range(3):
+    run("vit  d64  32x1025 h16", 64, False, 16, 16, [1025] * 32)
+    run("vit  d64  32x1024 h16", 64, False, 16, 16, [1024] * 32)
+    run("llm  d128 4x2177 h32/8", 128, True, 32, 8, [2177] * 4)
+    run("llm  d128 1x4281 h32/8", 128, True, 32, 8, [4281])
