@@ -422,9 +422,10 @@ const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
 
 int g_attn_waves = 0;   // 0 = per-shape default, 4 / 8 = forced (A/B experiments)
 
-template <int D, bool CAUSAL, int NW>
+// NB = 2: deeper rings (3, 4 buffers) measured 5-15 % slower on the ViT shape - they cost resident workgroups (LDS), and
+// with four workgroups per CU the wait for the next tile is already covered by the others' work
+template <int D, bool CAUSAL, int NW, int NB = 2>
 static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
-  constexpr int NB = 2;   // measured: a 3-deep ring costs a resident workgroup per CU and loses to 2 buffers at higher occupancy
   constexpr int LDS = NB * 2 * KT * (D * 2);
   static bool attr_set = false;
   if (!attr_set) {
@@ -438,10 +439,10 @@ static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
 }
 
 hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
-  // 8 waves (256 query rows) when the sequences are long enough to fill such blocks; ViT's 1025-row frames waste less
-  // with 128-row blocks
-  // 4 waves (128 query rows) per workgroup; 8 only pay for one very long causal sequence (fewer, fatter K/V streams)
-  const int nw = g_attn_waves ? g_attn_waves : ((a.causal && a.max_len >= 4096) ? 8 : 4);
+  // 4 waves (128 query rows) per workgroup.  With the XCD-aware block order the K/V stream of a head is shared in L2, and
+  // 8-wave workgroups (half the K/V reads, half the resident workgroups) measured equal or slower on every headline shape
+  // (scripts/attn_bench.py with AB_WAVES=1); the 8-wave form stays reachable through aigv_tune_attention for such A/Bs.
+  const int nw = g_attn_waves ? g_attn_waves : 4;
   if (head_dim == 64) {
     if (a.causal) return nw == 8 ? launch_attn<64, true, 8>(a, s) : launch_attn<64, true, 4>(a, s);
     return nw == 8 ? launch_attn<64, false, 8>(a, s) : launch_attn<64, false, 4>(a, s);

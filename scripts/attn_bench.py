@@ -23,8 +23,13 @@ def run(name, d, causal, h, hk, lens, iters=60):
     us = e0.elapsed_time(e1) / iters * 1e3
     fl = sum(4.0 * (L * (L + 1) / 2 if causal else L * L) * d * h for L in lens)
     print(f"{name}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s", flush=True)
+import os
 for rep in range(3):
+  for nw in ((0,) if not os.environ.get("AB_WAVES") else (4, 8)):
+    native.check(lib.aigv_tune_attention(nw))
+    print(f"-- waves per workgroup: {nw or 'default'}")
     run("vit  d64  32x1025 h16", 64, False, 16, 16, [1025] * 32)
     run("vit  d64  32x1024 h16", 64, False, 16, 16, [1024] * 32)
     run("llm  d128 4x2177 h32/8", 128, True, 32, 8, [2177] * 4)
     run("llm  d128 1x4281 h32/8", 128, True, 32, 8, [4281])
+native.check(lib.aigv_tune_attention(0))
