@@ -64,6 +64,8 @@ struct aigv_ctx {
   bf16_t *l_h = nullptr, *l_t = nullptr, *l_qkv = nullptr, *l_ao = nullptr, *l_ffn = nullptr, *l_rows = nullptr;
   int32_t *l_pos = nullptr, *l_seq = nullptr, *l_cu = nullptr, *l_rowidx = nullptr, *l_kvlen = nullptr;
   unsigned long long* l_packed = nullptr;
+  bool trim_last_layer = true;
+  bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 3 (attention out, hidden, normed) + [64, I]
   bf16_t* l_score_ws = nullptr;
   bf16_t *kc = nullptr, *vc = nullptr;   // [layer][seq][kv head][cap][D]
   float* dec_ws = nullptr;
@@ -456,6 +458,7 @@ int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out) {
     if ((rc = dalloc(c, &c->l_rowidx, (size_t)k.max_out_rows + k.max_seqs + 64))) break;
     if ((rc = dalloc(c, &c->l_kvlen, (size_t)k.max_seqs))) break;
     if ((rc = dalloc(c, &c->l_packed, (size_t)64))) break;
+    if ((rc = dalloc(c, &c->l_trim, (size_t)64 * (3 * k.llm_hidden + k.llm_inter)))) break;
     {
       int maxd = k.llm_hidden;
       for (int i = 0; i < k.n_score_layers; ++i) maxd = std::max(maxd, (int)k.score_dims[i]);
@@ -795,22 +798,29 @@ int aigv_motion_project(aigv_ctx* c, const void* motion_feature, int n_clips, vo
 }
 
 // ---- InternLM2 -----------------------------------------------------------------------------------------------
-static int final_rows(aigv_ctx* c, const int32_t* score_rows, float* score, int B, const int32_t* logit_rows, int R,
-                      int64_t* argmax, const bf16_t* hidden, int total_rows, hipStream_t s) {
+// rows whose final hidden state is consumed: [score rows (one per clip) | logit rows], validated and uploaded to l_rowidx
+static int upload_out_rows(aigv_ctx* c, const int32_t* score_rows, bool with_score, int B, const int32_t* logit_rows, int R,
+                           int total_rows, hipStream_t s) {
   const aigv_config& k = c->cfg;
-  const int H = k.llm_hidden;
-  const int nS = score ? B : 0;
   if (R > k.max_out_rows) return fail(c, AIGV_ERR_ARG, "%d logit rows exceed max_out_rows %d", R, k.max_out_rows);
   c->h_rowidx.clear();
-  for (int i = 0; i < nS; ++i) c->h_rowidx.push_back(score_rows[i]);
+  for (int i = 0; i < (with_score ? B : 0); ++i) c->h_rowidx.push_back(score_rows[i]);
   for (int i = 0; i < R; ++i) c->h_rowidx.push_back(logit_rows[i]);
   for (int v : c->h_rowidx)
     if (v < 0 || v >= total_rows) return fail(c, AIGV_ERR_ARG, "output row index %d outside 0..%d", v, total_rows - 1);
-  const int n = (int)c->h_rowidx.size();
+  if (!c->h_rowidx.empty()) HIPCHK(c, aigv_launch_write_ints(c->h_rowidx.data(), (int)c->h_rowidx.size(), c->l_rowidx, s));
+  return 0;
+}
+
+// final RMSNorm + heads on the consumed rows.  compact: `hidden` already holds exactly those rows, in l_rowidx order.
+static int final_rows(aigv_ctx* c, float* score, int B, int R, int64_t* argmax, const bf16_t* hidden, bool compact, hipStream_t s) {
+  const aigv_config& k = c->cfg;
+  const int H = k.llm_hidden;
+  const int nS = score ? B : 0;
+  const int n = nS + R;
   if (n == 0) return 0;
-  HIPCHK(c, aigv_launch_write_ints(c->h_rowidx.data(), n, c->l_rowidx, s));
   // final RMSNorm only on the rows that are consumed (modeling_internlm2.py:984)
-  HIPCHK(c, aigv_launch_rmsnorm(hidden, H, c->final_norm, c->l_rows, H, n, H, k.rms_eps, c->l_rowidx, s));
+  HIPCHK(c, aigv_launch_rmsnorm(hidden, H, c->final_norm, c->l_rows, H, n, H, k.rms_eps, compact ? nullptr : c->l_rowidx, s));
   for (int b0 = 0; b0 < nS; b0 += 64) {
     // NB: the reference's NaN guard looks at the whole batch slice; batches above 64 clips are guarded per 64
     ScoreHeadArgs a = c->score;
@@ -856,6 +866,19 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
   HIPCHK(c, aigv_launch_seqpos(cu, B, c->l_pos, c->l_seq, c->l_cu, T, s));
 
   HIPCHK(c, aigv_launch_embed(ids, slot, c->tok_emb, (const bf16_t*)vis, (const bf16_t*)motion, n_vis, c->l_h, T, H, s));
+  TRY(upload_out_rows(c, score_rows, score != nullptr, B, logit_rows, R, T, s));
+  // Row trimming: after the last layer's attention every row is independent, and only the consumed rows (one score row per
+  // clip + the answer rows) are read afterwards (stage2_eval.py:940-941; modeling_internvl_chat.py:469-481).  When they are
+  // few, the last layer finishes just those rows: attention for the query blocks that contain them, then wo / MLP on a
+  // compact copy through the weight-streaming skinny kernel.  K/V of the last layer still cover every row (keep_kv).
+  const int n_out = (int)c->h_rowidx.size();
+  int q_tail = 0;
+  for (int v : c->h_rowidx) {
+    int b = 0;
+    while (cu[b + 1] <= v) ++b;
+    q_tail = std::max(q_tail, cu[b + 1] - v);
+  }
+  const bool trim = c->trim_last_layer && n_out > 0 && n_out <= 64 && H % 128 == 0 && I % 128 == 0;
   double attn_flops = 0;
   for (int b = 0; b < B; ++b) { const double L = cu[b + 1] - cu[b]; attn_flops += 4.0 * (L * (L + 1) / 2) * D * k.llm_heads; }
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
@@ -876,9 +899,22 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       a.n_heads = k.llm_heads; a.n_kv_heads = nkv;
       a.q_group_stride = a.kv_head_stride = (g + 2) * D;
       a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
+      const bool last_trim = trim && li == k.llm_layers - 1;
+      a.q_tail = last_trim ? q_tail : 0;
       if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
-      ProfScope ps(c, AIGV_PROF_ATTN_LLM, attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
+      ProfScope ps(c, AIGV_PROF_ATTN_LLM, last_trim ? 0.0 : attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
       HIPCHK(c, aigv_launch_attention(a, D, s));
+    }
+    if (trim && li == k.llm_layers - 1) {
+      bf16_t *t_ao = c->l_trim, *t_h = t_ao + (size_t)64 * H, *t_n = t_h + (size_t)64 * H, *t_ffn = t_n + (size_t)64 * H;
+      HIPCHK(c, aigv_launch_gather_rows(c->l_ao, H, c->l_rowidx, n_out, t_ao, H, s));
+      HIPCHK(c, aigv_launch_gather_rows(c->l_h, H, c->l_rowidx, n_out, t_h, H, s));
+      TRY(run_skinny(c, t_ao, H, n_out, L.wo, H, H, H, nullptr, t_h, H, t_h, H, 1, s));
+      HIPCHK(c, aigv_launch_rmsnorm(t_h, H, L.fn, t_n, H, n_out, H, k.rms_eps, nullptr, s));
+      TRY(run_skinny(c, t_n, H, n_out, L.w13, H, 2 * I, H, nullptr, nullptr, 0, t_ffn, I, 2, s));
+      TRY(run_skinny(c, t_ffn, I, n_out, L.w2, I, H, I, nullptr, t_h, H, t_h, H, 1, s));
+      TRY(final_rows(c, score, B, R, argmax, t_h, true, s));
+      break;
     }
     {
       GemmArgs a = gemm_args(c->l_ao, H, L.wo, H, c->l_h, H, T, H, H);
@@ -893,7 +929,7 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       TRY(run_gemm(c, a, EPI_RESID, s));
     }
   }
-  TRY(final_rows(c, score_rows, score, B, logit_rows, R, argmax, c->l_h, T, s));
+  if (!trim) TRY(final_rows(c, score, B, R, argmax, c->l_h, false, s));
   if (keep_kv) {
     c->h_kvlen.resize(B);
     c->h_dec.resize((size_t)4 * B);   // pos | seq | visible kv length | slot, uploaded once; advanced on the device
@@ -911,6 +947,12 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
   } else {
     c->kv_valid = false;
   }
+  return 0;
+}
+
+int aigv_set_row_trimming(aigv_ctx* c, int on) {
+  if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_row_trimming: null context");
+  c->trim_last_layer = on != 0;
   return 0;
 }
 

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
   // causal work grows with the query block index: launch the heaviest blocks first
   const int q0 = (CAUSAL ? nqb - 1 - qb : qb) * QB;
   if (q0 >= len) return;
+  if (p.q_tail > 0 && q0 + QB <= len - p.q_tail) return;   // this block's rows are not consumed (last-layer row trimming)
   const int kv_len = len + p.kv_len_offset;       // keys visible in total (prefill: offset 0)
   const int qw = q0 + wave * 32;                  // first query row of this wave
 
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     // (1025 = 8 x 128 + 1 rows per ViT frame: three of the last workgroup's four waves).  Such a wave still stages its share
     // of every tile and joins the barriers, but leaves its SIMD's issue slots to the co-resident workgroups.
     if (CAUSAL && key0 > qw + 31 + p.kv_len_offset) continue;
-    if (qw >= len) continue;
+    if (qw >= len || (p.q_tail > 0 && qw + 32 <= len - p.q_tail)) continue;
 
     // ---- S^T = K · Q^T -------------------------------------------------------------------------
     f32x16 sacc[2];

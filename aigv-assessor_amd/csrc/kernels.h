@@ -59,6 +59,7 @@ struct AttnArgs {
   int causal;
   float post_div;               // score = bf16(bf16(q.k) / post_div)  (LLM: sqrt(d); ViT: 1, q is pre-scaled)
   float q_prescale;             // q <- bf16(q * q_prescale)           (ViT: d^-1/2; LLM: 1)
+  int q_tail;                   // > 0: only the last q_tail query rows of every sequence are computed (others left unwritten)
 };
 const char* aigv_attn_check(const AttnArgs& a, int head_dim);
 hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s);
@@ -82,6 +83,7 @@ hipError_t aigv_launch_pixel_shuffle(const bf16_t* vit, int grid, int Hv, bf16_t
 // im2col for the patch-embed GEMM: frames NCHW bf16 -> [F*g*g, Kp] (k = c*P*P + py*P + px, zero padded)
 hipError_t aigv_launch_im2col(const bf16_t* frames, int F, int C, int S, int P, int Kp, bf16_t* out, hipStream_t s);
 // x[f*(np+1)] = cls_pos (class token + its position row, precomputed) for every frame
+hipError_t aigv_launch_gather_rows(const bf16_t* src, int ld, const int32_t* idx, int n, bf16_t* dst, int H, hipStream_t s);
 hipError_t aigv_launch_cls_rows(const bf16_t* cls_pos, bf16_t* x, int F, int tokens_per_frame, int H, hipStream_t s);
 // RoPE in place on the fused qkv rows: per kv group, slots 0..g (q heads and K) are rotated.
 hipError_t aigv_launch_rope(bf16_t* qkv, int ld, const int32_t* pos, const bf16_t* cos, const bf16_t* sin,

@@ -161,6 +161,14 @@ __global__ void cls_rows_kernel(const bf16_t* __restrict__ cls_pos, bf16_t* __re
     *(u16x8*)(x + (size_t)f * tokens_per_frame * H + (c << 3)) = *(const u16x8*)(cls_pos + (c << 3));
 }
 
+// dst[i, :] = src[idx[i], :]  (compact copies of the few rows the last decoder layer still has to finish)
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ src, int ld, const int32_t* __restrict__ idx,
+                                   bf16_t* __restrict__ dst, int H) {
+  const int i = blockIdx.x;
+  const bf16_t* row = src + (size_t)idx[i] * ld;
+  for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x) *(u16x8*)(dst + (size_t)i * H + (c << 3)) = *(const u16x8*)(row + (c << 3));
+}
+
 // ---- RoPE in place (modeling_internlm2.py:247-261): out = bf16(bf16(x*cos) + bf16(rot(x)*sin)) ---------
 // qkv row layout: n_groups x slots_per_group x D; slots [0, n_rot) of every group are rotated (q heads + K).
 // cos/sin tables are [max_pos, D/2] bf16 (the second half of the reference's table repeats the first).
@@ -307,6 +315,13 @@ hipError_t aigv_launch_im2col(const bf16_t* frames, int F, int C, int S, int P, 
 hipError_t aigv_launch_cls_rows(const bf16_t* cls_pos, bf16_t* x, int F, int tokens_per_frame, int H, hipStream_t s) {
   if (F <= 0) return hipSuccess;
   hipLaunchKernelGGL(cls_rows_kernel, dim3(F), dim3(128), 0, s, cls_pos, x, tokens_per_frame, H);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_gather_rows(const bf16_t* src, int ld, const int32_t* idx, int n, bf16_t* dst, int H, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (H % 8 || ld % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, s, src, ld, idx, dst, H);
   return hipGetLastError();
 }
 

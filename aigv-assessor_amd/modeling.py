@@ -683,6 +683,13 @@ class InternVLChatModel(nn.Module):
         responses = tokenizer.batch_decode(out, skip_special_tokens=True)
         return [r.split(template.sep)[0].strip() for r in responses]
 
+    def set_row_trimming(self, on: bool = True):
+        """Last-layer row trimming (default on): the last decoder layer finishes only the rows whose hidden state is
+        consumed (score row + answer rows; stage2_eval.py:940-941, modeling_internvl_chat.py:469-481).  Off = every row
+        through every layer, as the reference computes it; the returned values are the same."""
+        lib, ctx = self._native()
+        native.check(lib.aigv_set_row_trimming(ctx, int(on)), ctx)
+
     # ---- measurement ---------------------------------------------------------------------------------------
     def prof_enable(self, on: bool = True):
         lib, ctx = self._native()

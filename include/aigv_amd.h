@@ -102,6 +102,12 @@ int aigv_motion_project(aigv_ctx* ctx, const void* motion_feature, int n_clips, 
 int aigv_llm_prefill(aigv_ctx* ctx, const int64_t* ids, const int32_t* slot, const int32_t* cu_seqlens, int n_clips,
                      const void* vis, int n_vis, const void* motion, const int32_t* score_rows, float* score,
                      const int32_t* logit_rows, int n_logit_rows, int64_t* argmax, int keep_kv, void* stream);
+/* Last-layer row trimming in aigv_llm_prefill (default on): when at most 64 rows are consumed (score rows + logit rows), the
+ * last decoder layer computes attention only for the query blocks holding them and finishes wo / MLP / final norm on a compact
+ * copy of those rows.  Rows are independent after attention, so the outputs are those of the untrimmed pass (up to the fp32
+ * summation order of the kernel that runs the few rows); off = every row through every layer, as the reference does. */
+int aigv_set_row_trimming(aigv_ctx* ctx, int on);
+
 /* One greedy decode step for every clip of the last keep_kv prefill (generate(): modeling_internvl_chat.py:769-811,
  * modeling_internlm2.py:1126-1163).  ids[B] int64 device (the previous tokens) -> next[B] int64 device. */
 int aigv_decode_step(aigv_ctx* ctx, const int64_t* ids, int64_t* next, void* stream);

@@ -118,6 +118,27 @@ def test_stage2_448_cls_tail_and_batch_invariance():
         assert torch.equal(o1["score1"], out["score1"][b:b + 1])
 
 
+def test_last_layer_row_trimming_is_output_equivalent():
+    """The trimmed last layer (only the consumed rows are finished, on the skinny kernel) returns what the full pass
+    returns: identical level tokens, scores within one bf16 ulp (fp32 summation order of a different kernel)."""
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    model, sd, toks, pv, motion, ref, out = run_case(cfg, B=3, T=2, seed=21)
+    check_levels(out, ref)
+    score_ok(out["score1"], ref["score1"])
+    model.set_row_trimming(False)
+    try:
+        full = model(mos=None, pixel_values=pv, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+                     image_flags=torch.ones(pv.shape[0], 1, dtype=torch.long), labels=toks["labels"], motion_feature=motion)
+    finally:
+        model.set_row_trimming(True)
+    check_levels(full, ref)
+    want = ref["label"] != -100
+    n_diff = int((full["logit"].cpu()[want] != out["logit"].cpu()[want]).sum())
+    assert n_diff <= 1, n_diff                      # a tie inside rounding noise may flip between the two kernels
+    d = (full["score1"].float() - out["score1"].float()).abs().cpu()
+    assert bool((d <= 2.0 ** -7 * full["score1"].float().abs().cpu().clamp_min(0.5)).all()), d
+
+
 def test_stage1_and_ragged_padded_batch():
     cfg = pkg.tiny(image_size=224, vit_layers=1)
     seed = 9
