@@ -1090,6 +1090,18 @@ int aigv_op_frame_ingest(const void* hwc_u8, int n_frames, int height, int width
   return 0;
 }
 
+int aigv_op_frame_resize_ingest(const void* hwc_u8, int n_frames, int in_h, int in_w, int out_h, int out_w, const float* mean,
+                                const float* stdv, void* tmp_u8, void* out_u8_hwc, void* out_nchw, void* stream) {
+  if (!hwc_u8 || !tmp_u8 || (!out_u8_hwc && !out_nchw) || n_frames < 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 ||
+      (out_nchw && (!mean || !stdv)))
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_op_frame_resize_ingest: bad argument (frames %d, %dx%d -> %dx%d)", n_frames, in_h, in_w, out_h, out_w);
+  if (in_h > 16384 || in_w > 16384 || out_h > 16384 || out_w > 16384)
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_op_frame_resize_ingest: sizes above 16384 are not supported");
+  HIPCHK(nullptr, aigv_launch_frame_resize_ingest((const uint8_t*)hwc_u8, n_frames, in_h, in_w, out_h, out_w, mean, stdv,
+                                                  (uint8_t*)tmp_u8, (uint8_t*)out_u8_hwc, (bf16_t*)out_nchw, (hipStream_t)stream));
+  return 0;
+}
+
 // ---- measurement -----------------------------------------------------------------------------------------------
 int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us) {
   if (!plan || M <= 0 || N <= 0 || K <= 0 || N % 128 || K % 64 || epi < 0 || epi >= EPI_COUNT)

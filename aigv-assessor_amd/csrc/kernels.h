@@ -115,6 +115,11 @@ hipError_t aigv_launch_kv_store(const bf16_t* qkv, int ld, const int32_t* seq_of
 // frame ingest: uint8 HWC RGB -> (u/255 - mean)/std -> bf16 NCHW (torchvision ToTensor + Normalize + bf16 cast)
 hipError_t aigv_launch_frame_ingest(const uint8_t* hwc, int n_frames, int H, int W, const float* mean, const float* stdv,
                                     bf16_t* out, hipStream_t s);
+// uint8 HWC frames at any resolution -> Pillow-exact BICUBIC resize -> uint8 HWC (out_u8, may be null) and / or normalised
+// bf16 NCHW (out_nchw, may be null); tmp_u8 holds the horizontal pass: n_frames * in_h * out_w * 3 bytes
+hipError_t aigv_launch_frame_resize_ingest(const uint8_t* hwc, int n_frames, int in_h, int in_w, int out_h, int out_w,
+                                           const float* mean, const float* stdv, uint8_t* tmp_u8, uint8_t* out_u8, bf16_t* out_nchw,
+                                           hipStream_t s);
 // a[i] += 1, b[i] += 1 for i < n (decode bookkeeping kept on the device: positions and visible KV lengths)
 hipError_t aigv_launch_advance(int32_t* a, int32_t* b, int n, hipStream_t s);
 // small host int arrays passed by value as kernel arguments (no memcpy, no implicit host/stream sync)

@@ -330,19 +330,28 @@ class InternVLChatModel(nn.Module):
             pass
 
     # ---- hot path -----------------------------------------------------------------------------------------
-    def ingest_frames(self, frames_u8: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> torch.Tensor:
-        """uint8 [F, S, S, 3] RGB frames (already resized on the host) -> normalised bf16 NCHW ``pixel_values`` on the
-        GPU: the ToTensor + Normalize + bf16 cast of the reference's eval transform (dataset.py:267-274, stage2_eval.py:932)."""
+    def ingest_frames(self, frames_u8: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+                      size: Optional[int] = None) -> torch.Tensor:
+        """uint8 [F, H, W, 3] RGB frames -> normalised bf16 NCHW ``pixel_values`` on the GPU: the reference's per-frame
+        ``image.resize((448, 448))`` (PIL BICUBIC; dataset.py:702-738 with max_num = 1, stage2_eval.py:453-456) when the
+        frames are not at the model resolution yet, then ToTensor + Normalize + the bf16 cast of its eval transform
+        (dataset.py:267-274, stage2_eval.py:932).  The resize is bit-exact with Pillow (include/aigv_amd.h)."""
         if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
             raise ValueError("frames must be uint8 [F, H, W, 3]")
         lib = native.load()
         if self.device.type != "cuda":
             raise native.NativeError("the scorer hot path runs on an MI355X only (no CPU fallback)")
+        S = int(size or self.config.image_size)
         f = frames_u8.to(self.device).contiguous()
         n, h, w, _ = f.shape
-        out = torch.empty((n, 3, h, w), dtype=torch.bfloat16, device=self.device)
+        out = torch.empty((n, 3, S, S), dtype=torch.bfloat16, device=self.device)
         m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
-        native.check(lib.aigv_op_frame_ingest(f.data_ptr(), n, h, w, m3, s3, out.data_ptr(), native.stream_ptr()))
+        if (h, w) == (S, S):
+            native.check(lib.aigv_op_frame_ingest(f.data_ptr(), n, h, w, m3, s3, out.data_ptr(), native.stream_ptr()))
+        else:
+            tmp = torch.empty(n * h * S * 3, dtype=torch.uint8, device=self.device)
+            native.check(lib.aigv_op_frame_resize_ingest(f.data_ptr(), n, h, w, S, S, m3, s3, tmp.data_ptr(), None, out.data_ptr(),
+                                                         native.stream_ptr()))
         return out
 
     def vit_tokens(self, pixel_values: torch.Tensor) -> torch.Tensor:

@@ -147,6 +147,16 @@ int aigv_op_lm_head_argmax(const void* h, int rows, int hidden, const void* W, i
 int aigv_op_frame_ingest(const void* hwc_u8, int n_frames, int height, int width, const float* mean, const float* stdv,
                          void* out_nchw, void* stream);
 
+/* Frame resize + ingest: uint8 [F,in_h,in_w,3] RGB frames at the video's resolution -> Pillow's BICUBIC
+ * `Image.resize((out_w, out_h))` (the reference's dynamic_preprocess tile, internvl/train/dataset.py:702-738 with max_num = 1;
+ * stage2_eval.py:453-456), bit-exact with Pillow's 8-bit ImagingResample (22-bit fixed-point coefficients, horizontal pass
+ * stored as uint8, then the vertical pass) -> uint8 [F,out_h,out_w,3] in out_u8_hwc (may be NULL) and / or the normalised bf16
+ * NCHW pixel_values of aigv_op_frame_ingest in out_nchw (may be NULL).  tmp_u8: DEVICE scratch of F*in_h*out_w*3 bytes.
+ * Coefficient tables are computed on the host (double precision, as Pillow does) and cached on the device per size pair; the
+ * first call for a size pair synchronises on their upload.  mean/std: HOST float[3]. */
+int aigv_op_frame_resize_ingest(const void* hwc_u8, int n_frames, int in_h, int in_w, int out_h, int out_w, const float* mean,
+                                const float* stdv, void* tmp_u8, void* out_u8_hwc, void* out_nchw, void* stream);
+
 /* GEMM tile-kernel selection: mode 0 = cost model (default), 1 = always the 128x128 kernel, 2 = always the 256x256
  * phase-interleaved kernel where N % 256 == 0; rate256 > 0 overrides the model's relative throughput of the 256 kernel. */
 int aigv_tune_gemm(int mode, double rate256);

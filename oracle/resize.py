@@ -1,0 +1,110 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement of the frame resize of the reference's eval transform.
+
+The reference resizes every sampled frame with PIL: ``dynamic_preprocess(..., max_num=1, use_thumbnail=True)`` produces one
+``image.resize((448, 448))`` tile (internvl/train/dataset.py:702-738, stage2_eval.py:453-456) and ``build_transform`` applies
+``T.Resize((448, 448), interpolation=BICUBIC)`` to that PIL image (dataset.py:267-274) — an identity once the tile is 448².
+``Image.resize`` defaults to BICUBIC for RGB images, so the arithmetic on the path is Pillow's ``ImagingResample`` for 8-bit
+images (third-party dependency: Pillow, ``src/libImaging/Resample.c``; the reference pins no version, this container has
+12.2.0).  Restated here from the published algorithm:
+
+  per axis  scale = in / out, filterscale = max(scale, 1), support = 2 * filterscale (bicubic, a = -0.5),
+            ksize = ceil(support) * 2 + 1; for output index i: center = (i + 0.5) * scale,
+            xmin = max(int(center - support + 0.5), 0), xmax = min(int(center + support + 0.5), in) - xmin,
+            w[x] = bicubic((x + xmin - center + 0.5) / filterscale) normalised to sum 1 (double precision),
+            fixed point: k[x] = int(w[x] * 2^22 +- 0.5)  (PRECISION_BITS = 32 - 8 - 2)
+  passes    horizontal first (only the source rows the vertical pass will read), then vertical; each output byte is
+            clip8((2^21 + sum_x pixel[x] * k[x]) >> 22), the horizontal result is stored as uint8 before the vertical pass.
+
+Pinned: `tests/test_oracle_golden.py` checks this restatement byte-for-byte against PIL itself (imported in the test) and
+against fixtures recorded from PIL (tests/golden/resize.npz, tests/golden/make_resize_golden.py).
+"""
+import math
+
+import numpy as np
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def precompute_coeffs(in_size: int, out_size: int):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc for the full box (in0 = 0, in1 = in_size).
+    Returns (ksize, bounds int32 [out, 2] = (xmin, count), coeffs int32 [out, ksize])."""
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            pre = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + pre * (1 << PRECISION_BITS)) if pre < 0 else int(0.5 + pre * (1 << PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return ksize, bounds, kk
+
+
+def _clip8(acc: np.ndarray) -> np.ndarray:
+    return np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+
+
+def _pass(img: np.ndarray, bounds: np.ndarray, kk: np.ndarray, axis: int) -> np.ndarray:
+    """One resampling pass along `axis` (0 = rows / vertical, 1 = columns / horizontal) of a uint8 [H, W, C] image."""
+    out_size = bounds.shape[0]
+    shape = list(img.shape)
+    shape[axis] = out_size
+    out = np.empty(shape, dtype=np.uint8)
+    src = img.astype(np.int64)
+    for i in range(out_size):
+        lo, n = int(bounds[i, 0]), int(bounds[i, 1])
+        k = kk[i, :n].astype(np.int64)
+        if axis == 1:
+            acc = (src[:, lo:lo + n, :] * k[None, :, None]).sum(axis=1) + (1 << (PRECISION_BITS - 1))
+            out[:, i, :] = _clip8(acc)
+        else:
+            acc = (src[lo:lo + n, :, :] * k[:, None, None]).sum(axis=0) + (1 << (PRECISION_BITS - 1))
+            out[i, :, :] = _clip8(acc)
+    return out
+
+
+def resize_bicubic_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """PIL ``Image.fromarray(img).resize((out_w, out_h))`` for a uint8 [H, W, 3] RGB image (ImagingResample, BICUBIC)."""
+    assert img.dtype == np.uint8 and img.ndim == 3
+    in_h, in_w = img.shape[:2]
+    need_h, need_v = out_w != in_w, out_h != in_h
+    if not need_h and not need_v:
+        return img.copy()
+    _, bh, kh = precompute_coeffs(in_w, out_w)
+    _, bv, kv = precompute_coeffs(in_h, out_h)
+    cur = img
+    if need_h:
+        first = int(bv[0, 0])
+        last = int(bv[-1, 0] + bv[-1, 1])
+        cur = _pass(img[first:last], bh, kh, axis=1)          # only the rows the vertical pass reads
+        bv = bv.copy()
+        bv[:, 0] -= first
+    if need_v:
+        cur = _pass(cur, bv, kv, axis=0)
+    return cur

@@ -456,3 +456,65 @@ def test_frame_ingest_is_bit_exact(lib):
     mean, std = (C.c_float * 3)(*O.IMAGENET_MEAN), (C.c_float * 3)(*O.IMAGENET_STD)
     sync(lib.aigv_op_frame_ingest(ptr(dev(u)), 3, 28, 44, mean, std, ptr(out), None), lib)
     assert torch.equal(out.cpu(), want)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# frame resize + ingest: Pillow-exact BICUBIC on the GPU
+# ---------------------------------------------------------------------------------------------------------
+def _resize_ingest(lib, frames_u8, oh, ow, want_u8=True, want_nchw=True):
+    import ctypes
+    from aigv_assessor_amd.native import ptr
+    f = dev(torch.from_numpy(frames_u8))
+    n, ih, iw, _ = f.shape
+    tmp = torch.empty(n * ih * ow * 3, dtype=torch.uint8, device="cuda")
+    u8 = torch.full((n, oh, ow, 3), 77, dtype=torch.uint8, device="cuda") if want_u8 else None
+    pv = torch.full((n, 3, oh, ow), float("nan"), dtype=BF, device="cuda") if want_nchw else None
+    mean, std = (ctypes.c_float * 3)(0.485, 0.456, 0.406), (ctypes.c_float * 3)(0.229, 0.224, 0.225)
+    sync(lib.aigv_op_frame_resize_ingest(ptr(f), n, ih, iw, oh, ow, mean, std, ptr(tmp), ptr(u8), ptr(pv), None), lib)
+    return u8, pv
+
+
+def test_frame_resize_is_bit_exact_with_pillow_fixtures(lib):
+    """The recorded Pillow results (tests/golden/resize.npz): every byte equal; the fused bf16 NCHW output equals the
+    ToTensor / Normalize / bf16 restatement applied to Pillow's bytes."""
+    import os
+    import numpy as np
+    from oracle import oracle as O
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resize.npz"))
+    n = len([k for k in z.files if k.startswith("in")])
+    for i in range(n):
+        want = z[f"out{i}"]
+        u8, pv = _resize_ingest(lib, z[f"in{i}"][None], want.shape[0], want.shape[1])
+        assert np.array_equal(u8.cpu().numpy()[0], want), i
+        ref = O.normalize_frames_u8(torch.from_numpy(want)[None])
+        assert torch.equal(pv.cpu(), ref), i
+
+
+@pytest.mark.parametrize("ih,iw,oh,ow,frames", [(720, 1280, 448, 448, 3), (1080, 1920, 448, 448, 2), (224, 224, 448, 448, 4),
+                                                (448, 448, 448, 448, 2), (360, 640, 224, 224, 5), (37, 1000, 20, 30, 1)])
+def test_frame_resize_matches_oracle_at_video_sizes(lib, ih, iw, oh, ow, frames):
+    """Seeded frames at real video resolutions (several frames per call: the frame stride of both passes) against the CPU
+    restatement of Pillow's algorithm - bit-exact, uint8 and normalised bf16 outputs, each also on its own."""
+    import numpy as np
+    from oracle import oracle as O
+    from oracle.resize import resize_bicubic_u8
+    rng = np.random.default_rng(ih * 7 + iw + frames)
+    fr = rng.integers(0, 256, (frames, ih, iw, 3), dtype=np.uint8)
+    fr[0, : ih // 2] = np.where(rng.random((ih // 2, iw, 3)) < 0.5, 0, 255)      # hard edges in one frame
+    want = np.stack([resize_bicubic_u8(fr[i], oh, ow) for i in range(frames)])
+    u8, pv = _resize_ingest(lib, fr, oh, ow)
+    assert np.array_equal(u8.cpu().numpy(), want)
+    ref = O.normalize_frames_u8(torch.from_numpy(want))
+    assert torch.equal(pv.cpu(), ref)
+    u8_only, none = _resize_ingest(lib, fr, oh, ow, want_nchw=False)
+    assert none is None and torch.equal(u8_only, u8)
+    none, pv_only = _resize_ingest(lib, fr, oh, ow, want_u8=False)
+    assert none is None and torch.equal(pv_only, pv)
+
+
+def test_frame_resize_rejects_bad_arguments(lib):
+    from aigv_assessor_amd import native
+    t = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    assert lib.aigv_op_frame_resize_ingest(t.data_ptr(), 1, 2, 2, 2, 2, None, None, t.data_ptr(), None, None, None) != 0   # no output
+    assert lib.aigv_op_frame_resize_ingest(t.data_ptr(), 1, 0, 2, 2, 2, None, None, t.data_ptr(), t.data_ptr(), None, None) != 0
+    assert lib.aigv_op_frame_resize_ingest(t.data_ptr(), 1, 2, 2, 2, 2, None, None, t.data_ptr(), None, t.data_ptr(), None) != 0   # nchw needs mean/std

@@ -140,3 +140,28 @@ def test_answer_slice_and_level_parse():
     assert O.answer_slice(labels, logit, im_end_id=99).tolist() == [3, 4, 5]
     assert O.parse_level("The static quality of the video is good.") == 4
     assert O.parse_level("excellent") == 5 and O.parse_level("bad poor") == 1 and O.parse_level("n/a") == 0
+
+
+def test_frame_resize_restatement_matches_pillow():
+    """oracle/resize.py (Pillow's 8-bit ImagingResample, BICUBIC) byte-for-byte: against the fixtures recorded from Pillow
+    (tests/golden/resize.npz, make_resize_golden.py) and, where Pillow is importable, against Pillow itself on fresh inputs."""
+    import numpy as np
+    from oracle.resize import resize_bicubic_u8, precompute_coeffs
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resize.npz"))
+    n = len([k for k in z.files if k.startswith("in")])
+    assert n >= 6
+    for i in range(n):
+        want = z[f"out{i}"]
+        assert np.array_equal(resize_bicubic_u8(z[f"in{i}"], want.shape[0], want.shape[1]), want), i
+    # coefficient tables: each row sums to 2^22 up to the rounding of its taps; the full box is covered
+    ks, b, kk = precompute_coeffs(1280, 448)
+    assert ks == 13 and b[0, 0] == 0 and b[-1, 0] + b[-1, 1] == 1280
+    assert np.all(np.abs(kk.sum(axis=1) - (1 << 22)) <= ks)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rng = np.random.default_rng(5)
+    for (h, w, oh, ow) in [(720, 1280, 448, 448), (224, 224, 448, 448), (448, 448, 448, 448), (101, 77, 50, 120)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(resize_bicubic_u8(img, oh, ow), np.asarray(Image.fromarray(img).resize((ow, oh)))), (h, w, oh, ow)
