@@ -64,6 +64,7 @@ struct aigv_ctx {
   bf16_t *l_h = nullptr, *l_t = nullptr, *l_qkv = nullptr, *l_ao = nullptr, *l_ffn = nullptr, *l_rows = nullptr;
   int32_t *l_pos = nullptr, *l_seq = nullptr, *l_cu = nullptr, *l_rowidx = nullptr, *l_kvlen = nullptr;
   unsigned long long* l_packed = nullptr;
+  int32_t* l_neg1 = nullptr;   // max_tokens x int32 -1: the "plain text token" slot map of aigv_llm_extend
   bool trim_last_layer = true;
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 3 (attention out, hidden, normed) + [64, I]
   bf16_t* l_score_ws = nullptr;
@@ -459,6 +460,8 @@ int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out) {
     if ((rc = dalloc(c, &c->l_kvlen, (size_t)k.max_seqs))) break;
     if ((rc = dalloc(c, &c->l_packed, (size_t)64))) break;
     if ((rc = dalloc(c, &c->l_trim, (size_t)64 * (3 * k.llm_hidden + k.llm_inter)))) break;
+    if ((rc = dalloc(c, &c->l_neg1, (size_t)k.max_tokens))) break;
+    if (hipMemset(c->l_neg1, 0xFF, (size_t)k.max_tokens * sizeof(int32_t)) != hipSuccess) { rc = fail(c, AIGV_ERR_HIP, "hipMemset failed"); break; }
     {
       int maxd = k.llm_hidden;
       for (int i = 0; i < k.n_score_layers; ++i) maxd = std::max(maxd, (int)k.score_dims[i]);
@@ -861,7 +864,7 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
   hipStream_t s = (hipStream_t)stream;
   const int H = k.llm_hidden, I = k.llm_inter, D = c->head_dim, g = c->g, nkv = k.llm_kv_heads;
 
-  if (B + 1 > AIGV_SMALL_INTS) return fail(c, AIGV_ERR_ARG, "at most %d clips per prefill call", AIGV_SMALL_INTS - 1);
+  if (B + 1 > AIGV_SMALL_INTS / 2) return fail(c, AIGV_ERR_ARG, "at most %d clips per prefill call", AIGV_SMALL_INTS / 2 - 1);
   // positions / sequence ids / cu_seqlens are produced on the device from cu passed as a kernel argument
   HIPCHK(c, aigv_launch_seqpos(cu, B, c->l_pos, c->l_seq, c->l_cu, T, s));
 
@@ -890,6 +893,8 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
     if (keep_kv)
       HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, T,
                                      nkv, g, D, k.kv_capacity, s));
+    // a pass that only fills the cache (no output rows) needs nothing of the last layer beyond its K/V
+    if (n_out == 0 && c->trim_last_layer && li == k.llm_layers - 1) break;
     {
       AttnArgs a{};
       a.q = c->l_qkv; a.k = c->l_qkv + (size_t)g * D; a.v = c->l_qkv + (size_t)(g + 1) * D;
@@ -946,6 +951,87 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
     c->kv_valid = true;
   } else {
     c->kv_valid = false;
+  }
+  return 0;
+}
+
+// Continue the sequences kept by aigv_llm_prefill(keep_kv = 1) with new TEXT tokens: causal attention of the new rows over the
+// cached keys plus themselves.  commit = 0 leaves the cache lengths where they were, so several continuations of ONE prefix
+// (the four quality-perspective questions behind the same video tokens) can be scored one after the other.
+int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, const int32_t* score_rows, float* score,
+                    const int32_t* logit_rows, int R, int64_t* argmax, int commit, void* stream) {
+  if (!c || !ids || !cu) return fail(c, AIGV_ERR_ARG, "aigv_llm_extend: null argument");
+  if (!c->kv_valid) return fail(c, AIGV_ERR_STATE, "aigv_llm_extend: no KV state (run aigv_llm_prefill with keep_kv)");
+  const aigv_config& k = c->cfg;
+  if (B != c->kv_seqs) return fail(c, AIGV_ERR_ARG, "aigv_llm_extend: %d sequences, the cache holds %d", B, c->kv_seqs);
+  if (B + 1 > AIGV_SMALL_INTS / 2) return fail(c, AIGV_ERR_ARG, "at most %d clips per call", AIGV_SMALL_INTS / 2 - 1);
+  if (cu[0] != 0) return fail(c, AIGV_ERR_ARG, "cu_seqlens[0] must be 0");
+  int max_new = 0;
+  for (int b = 0; b < B; ++b) {
+    const int n = cu[b + 1] - cu[b];
+    if (n <= 0) return fail(c, AIGV_ERR_ARG, "clip %d: no new tokens", b);
+    if (c->h_kvlen[b] + n > k.kv_capacity || c->h_kvlen[b] + n > k.max_positions)
+      return fail(c, AIGV_ERR_STATE, "clip %d: KV cache / RoPE table exhausted (%d cached + %d new, capacity %d)", b, c->h_kvlen[b], n, k.kv_capacity);
+    max_new = std::max(max_new, n);
+  }
+  const int T = cu[B];
+  if (T > k.max_tokens) return fail(c, AIGV_ERR_ARG, "%d new tokens exceed max_tokens %d", T, k.max_tokens);
+  if ((score && !score_rows) || (R > 0 && (!logit_rows || !argmax))) return fail(c, AIGV_ERR_ARG, "output rows/buffers inconsistent");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int H = k.llm_hidden, I = k.llm_inter, D = c->head_dim, g = c->g, nkv = k.llm_kv_heads;
+  // positions continue after the cached tokens; the cached lengths are the per-sequence key offsets of the attention
+  HIPCHK(c, aigv_launch_seqpos(cu, B, c->l_pos, c->l_seq, c->l_cu, T, s, c->h_kvlen.data()));
+  HIPCHK(c, aigv_launch_write_ints(c->h_kvlen.data(), B, c->l_kvlen, s));
+  HIPCHK(c, aigv_launch_embed(ids, c->l_neg1, c->tok_emb, nullptr, nullptr, 0, c->l_h, T, H, s));
+  TRY(upload_out_rows(c, score_rows, score != nullptr, B, logit_rows, R, T, s));
+  double attn_flops = 0;
+  for (int b = 0; b < B; ++b) { const double n = cu[b + 1] - cu[b]; attn_flops += 4.0 * n * (c->h_kvlen[b] + (n + 1) / 2) * D * k.llm_heads; }
+  const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
+  for (int li = 0; li < k.llm_layers; ++li) {
+    const LlmLayer& L = c->llm[li];
+    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
+    TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
+    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, g + 1, g + 2, nkv, D, s));
+    HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, T, nkv, g, D,
+                                   k.kv_capacity, s));
+    {
+      AttnArgs a{};
+      a.q = c->l_qkv; a.ldq = c->qkv_out;
+      a.k = c->kc + li * kv_layer; a.v = c->vc + li * kv_layer;
+      a.ldk = a.ldv = D; a.kv_head_stride = k.kv_capacity * D; a.kv_seq_stride = (size_t)nkv * k.kv_capacity * D;
+      a.kv_off = c->l_kvlen;
+      a.o = c->l_ao; a.ldo = H;
+      a.cu = c->l_cu; a.n_seq = B; a.max_len = max_new;
+      a.n_heads = k.llm_heads; a.n_kv_heads = nkv;
+      a.q_group_stride = (g + 2) * D;
+      a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
+      if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
+      ProfScope ps(c, AIGV_PROF_ATTN_LLM, attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
+      HIPCHK(c, aigv_launch_attention(a, D, s));
+    }
+    {
+      GemmArgs a = gemm_args(c->l_ao, H, L.wo, H, c->l_h, H, T, H, H);
+      a.resid = c->l_h; a.ldr = H;
+      TRY(run_gemm(c, a, EPI_RESID, s));
+    }
+    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, T, H, k.rms_eps, nullptr, s));
+    TRY(run_gemm(c, gemm_args(c->l_t, H, L.w13, H, c->l_ffn, I, T, 2 * I, H), EPI_SWIGLU, s));
+    {
+      GemmArgs a = gemm_args(c->l_ffn, I, L.w2, I, c->l_h, H, T, H, I);
+      a.resid = c->l_h; a.ldr = H;
+      TRY(run_gemm(c, a, EPI_RESID, s));
+    }
+  }
+  TRY(final_rows(c, score, B, R, argmax, c->l_h, false, s));
+  if (commit) {
+    for (int b = 0; b < B; ++b) {
+      const int len = c->h_kvlen[b] + (cu[b + 1] - cu[b]);
+      c->h_kvlen[b] = len;
+      c->h_dec[b] = len; c->h_dec[2 * B + b] = len + 1;
+    }
+    HIPCHK(c, aigv_launch_write_ints(c->h_dec.data(), B, c->dec_pos, s));
+    HIPCHK(c, aigv_launch_write_ints(c->h_dec.data() + 2 * B, B, c->dec_kvlen, s));
   }
   return 0;
 }

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
   const int q0 = (CAUSAL ? nqb - 1 - qb : qb) * QB;
   if (q0 >= len) return;
   if (p.q_tail > 0 && q0 + QB <= len - p.q_tail) return;   // this block's rows are not consumed (last-layer row trimming)
-  const int kv_len = len + p.kv_len_offset;       // keys visible in total (prefill: offset 0)
+  const int kv_off = p.kv_off ? p.kv_off[seq] : p.kv_len_offset;   // keys in front of this sequence's first query row
+  const int kv_len = len + kv_off;                // keys visible in total (plain prefill: offset 0)
   const int qw = q0 + wave * 32;                  // first query row of this wave
 
   // ---- Q^T fragments: lane (c,h) holds Q[qw+c][16*ks + 8h + j] --------------------------------------
@@ -99,11 +100,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
   // ---- tile range ----------------------------------------------------------------------------------
   int n_tiles = (kv_len + KT - 1) / KT;
   if (CAUSAL) {
-    const int last_q = min(q0 + QB, len) - 1 + p.kv_len_offset;   // last visible key index of the block
+    const int last_q = min(q0 + QB, len) - 1 + kv_off;   // last visible key index of the block
     n_tiles = min(n_tiles, last_q / KT + 1);
   }
-  const bf16_t* kbase = p.k + (size_t)row0 * p.ldk + (size_t)hk * p.kv_head_stride;
-  const bf16_t* vbase = p.v + (size_t)row0 * p.ldv + (size_t)hk * p.kv_head_stride;
+  const size_t kv_seq = p.kv_seq_stride ? (size_t)seq * p.kv_seq_stride : 0;
+  const bf16_t* kbase = p.k + (p.kv_seq_stride ? kv_seq : (size_t)row0 * p.ldk) + (size_t)hk * p.kv_head_stride;
+  const bf16_t* vbase = p.v + (p.kv_seq_stride ? kv_seq : (size_t)row0 * p.ldv) + (size_t)hk * p.kv_head_stride;
 
   // LDS-DMA staging: a wave-instruction writes 1 KB = RPI rows linearly, so the bank swizzles are applied to the per-lane
   // SOURCE chunk (the same XOR the fragment reads apply).  Keys past kv_len re-read the last valid row (masked later).
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     // wave-uniform skips: tiles entirely in this wave's causal future; waves whose 32 query rows all lie past the sequence
     // (1025 = 8 x 128 + 1 rows per ViT frame: three of the last workgroup's four waves).  Such a wave still stages its share
     // of every tile and joins the barriers, but leaves its SIMD's issue slots to the co-resident workgroups.
-    if (CAUSAL && key0 > qw + 31 + p.kv_len_offset) continue;
+    if (CAUSAL && key0 > qw + 31 + kv_off) continue;
     if (qw >= len || (p.q_tail > 0 && qw + 32 <= len - p.q_tail)) continue;
 
     // ---- S^T = K · Q^T -------------------------------------------------------------------------
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     // ---- online softmax on the fp32 scores (one FMA + one exp2 per element) ---------------------------------
     // p = exp2(s * c - m * c), c = log2(e) / post_div.  The mask is only evaluated on tiles that need it (the
     // causal diagonal / the ragged last tile); the O rescale is skipped when no row maximum moved (wave-uniform).
-    const int qpos = qw + c + p.kv_len_offset;   // index of the last key this query may see (causal)
-    const bool need_mask = (key0 + KT > kv_len) || (CAUSAL && key0 + KT - 1 > qw + p.kv_len_offset);
+    const int qpos = qw + c + kv_off;   // index of the last key this query may see (causal)
+    const bool need_mask = (key0 + KT > kv_len) || (CAUSAL && key0 + KT - 1 > qw + kv_off);
     float tmax = -INFINITY;
     if (need_mask) {
 #pragma unroll
@@ -417,7 +419,8 @@ const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
   if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.ldo % 4) || (a.q_group_stride % 8) || (a.kv_head_stride % 8))
     return "attention: strides must keep 16-byte alignment";
   if (!a.q || !a.k || !a.v || !a.o || !a.cu) return "attention: null operand";
-  if (a.kv_len_offset != 0) return "attention: prefill kernel needs kv_len_offset == 0";
+  if ((a.kv_len_offset != 0 || a.kv_off) && !a.kv_seq_stride) return "attention: a key offset needs K/V in cache layout (kv_seq_stride)";
+  if (a.kv_len_offset < 0 || (a.kv_seq_stride % 8)) return "attention: bad key offset / cache stride";
   return nullptr;
 }
 

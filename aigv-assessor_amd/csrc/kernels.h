@@ -55,7 +55,10 @@ struct AttnArgs {
   int n_seq, max_len;
   int n_heads, n_kv_heads;
   int q_group_stride, kv_head_stride;
-  int kv_len_offset;            // must be 0 for the prefill kernel
+  int kv_len_offset;            // keys that precede the first query row of every sequence (0: plain prefill)
+  const int32_t* kv_off;        // per-sequence form of kv_len_offset (device, [n_seq]); overrides it when non-null
+  size_t kv_seq_stride;         // 0: K/V rows are packed like the query rows (row0 * ldk); else K/V of sequence s start at
+                                // s * kv_seq_stride elements (a KV cache [seq][kv head][capacity][D]: ldk = D, kv_head_stride = cap * D)
   int causal;
   float post_div;               // score = bf16(bf16(q.k) / post_div)  (LLM: sqrt(d); ViT: 1, q is pre-scaled)
   float q_prescale;             // q <- bf16(q * q_prescale)           (ViT: d^-1/2; LLM: 1)
@@ -125,7 +128,7 @@ hipError_t aigv_launch_advance(int32_t* a, int32_t* b, int n, hipStream_t s);
 // small host int arrays passed by value as kernel arguments (no memcpy, no implicit host/stream sync)
 #define AIGV_SMALL_INTS 256
 struct SmallInts { int32_t v[AIGV_SMALL_INTS]; };
-// pos[t] = t - cu[seq(t)], seq[t], and a device copy of cu[0..n_seq]
+// pos[t] = t - cu[seq(t)] (+ pos_offset[seq(t)]), seq[t], and a device copy of cu[0..n_seq]; at most 127 sequences
 hipError_t aigv_launch_seqpos(const int32_t* cu_host, int n_seq, int32_t* pos, int32_t* seq, int32_t* cu_dev, int tokens,
-                              hipStream_t s);
+                              hipStream_t s, const int32_t* pos_offset_host = nullptr);
 hipError_t aigv_launch_write_ints(const int32_t* host, int n, int32_t* dst, hipStream_t s);

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void seqpos_kernel(const SmallInts cu, int n_s
   if (t >= tokens) return;
   int b = 0;
   while (b + 1 < n_seq && t >= cu.v[b + 1]) ++b;
-  pos[t] = t - cu.v[b];
+  pos[t] = t - cu.v[b] + cu.v[AIGV_SMALL_INTS / 2 + b];   // second half of the argument: per-sequence position offsets
   seq[t] = b;
 }
 
@@ -253,10 +253,12 @@ __global__ void advance_kernel(int32_t* a, int32_t* b, int n) {
 }  // namespace
 
 hipError_t aigv_launch_seqpos(const int32_t* cu_host, int n_seq, int32_t* pos, int32_t* seq, int32_t* cu_dev, int tokens,
-                              hipStream_t s) {
-  if (n_seq <= 0 || n_seq + 1 > AIGV_SMALL_INTS || tokens <= 0) return hipErrorInvalidValue;
+                              hipStream_t s, const int32_t* pos_offset_host) {
+  if (n_seq <= 0 || n_seq + 1 > AIGV_SMALL_INTS / 2 || tokens <= 0) return hipErrorInvalidValue;
   SmallInts a{};
   for (int i = 0; i <= n_seq; ++i) a.v[i] = cu_host[i];
+  if (pos_offset_host)
+    for (int i = 0; i < n_seq; ++i) a.v[AIGV_SMALL_INTS / 2 + i] = pos_offset_host[i];
   hipLaunchKernelGGL(seqpos_kernel, dim3((tokens + 255) / 256), dim3(256), 0, s, a, n_seq, pos, seq, cu_dev, tokens);
   return hipGetLastError();
 }

@@ -454,13 +454,26 @@ class InternVLChatModel(nn.Module):
             raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
         B, N = input_ids.shape
         dev = self.device
-        H = self.config.llm_config.hidden_size
-
+        n_frames = visual_tokens.shape[0] if visual_tokens is not None else pixel_values.shape[0]
         # ---- index bookkeeping first, on the host (one small D2H copy if the ids live on the device), so that
         # every kernel of the step can then be enqueued back to back without a host sync in between ----
+        plan = self._plan(input_ids, attention_mask, labels, image_flags, n_frames, full_logits)
+        motion_feature = self._motion_feature(pixel_values, B, motion_feature)
+
+        # ---- device work: ViT -> projector -> motion projector -> LLM pass + heads ----
+        self._native(n_frames=n_frames, n_tokens=plan["cu"][-1], n_clips=B, out_rows=len(plan["logit_rows"]))   # size workspaces once
+        vit_embeds, motion = self._visual_inputs(pixel_values, visual_tokens, motion_feature, plan)
+        score, amax = self._prefill(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], motion,
+                                    plan["score_rows"], plan["logit_rows"])
+        return self._outputs(plan, B, N, score, amax, mos)
+
+    def _plan(self, input_ids, attention_mask, labels, image_flags, n_frames, full_logits=False):
+        """Host-side token bookkeeping of one pass: packed ids, which packed row takes which visual / motion token
+        (modeling_internvl_chat.py:351-378), and the rows whose outputs are consumed."""
+        B, N = input_ids.shape
         ids_h = input_ids.detach().to("cpu")
         mask_h = attention_mask.detach().to("cpu") if attention_mask is not None else None
-        labels_h = labels.detach().to("cpu")
+        labels_h = labels.detach().to("cpu") if labels is not None else torch.full_like(ids_h, -100)
         flags_h = image_flags.detach().to("cpu").squeeze(-1) if image_flags is not None else None
         ids_packed, cu, row_of = self._pack(ids_h, mask_h)
         lens = [cu[i + 1] - cu[i] for i in range(B)]
@@ -475,7 +488,6 @@ class InternVLChatModel(nn.Module):
         is_motion = torch.zeros_like(sel)
         is_motion[last_pos] = True
         vis_sel = sel & ~is_motion
-        n_frames = visual_tokens.shape[0] if visual_tokens is not None else pixel_values.shape[0]
         keep = torch.arange(n_frames) if flags_h is None else (flags_h == 1).nonzero().flatten()
         n_vis = int(keep.numel()) * self.num_image_token
         if int(vis_sel.sum()) != n_vis:
@@ -492,29 +504,102 @@ class InternVLChatModel(nn.Module):
         score_rows = [cu[i + 1] - 4 for i in range(B)] if self.stage == 2 else None
         if score_rows is not None and min(lens) < 4:
             raise ValueError("clips need at least 4 tokens for the score row hidden[:, -4]")
-        motion_feature = self._motion_feature(pixel_values, B, motion_feature)
+        return dict(ids_h=ids_h, mask_h=mask_h, labels_h=labels_h, flags_h=flags_h, ids_packed=ids_packed, cu=cu, row_of=row_of,
+                    lens=lens, slot=slot, n_vis=n_vis, keep=keep, n_frames=n_frames, want=want, logit_rows=logit_rows,
+                    score_rows=score_rows, last_ctx=(last_pos - torch.tensor(cu[:-1])).tolist())
 
-        # ---- device work: ViT -> projector -> motion projector -> LLM pass + heads ----
-        self._native(n_frames=n_frames, n_tokens=cu[-1], n_clips=B, out_rows=len(logit_rows))   # size workspaces once
+    def _visual_inputs(self, pixel_values, visual_tokens, motion_feature, plan):
+        H = self.config.llm_config.hidden_size
         if visual_tokens is None:
             visual_tokens = self.vit_tokens(pixel_values)
         vit_embeds = self.project(visual_tokens)                       # [F, ntok, H]
-        if flags_h is not None and int(keep.numel()) != n_frames:
-            vit_embeds = vit_embeds[keep.pin_memory().to(dev, non_blocking=True)]
-        vit_embeds = vit_embeds.reshape(-1, H)
-        motion = self.motion_embed(motion_feature)
-        score, amax = self._prefill(ids_packed, slot, cu, vit_embeds, n_vis, motion, score_rows, logit_rows)
+        if plan["flags_h"] is not None and int(plan["keep"].numel()) != plan["n_frames"]:
+            vit_embeds = vit_embeds[plan["keep"].pin_memory().to(self.device, non_blocking=True)]
+        return vit_embeds.reshape(-1, H), self.motion_embed(motion_feature)
+
+    def _outputs(self, plan, B, N, score, amax, mos):
+        dev = self.device
         def up(t):   # host -> device through pinned memory, never blocking the host (keeps the CPU ahead of the GPU)
             return t if t.is_cuda else t.contiguous().pin_memory().to(dev, non_blocking=True)
         logit = torch.full((B * (N - 1),), -1, dtype=torch.long, device=dev)
-        if len(logit_rows):
-            logit.index_copy_(0, up(want.reshape(-1).nonzero().flatten()), amax)   # index list built on the host: no sync
-        out = {"label": up(labels_h[..., 1:].contiguous().view(-1)), "logit": logit.view(-1)}
+        if len(plan["logit_rows"]):
+            logit.index_copy_(0, up(plan["want"].reshape(-1).nonzero().flatten()), amax)   # index list built on the host: no sync
+        out = {"label": up(plan["labels_h"][..., 1:].contiguous().view(-1)), "logit": logit.view(-1)}
         if self.stage == 2:
             score1 = score.to(torch.bfloat16)       # the head computes in bf16; the value is exact in fp32
             out["score1"] = score1
             out["loss"] = F.l1_loss(score1, mos.to(dev).to(score1.dtype)) if mos is not None else None
         return out
+
+    def forward_shared_prefix(self, prompts, pixel_values: Optional[torch.Tensor] = None, image_flags: Optional[torch.Tensor] = None,
+                              motion_feature: Optional[torch.Tensor] = None, visual_tokens: Optional[torch.Tensor] = None, mos=None):
+        """Score the same clips under several prompts that share their beginning - the reference's four quality
+        perspectives ask four questions BEHIND the same system + frame + motion tokens (8f-3) and
+        run four full passes (stage2_eval.py evaluates one jsonl per perspective).  Here the common prefix runs once
+        (ViT, projector, LLM prefill into the KV cache); every prompt then only continues its own few question / answer
+        tokens over the cached keys (``aigv_llm_extend``).  ``prompts``: list of ``(input_ids[B, N_p], attention_mask,
+        labels)``; returns the list of ``forward`` result dicts, one per prompt.  Causal attention makes the prefix rows
+        independent of what follows, so each result is that of a separate ``forward`` call up to kernel summation order."""
+        if self.img_context_token_id is None:
+            raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
+        if not prompts:
+            return []
+        n_frames = visual_tokens.shape[0] if visual_tokens is not None else pixel_values.shape[0]
+        plans = [self._plan(ids, am, lab, image_flags, n_frames) for (ids, am, lab) in prompts]
+        B = prompts[0][0].shape[0]
+        # common prefix per clip: identical tokens in every prompt, all <IMG_CONTEXT> tokens inside, every consumed row outside
+        pre = []
+        for b in range(B):
+            seqs = [pl["ids_packed"][pl["cu"][b]:pl["cu"][b + 1]] for pl in plans]
+            n = min(len(x) for x in seqs)
+            eq = torch.ones(n, dtype=torch.bool)
+            for x in seqs[1:]:
+                eq &= x[:n] == seqs[0][:n]
+            lcp = int(n if bool(eq.all()) else eq.long().argmin())
+            first_needed = []
+            for pl in plans:
+                rows = [r - pl["cu"][b] for r in pl["logit_rows"] if pl["cu"][b] <= r < pl["cu"][b + 1]]
+                if pl["score_rows"] is not None:
+                    rows.append(pl["score_rows"][b] - pl["cu"][b])
+                first_needed.append(min(rows) if rows else pl["lens"][b] - 1)
+            p_b = min([lcp] + first_needed + [pl["lens"][b] - 1 for pl in plans])
+            if p_b <= max(pl["last_ctx"][b] for pl in plans):
+                raise ValueError(f"clip {b}: the prompts diverge before the last <IMG_CONTEXT> token - no shared video prefix")
+            pre.append(p_b)
+        p0 = plans[0]
+        ids_prefix = torch.cat([p0["ids_packed"][p0["cu"][b]:p0["cu"][b] + pre[b]] for b in range(B)])
+        slot_prefix = torch.cat([p0["slot"][p0["cu"][b]:p0["cu"][b] + pre[b]] for b in range(B)])
+        cu_prefix = [0]
+        for b in range(B):
+            cu_prefix.append(cu_prefix[-1] + pre[b])
+        motion_feature = self._motion_feature(pixel_values, B, motion_feature)
+        longest = max(max(pl["lens"]) for pl in plans)
+        self._native(n_frames=n_frames, n_tokens=cu_prefix[-1], n_clips=B, out_rows=max(len(pl["logit_rows"]) for pl in plans),
+                     kv_cap=longest + 1)
+        vit_embeds, motion = self._visual_inputs(pixel_values, visual_tokens, motion_feature, p0)
+        self._prefill(ids_prefix, slot_prefix, cu_prefix, vit_embeds, p0["n_vis"], motion, None, [], keep_kv=True, kv_cap=longest + 1)
+        lib, ctx = native.load(), self._ctx
+        dev = self.device
+        outs = []
+        for pl, (ids, _, _) in zip(plans, prompts):
+            suffix = torch.cat([pl["ids_packed"][pl["cu"][b] + pre[b]:pl["cu"][b + 1]] for b in range(B)])
+            cu_s = [0]
+            for b in range(B):
+                cu_s.append(cu_s[-1] + pl["lens"][b] - pre[b])
+            def local(r):   # packed row of the full prompt -> packed row of the suffix batch
+                b = max(i for i in range(B) if pl["cu"][i] <= r)
+                return cu_s[b] + (r - pl["cu"][b] - pre[b])
+            lrows = [local(r) for r in pl["logit_rows"]]
+            srows = [local(r) for r in pl["score_rows"]] if pl["score_rows"] is not None else None
+            ids_d = suffix.to(torch.long).contiguous().pin_memory().to(dev, non_blocking=True)
+            score = torch.empty(B, dtype=torch.float32, device=dev) if srows is not None else None
+            amax = torch.empty(max(len(lrows), 1), dtype=torch.long, device=dev)
+            native.check(lib.aigv_llm_extend(ctx, ids_d.data_ptr(), native.i32_array(cu_s), B,
+                                             native.i32_array(srows) if srows is not None else None, native.ptr(score),
+                                             native.i32_array(lrows) if lrows else None, len(lrows), amax.data_ptr(), 0,
+                                             native.stream_ptr()), ctx)
+            outs.append(self._outputs(pl, B, ids.shape[1], score, amax[: len(lrows)], mos))
+        return outs
 
     # ---- generation (API surface; greedy) -------------------------------------------------------------------
     def _greedy(self, ids_packed, slot, cu, vis, n_vis, max_new_tokens: int, eos_ids: List[int], pad_id: int):

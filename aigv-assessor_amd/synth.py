@@ -168,6 +168,32 @@ def canonical_tokens(cfg: InternVLChatConfig, n_clips: int, n_frames: int, seed:
             "img_context_token_id": sp["img_context"], "im_end_id": sp["im_end"]}
 
 
+def perspective_prompts(base: Dict[str, torch.Tensor], n_prompts: int, seed: int = 0, question_lens=(16, 11, 21, 16),
+                        answer_len: int = 9) -> List[Dict[str, torch.Tensor]]:
+    """Variants of a canonical prompt that share everything up to the motion block and differ in the question / answer tokens
+    behind it - the shape of the reference's four quality perspectives (`...Motion Feature:
+    <img><IMG_CONTEXT></img>{question}<|im_end|><|im_start|>assistant\n{answer}<|im_end|>`).  Prompt 0 is `base` itself."""
+    ids0, lab0 = base["input_ids"], base["labels"]
+    n_clips, n0 = ids0.shape
+    cut = n0 - 16 - (answer_len + 1)                 # first question token of the canonical layout
+    g = torch.Generator().manual_seed(7000 + seed)
+    hi = int(min(base["im_end_id"], ids0.max().item() + 1))
+    out = [dict(base)]
+    for p in range(1, n_prompts):
+        q = int(question_lens[p % len(question_lens)])
+        rows, labs = [], []
+        for b in range(n_clips):
+            question = torch.randint(3, max(4, hi), (q,), generator=g).tolist()
+            ans = torch.randint(3, max(4, hi), (answer_len,), generator=g).tolist() + [int(base["im_end_id"])]
+            rows.append(ids0[b, :cut].tolist() + question + ans)
+            labs.append([-100] * (cut + q) + ans)
+        ids = torch.tensor(rows, dtype=torch.long)
+        out.append({"input_ids": ids, "labels": torch.tensor(labs, dtype=torch.long),
+                    "attention_mask": torch.ones_like(ids, dtype=torch.bool),
+                    "img_context_token_id": base["img_context_token_id"], "im_end_id": base["im_end_id"]})
+    return out
+
+
 def canonical_len(cfg: InternVLChatConfig, n_frames: int, answer_len: int = 9) -> int:
     return 40 + n_frames * (7 + cfg.num_image_token) + 7 + 16 + answer_len + 1
 

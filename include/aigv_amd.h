@@ -102,6 +102,15 @@ int aigv_motion_project(aigv_ctx* ctx, const void* motion_feature, int n_clips, 
 int aigv_llm_prefill(aigv_ctx* ctx, const int64_t* ids, const int32_t* slot, const int32_t* cu_seqlens, int n_clips,
                      const void* vis, int n_vis, const void* motion, const int32_t* score_rows, float* score,
                      const int32_t* logit_rows, int n_logit_rows, int64_t* argmax, int keep_kv, void* stream);
+/* Continue the sequences kept by aigv_llm_prefill(keep_kv = 1) with new TEXT tokens (no visual slots): ids = DEVICE int64 of the
+ * packed new tokens, cu = HOST int32[n_clips + 1] over the new tokens only; rows index the packed new tokens.  The new rows attend
+ * causally to the cached keys and to themselves (positions continue after the cache).  commit = 0 leaves the cache lengths
+ * unchanged, so several continuations of ONE prefix - the four quality-perspective questions behind the same video tokens
+ *  - can be scored one after the other; commit = 1 appends them (a longer chat turn before aigv_decode_step).
+ * Replaces re-running modeling_internvl_chat.py:306-488 from the first token for every question. */
+int aigv_llm_extend(aigv_ctx* ctx, const int64_t* ids, const int32_t* cu, int n_clips, const int32_t* score_rows, float* score,
+                    const int32_t* logit_rows, int n_logit_rows, int64_t* argmax, int commit, void* stream);
+
 /* Last-layer row trimming in aigv_llm_prefill (default on): when at most 64 rows are consumed (score rows + logit rows), the
  * last decoder layer computes attention only for the query blocks holding them and finishes wo / MLP / final norm on a compact
  * copy of those rows.  Rows are independent after attention, so the outputs are those of the untrimmed pass (up to the fp32

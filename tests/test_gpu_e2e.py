@@ -139,6 +139,71 @@ def test_last_layer_row_trimming_is_output_equivalent():
     assert bool((d <= 2.0 ** -7 * full["score1"].float().abs().cpu().clamp_min(0.5)).all()), d
 
 
+def test_shared_prefix_scoring_matches_separate_passes():
+    """Four prompts behind one video prefix: the prefix runs once into the KV cache, every prompt continues
+    its own question / answer tokens (aigv_llm_extend).  Each result must be that of a separate full pass: identical level
+    tokens (a rounding tie may flip), score within one bf16 ulp; and prompt 0 still matches the oracle."""
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    model, sd, toks, pv, motion, ref, out0 = run_case(cfg, B=2, T=2, seed=31)
+    prompts = synth.perspective_prompts(toks, 4, seed=31)
+    flags = torch.ones(pv.shape[0], 1, dtype=torch.long)
+    outs = model.forward_shared_prefix([(p["input_ids"], p["attention_mask"], p["labels"]) for p in prompts], pixel_values=pv,
+                                       image_flags=flags, motion_feature=motion)
+    torch.cuda.synchronize()
+    assert len(outs) == 4
+    check_levels(outs[0], ref)
+    score_ok(outs[0]["score1"], ref["score1"])
+    flips = 0
+    for p, got in zip(prompts, outs):
+        sep = model(mos=None, pixel_values=pv, input_ids=p["input_ids"], attention_mask=p["attention_mask"], image_flags=flags,
+                    labels=p["labels"], motion_feature=motion)
+        assert torch.equal(got["label"], sep["label"]) and got["logit"].shape == sep["logit"].shape
+        want = (p["labels"][:, 1:] != -100).reshape(-1)
+        flips += int((got["logit"].cpu()[want] != sep["logit"].cpu()[want]).sum())
+        assert bool((got["logit"].cpu()[~want] == -1).all())
+        d = (got["score1"].float() - sep["score1"].float()).abs().cpu()
+        assert bool((d <= 2.0 ** -7 * sep["score1"].float().abs().cpu().clamp_min(0.5)).all()), (d, got["score1"], sep["score1"])
+    assert flips <= 1, flips
+
+
+def test_extend_continues_a_prefill_exactly_like_a_longer_prefill():
+    """aigv_llm_extend with commit: prefill(prompt[:-k]) + extend(prompt[-k:]) yields the next token of prefill(prompt), and a
+    decode step after the committed extension agrees with the decode step after the full prefill."""
+    from aigv_assessor_amd import native
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    model, sd, toks, pv, motion, ref, out0 = run_case(cfg, B=2, T=2, seed=33)
+    lib = native.load()
+    flags = torch.ones(pv.shape[0], 1, dtype=torch.long)
+    plan = model._plan(toks["input_ids"], toks["attention_mask"], toks["labels"], flags, pv.shape[0])
+    vit_embeds, mot = model._visual_inputs(pv, None, motion, plan)
+    B, cu, k = 2, plan["cu"], 7
+    last_rows = [cu[b + 1] - 1 for b in range(B)]
+    cap = max(plan["lens"]) + 8
+    _, nxt_full = model._prefill(plan["ids_packed"], plan["slot"], cu, vit_embeds, plan["n_vis"], mot, None, last_rows, keep_kv=True, kv_cap=cap)
+    ctx = model._ctx        # (the context is re-created when the KV capacity grows: take the handle after the prefill)
+    step_full = torch.empty_like(nxt_full)
+    native.check(lib.aigv_decode_step(ctx, nxt_full.contiguous().data_ptr(), step_full.data_ptr(), None), ctx)
+    torch.cuda.synchronize()
+    # the same prompt as prefix + k-token extension
+    ids_p = torch.cat([plan["ids_packed"][cu[b]:cu[b + 1] - k] for b in range(B)])
+    slot_p = torch.cat([plan["slot"][cu[b]:cu[b + 1] - k] for b in range(B)])
+    cu_p = [0, plan["lens"][0] - k, plan["lens"][0] + plan["lens"][1] - 2 * k]
+    model._prefill(ids_p, slot_p, cu_p, vit_embeds, plan["n_vis"], mot, None, [], keep_kv=True, kv_cap=cap)
+    tail = torch.cat([plan["ids_packed"][cu[b + 1] - k:cu[b + 1]] for b in range(B)]).to(torch.long).cuda()
+    nxt_ext = torch.empty(B, dtype=torch.long, device="cuda")
+    native.check(lib.aigv_llm_extend(ctx, tail.data_ptr(), native.i32_array([0, k, 2 * k]), B, None, None,
+                                     native.i32_array([k - 1, 2 * k - 1]), B, nxt_ext.data_ptr(), 1, None), ctx)
+    step_ext = torch.empty_like(nxt_ext)
+    native.check(lib.aigv_decode_step(ctx, nxt_ext.contiguous().data_ptr(), step_ext.data_ptr(), None), ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(nxt_ext.cpu(), nxt_full.cpu()), (nxt_ext, nxt_full)
+    assert torch.equal(step_ext.cpu(), step_full.cpu()), (step_ext, step_full)
+    # without a cache the call is refused
+    model._prefill(plan["ids_packed"], plan["slot"], cu, vit_embeds, plan["n_vis"], mot, None, last_rows)
+    assert lib.aigv_llm_extend(ctx, tail.data_ptr(), native.i32_array([0, k, 2 * k]), B, None, None, native.i32_array([0, k]), B,
+                               nxt_ext.data_ptr(), 0, None) != 0
+
+
 def test_stage1_and_ragged_padded_batch():
     cfg = pkg.tiny(image_size=224, vit_layers=1)
     seed = 9
