@@ -366,14 +366,21 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* 
 #pragma unroll
     for (int j2 = 0; j2 < G; ++j2) acc[j2][0] = acc[j2][1] = 0.f;
     const int kbeg = wave * 32, kend = min(kbeg + 32, nkeys);
-    for (int kk = kbeg; kk < kend; ++kk) {
-      const uint32_t raw = *(const uint32_t*)(vb + (size_t)kk * D + 2 * d2);
-      const float v0 = bf2f((bf16_t)(raw & 0xffff)), v1 = bf2f((bf16_t)(raw >> 16));
+    // eight V rows in flight per step: the loop is a chain of L2 latencies, not of FMAs (rows past kend re-read the last valid
+    // row and get p = 0: keys are summed in the same order as a plain loop)
+    for (int k0 = kbeg; k0 < kend; k0 += 8) {
+      uint32_t raw[8];
 #pragma unroll
-      for (int j2 = 0; j2 < G; ++j2) {
-        const float pr = sS[j2][kk];
-        acc[j2][0] += pr * v0;
-        acc[j2][1] += pr * v1;
+      for (int u = 0; u < 8; ++u) raw[u] = *(const uint32_t*)(vb + (size_t)min(k0 + u, kend - 1) * D + 2 * d2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float v0 = bf2f((bf16_t)(raw[u] & 0xffff)), v1 = bf2f((bf16_t)(raw[u] >> 16));
+#pragma unroll
+        for (int j2 = 0; j2 < G; ++j2) {
+          const float pr = (k0 + u < kend) ? sS[j2][k0 + u] : 0.f;
+          acc[j2][0] += pr * v0;
+          acc[j2][1] += pr * v1;
+        }
       }
     }
 #pragma unroll
@@ -387,25 +394,55 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* 
   if (t < G) { wbase[(size_t)t * (D + 2)] = sM[t]; wbase[(size_t)t * (D + 2) + 1] = sL[t]; }
 }
 
+constexpr int MERGE_MAX_CHUNKS = 128;   // capacity / DC the merge kernel holds in LDS (a 16 384-token cache)
+
 template <int G>
 __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __restrict__ ws, int max_chunks,
                                                                 const int32_t* __restrict__ kv_lens, bf16_t* __restrict__ o,
                                                                 int ldo) {
   constexpr int D = 128;
+  __shared__ float sM[G][MERGE_MAX_CHUNKS], sW[G][MERGE_MAX_CHUNKS];   // chunk maxima, then chunk weights exp(m - M)
+  __shared__ float sL[G];
   const int hk = blockIdx.x, seq = blockIdx.y, n_kv = gridDim.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nch = (kv_lens[seq] + DC - 1) / DC;
   const float* base = ws + (((size_t)seq * n_kv + hk) * max_chunks) * G * (D + 2);
-  for (int i = threadIdx.x; i < G * D; i += 256) {
-    const int j2 = i / D, d = i % D;
-    float M = -INFINITY;
-    for (int ch = 0; ch < nch; ++ch) M = fmaxf(M, base[((size_t)ch * G + j2) * (D + 2)]);
-    float L = 0.f, A = 0.f;
-    for (int ch = 0; ch < nch; ++ch) {
-      const float* pp = base + ((size_t)ch * G + j2) * (D + 2);
-      const float sc = __expf(pp[0] - M);
-      L += pp[1] * sc;
-      A += pp[2 + d] * sc;
+  // all chunk statistics with independent loads (the chunk loop used to be a chain of global-load latencies)
+  for (int i = t; i < nch * G; i += 256) {
+    const int ch = i / G, j2 = i - ch * G;
+    const float* pp = base + ((size_t)ch * G + j2) * (D + 2);
+    sM[j2][ch] = pp[0];
+    sW[j2][ch] = pp[1];
+  }
+  __syncthreads();
+  for (int j2 = wave; j2 < G; j2 += 4) {   // one wave per head: global maximum, chunk weights, denominator - chunks in order
+    float m = -INFINITY;
+    for (int ch = lane; ch < nch; ch += 64) m = fmaxf(m, sM[j2][ch]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int c0 = 0; c0 < nch; c0 += 64) {
+      const int ch = c0 + lane;
+      const float w = ch < nch ? __expf(sM[j2][ch] - m) : 0.f;
+      const float lw = ch < nch ? sW[j2][ch] * w : 0.f;
+      if (ch < nch) sW[j2][ch] = w;
+      l += wave_sum(lw);
     }
+    if (lane == 0) sL[j2] = l;
+  }
+  __syncthreads();
+  for (int i = t; i < G * D; i += 256) {
+    const int j2 = i / D, d = i % D;
+    float A = 0.f;
+    int ch = 0;
+    for (; ch + 8 <= nch; ch += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[((size_t)(ch + u) * G + j2) * (D + 2) + 2 + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) A += v[u] * sW[j2][ch + u];
+    }
+    for (; ch < nch; ++ch) A += base[((size_t)ch * G + j2) * (D + 2) + 2 + d] * sW[j2][ch];
+    const float L = sL[j2];
     o[(size_t)seq * ldo + (size_t)(hk * G + j2) * D + d] = f2bf(L > 0.f ? A / L : 0.f);
   }
 }
@@ -463,7 +500,7 @@ hipError_t aigv_launch_attention_decode(const bf16_t* q, int ldq, int q_group_st
                                         const bf16_t* vc, const int32_t* kv_lens, int cap, bf16_t* o, int ldo,
                                         int n_seq, int n_kv, int g, int head_dim, float post_div, int max_kv_len,
                                         float* ws, hipStream_t s) {
-  if (head_dim != 128 || !ws || max_kv_len <= 0 || max_kv_len > cap) return hipErrorInvalidValue;
+  if (head_dim != 128 || !ws || max_kv_len <= 0 || max_kv_len > cap || (cap + DC - 1) / DC > MERGE_MAX_CHUNKS) return hipErrorInvalidValue;
   const int max_chunks = (cap + DC - 1) / DC;
   dim3 grid1((max_kv_len + DC - 1) / DC, n_kv, n_seq), grid2(n_kv, n_seq);
 #define DEC(G)                                                                                                              \
