@@ -1036,6 +1036,40 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
   return 0;
 }
 
+// Replicate the kept sequences: slots [0, B) -> [B, 2B), ... so that `copies` different continuations of every sequence can
+// be extended in ONE pass (the decoder weights are then streamed once for all of them).
+int aigv_kv_fork(aigv_ctx* c, int copies, void* stream) {
+  if (!c) return fail(c, AIGV_ERR_ARG, "aigv_kv_fork: null context");
+  if (!c->kv_valid) return fail(c, AIGV_ERR_STATE, "aigv_kv_fork: no KV state (run aigv_llm_prefill with keep_kv)");
+  const aigv_config& k = c->cfg;
+  const int B = c->kv_seqs;
+  if (copies < 1 || (long)B * copies > k.max_seqs) return fail(c, AIGV_ERR_ARG, "aigv_kv_fork: %d x %d sequences exceed max_seqs %d", B, copies, k.max_seqs);
+  if (copies == 1) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t slot = (size_t)k.llm_kv_heads * k.kv_capacity * c->head_dim;      // elements per sequence and layer
+  const size_t kv_layer = (size_t)k.max_seqs * slot;
+  for (int li = 0; li < k.llm_layers; ++li)
+    for (int cpy = 1; cpy < copies; ++cpy) {
+      HIPCHK(c, hipMemcpyAsync(c->kc + li * kv_layer + (size_t)cpy * B * slot, c->kc + li * kv_layer, (size_t)B * slot * sizeof(bf16_t), hipMemcpyDeviceToDevice, s));
+      HIPCHK(c, hipMemcpyAsync(c->vc + li * kv_layer + (size_t)cpy * B * slot, c->vc + li * kv_layer, (size_t)B * slot * sizeof(bf16_t), hipMemcpyDeviceToDevice, s));
+    }
+  const int N = B * copies;
+  c->h_kvlen.resize(N);
+  c->h_dec.resize((size_t)4 * N);
+  for (int i = 0; i < N; ++i) {
+    const int len = c->h_kvlen[i % B];
+    c->h_kvlen[i] = len;
+    c->h_dec[i] = len; c->h_dec[N + i] = i; c->h_dec[2 * N + i] = len + 1; c->h_dec[3 * N + i] = -1;
+  }
+  HIPCHK(c, aigv_launch_write_ints(c->h_dec.data(), N, c->dec_pos, s));
+  HIPCHK(c, aigv_launch_write_ints(c->h_dec.data() + N, N, c->dec_seq, s));
+  HIPCHK(c, aigv_launch_write_ints(c->h_dec.data() + 2 * N, N, c->dec_kvlen, s));
+  HIPCHK(c, aigv_launch_write_ints(c->h_dec.data() + 3 * N, N, c->dec_slot, s));
+  c->kv_seqs = N;
+  return 0;
+}
+
 int aigv_set_row_trimming(aigv_ctx* c, int on) {
   if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_row_trimming: null context");
   c->trim_last_layer = on != 0;

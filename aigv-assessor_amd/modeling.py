@@ -574,31 +574,45 @@ class InternVLChatModel(nn.Module):
             cu_prefix.append(cu_prefix[-1] + pre[b])
         motion_feature = self._motion_feature(pixel_values, B, motion_feature)
         longest = max(max(pl["lens"]) for pl in plans)
-        self._native(n_frames=n_frames, n_tokens=cu_prefix[-1], n_clips=B, out_rows=max(len(pl["logit_rows"]) for pl in plans),
-                     kv_cap=longest + 1)
+        P = len(plans)
+        n_suffix = sum(pl["cu"][-1] for pl in plans) - P * cu_prefix[-1]
+        self._native(n_frames=n_frames, n_tokens=max(cu_prefix[-1], n_suffix), n_clips=B * P,
+                     out_rows=sum(len(pl["logit_rows"]) for pl in plans), kv_cap=longest + 1)
         vit_embeds, motion = self._visual_inputs(pixel_values, visual_tokens, motion_feature, p0)
         self._prefill(ids_prefix, slot_prefix, cu_prefix, vit_embeds, p0["n_vis"], motion, None, [], keep_kv=True, kv_cap=longest + 1)
         lib, ctx = native.load(), self._ctx
         dev = self.device
-        outs = []
-        for pl, (ids, _, _) in zip(plans, prompts):
-            suffix = torch.cat([pl["ids_packed"][pl["cu"][b] + pre[b]:pl["cu"][b + 1]] for b in range(B)])
-            cu_s = [0]
+        # one cache copy per prompt, then ONE continuation pass over B * P sequences (sequence p * B + b = clip b under prompt p):
+        # the decoder weights are streamed once for all prompts
+        native.check(lib.aigv_kv_fork(ctx, P, native.stream_ptr()), ctx)
+        parts, cu_s, lrows, srows, n_l = [], [0], [], [], []
+        for pl in plans:
+            base = cu_s[-1]
+            starts = []
             for b in range(B):
+                parts.append(pl["ids_packed"][pl["cu"][b] + pre[b]:pl["cu"][b + 1]])
+                starts.append(cu_s[-1])
                 cu_s.append(cu_s[-1] + pl["lens"][b] - pre[b])
-            def local(r):   # packed row of the full prompt -> packed row of the suffix batch
+            def local(r, pl=pl, starts=starts):   # packed row of the full prompt -> packed row of the suffix batch
                 b = max(i for i in range(B) if pl["cu"][i] <= r)
-                return cu_s[b] + (r - pl["cu"][b] - pre[b])
-            lrows = [local(r) for r in pl["logit_rows"]]
-            srows = [local(r) for r in pl["score_rows"]] if pl["score_rows"] is not None else None
-            ids_d = suffix.to(torch.long).contiguous().pin_memory().to(dev, non_blocking=True)
-            score = torch.empty(B, dtype=torch.float32, device=dev) if srows is not None else None
-            amax = torch.empty(max(len(lrows), 1), dtype=torch.long, device=dev)
-            native.check(lib.aigv_llm_extend(ctx, ids_d.data_ptr(), native.i32_array(cu_s), B,
-                                             native.i32_array(srows) if srows is not None else None, native.ptr(score),
-                                             native.i32_array(lrows) if lrows else None, len(lrows), amax.data_ptr(), 0,
-                                             native.stream_ptr()), ctx)
-            outs.append(self._outputs(pl, B, ids.shape[1], score, amax[: len(lrows)], mos))
+                return starts[b] + (r - pl["cu"][b] - pre[b])
+            rows = [local(r) for r in pl["logit_rows"]]
+            lrows += rows
+            n_l.append(len(rows))
+            if pl["score_rows"] is not None:
+                srows += [local(r) for r in pl["score_rows"]]
+        ids_d = torch.cat(parts).to(torch.long).contiguous().pin_memory().to(dev, non_blocking=True)
+        score = torch.empty(B * P, dtype=torch.float32, device=dev) if self.stage == 2 else None
+        amax = torch.empty(max(len(lrows), 1), dtype=torch.long, device=dev)
+        native.check(lib.aigv_llm_extend(ctx, ids_d.data_ptr(), native.i32_array(cu_s), B * P,
+                                         native.i32_array(srows) if score is not None else None, native.ptr(score),
+                                         native.i32_array(lrows) if lrows else None, len(lrows), amax.data_ptr(), 0,
+                                         native.stream_ptr()), ctx)
+        outs, off = [], 0
+        for p, (pl, (ids, _, _)) in enumerate(zip(plans, prompts)):
+            outs.append(self._outputs(pl, B, ids.shape[1], score[p * B:(p + 1) * B] if score is not None else None,
+                                      amax[off:off + n_l[p]], mos))
+            off += n_l[p]
         return outs
 
     # ---- generation (API surface; greedy) -------------------------------------------------------------------

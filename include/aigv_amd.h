@@ -111,6 +111,11 @@ int aigv_llm_prefill(aigv_ctx* ctx, const int64_t* ids, const int32_t* slot, con
 int aigv_llm_extend(aigv_ctx* ctx, const int64_t* ids, const int32_t* cu, int n_clips, const int32_t* score_rows, float* score,
                     const int32_t* logit_rows, int n_logit_rows, int64_t* argmax, int commit, void* stream);
 
+/* Replicate the n kept sequences `copies` times (cache slots [0, n) -> [n, 2n), ...; needs n * copies <= max_seqs): the copies can
+ * then take DIFFERENT continuations in one aigv_llm_extend call over n * copies sequences (sequence c * n + b continues clip b),
+ * which streams the decoder weights once for all of them. */
+int aigv_kv_fork(aigv_ctx* ctx, int copies, void* stream);
+
 /* Last-layer row trimming in aigv_llm_prefill (default on): when at most 64 rows are consumed (score rows + logit rows), the
  * last decoder layer computes attention only for the query blocks holding them and finishes wo / MLP / final norm on a compact
  * copy of those rows.  Rows are independent after attention, so the outputs are those of the untrimmed pass (up to the fp32
