@@ -321,8 +321,33 @@ GemmPlan plan_gemm(int M, int N, int K, int epi) {
   return pl;
 }
 
+// Columns are independent too: N = 256 j + 128 (InternViT-6B: 3200, 9600) would put the whole GEMM on the 128 kernel; instead the
+// first 256 j columns take the row-band plan and only the last 128 columns run on the 128 kernel.
+int split_columns(int M, int N, int K, int epi) {   // width of the right-hand 128-kernel band, 0 = no column split
+  if (g_gemm_mode != 0 || N % 256 != 128 || N < 384 || epi == EPI_PATCH || epi == EPI_SWIGLU) return 0;
+  const int nk = K / 64;
+  const double whole = t128(M, N, nk);
+  const double split = plan_gemm(M, N - 128, K, epi).est_us + t128(M, 128, nk) + LAUNCH_GAP;
+  return split < whole ? 128 : 0;
+}
+
+GemmArgs col_slice(const GemmArgs& a, int n0, int n) {
+  GemmArgs b = a;
+  b.N = n;
+  b.W = a.W + (size_t)n0 * a.ldw;
+  b.C = a.C + n0;
+  if (a.bias) b.bias = a.bias + n0;
+  if (a.ls) b.ls = a.ls + n0;
+  if (a.resid) b.resid = a.resid + n0;
+  return b;
+}
+
 int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
+  if (const int right = split_columns(a.M, a.N, a.K, epi)) {
+    TRY(run_gemm(c, col_slice(a, 0, a.N - right), epi, s));
+    return launch_one(c, col_slice(a, a.N - right, right), epi, false, s);
+  }
   const GemmPlan pl = plan_gemm(a.M, a.N, a.K, epi);
   if (pl.top_tiles < 0) return launch_one(c, a, epi, true, s);
   int row = 0;
@@ -1226,10 +1251,12 @@ int aigv_op_frame_resize_ingest(const void* hwc_u8, int n_frames, int in_h, int 
 int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us) {
   if (!plan || M <= 0 || N <= 0 || K <= 0 || N % 128 || K % 64 || epi < 0 || epi >= EPI_COUNT)
     return fail(nullptr, AIGV_ERR_ARG, "aigv_plan_gemm: bad problem M=%d N=%d K=%d epi=%d", M, N, K, epi);
-  const GemmPlan pl = plan_gemm(M, N, K, epi);
+  const int right = split_columns(M, N, K, epi);
+  const GemmPlan pl = plan_gemm(M, N - right, K, epi);
+  plan[6] = right;
   plan[0] = pl.top_tiles; plan[1] = pl.mid_tiles; plan[2] = pl.mid_slices; plan[3] = pl.last_rows; plan[4] = pl.last_kind;
   plan[5] = pl.last_slices;
-  if (est_us) *est_us = pl.est_us;
+  if (est_us) *est_us = pl.est_us + (right ? t128(M, right, K / 64) + LAUNCH_GAP : 0.0);
   return 0;
 }
 

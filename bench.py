@@ -131,7 +131,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips-per-gpu", type=int, default=4)
     ap.add_argument("--frames", type=int, default=8)
-    ap.add_argument("--model", default="8b", choices=["8b", "tiny"])
+    ap.add_argument("--model", default="8b", choices=["8b", "26b", "tiny"],
+                    help="8b = the headline config; 26b = BASELINE config 4 widths (InternViT-6B + InternLM2-20B; use --frames 16 --clips-per-gpu 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event roofline measurement")
     ap.add_argument("--all-rows", action="store_true", help="A/B: run every row through the last decoder layer (no row trimming)")
@@ -156,7 +157,7 @@ def main():
     from aigv_assessor_amd.dist_utils import score_clips_dp
     from aigv_assessor_amd.modeling import InternVLChatModel
 
-    cfg = pkg.internvl2_8b() if args.model == "8b" else pkg.tiny(image_size=448)
+    cfg = pkg.internvl2_8b() if args.model == "8b" else pkg.internvl2_26b() if args.model == "26b" else pkg.tiny(image_size=448)
     T, Bl = args.frames, args.clips_per_gpu
     B = Bl * world
     N = synth.canonical_len(cfg, T)
@@ -225,7 +226,7 @@ def main():
         fl = flops_per_clip(cfg, T, N, answer_rows=10)
         clips_per_s = B * args.steps / dt
         line = {
-            "metric": "scored clips/sec (8-frame 448x448, InternVL2-8B stage-2 score eval)", "value": clips_per_s,
+            "metric": f"scored clips/sec ({T}-frame {cfg.image_size}x{cfg.image_size}, InternVL2-{args.model.upper()} stage-2 score eval)", "value": clips_per_s,
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",

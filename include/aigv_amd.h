@@ -177,7 +177,9 @@ int aigv_tune_gemm(int mode, double rate256);
 /* The row bands run_gemm would cut an M x N x K problem into (host logic only, no GPU): plan[0] = row tiles (x256 rows) on the
  * 256x256 kernel in whole rounds, or -1 = the whole problem in one launch of that kernel; plan[1] = row tiles on the 256x256
  * kernel with split-K, plan[2] = their K slices; plan[3] = remaining rows, plan[4] = their kernel (0 none, 1 skinny
- * weight-streaming, 2 the 128x128 kernel), plan[5] = split-K slices on the 128x128 kernel (1 = none); est_us = the model's time. */
+ * weight-streaming, 2 the 128x128 kernel), plan[5] = split-K slices on the 128x128 kernel (1 = none); plan[6] = width of a right-hand
+ * column band that runs on the 128x128 kernel over all rows (N = 256 j + 128: plan[0..5] then describe the first 256 j columns;
+ * 0 = no column split); `plan` holds 7 ints; est_us = the model's time. */
 int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us);
 /* Waves per prefill-attention workgroup: 0 = per-shape default, 4 or 8 = forced (32 query rows per wave). */
 int aigv_tune_attention(int waves);

@@ -116,7 +116,8 @@ def test_gemm_epilogues(lib, M, N, K, epi):
 
 @pytest.mark.parametrize("mode", [1, 2 + 16, 2 + 32, 2 + 64, 0])
 @pytest.mark.parametrize("M,N,K,epi", [(1100, 512, 448, 0), (777, 256, 64, 1), (515, 768, 1024, 2), (300, 256, 192, 3),
-                                        (1029, 1024, 512, 4), (256, 256, 128, 0)])
+                                        (1029, 1024, 512, 4), (256, 256, 128, 0),
+                                        (12000, 1408, 256, 0), (12100, 1408, 320, 2), (600, 384, 256, 3)])   # N = 256 j + 128: column split on the big ones
 def test_gemm_tile_kernels_agree(lib, mode, M, N, K, epi):
     """mode 1 = 128x128 kernel, 2 + 16*(1+v) = 256x256 phase-interleaved kernel with schedule variant v,
     0 = cost-model split (256 main + 128/skinny tail)."""

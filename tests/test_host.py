@@ -54,16 +54,16 @@ def test_gemm_row_band_planner(built):
     lib = native.load()
 
     def plan(M, N, K, epi):
-        p, est = (ctypes.c_int * 6)(), ctypes.c_double()
+        p, est = (ctypes.c_int * 7)(), ctypes.c_double()
         native.check(lib.aigv_plan_gemm(M, N, K, epi, p, ctypes.byref(est)))
-        return list(p), est.value
+        return list(p)[:6], est.value, p[6]
 
     shapes = [(8708, 28672, 4096, 4), (8708, 4096, 14336, 3), (8708, 4096, 4096, 3), (8708, 6144, 4096, 0), (32800, 3072, 1024, 0),
               (32800, 4096, 1024, 1), (32800, 1024, 4096, 2), (2177, 4096, 14336, 3), (1, 128, 64, 0), (300, 256, 128, 1), (515, 384, 1024, 2),
               (4354, 6144, 6144, 0), (8192, 4096, 4096, 5), (70, 512, 192, 4)]
     for M, N, K, epi in shapes:
-        (top, mid, ms, last, kind, ls), est = plan(M, N, K, epi)
-        assert est > 0
+        (top, mid, ms, last, kind, ls), est, right = plan(M, N, K, epi)
+        assert est > 0 and right == 0
         if top < 0:
             assert N % 256 == 0 and (mid, last, kind) == (0, 0, 0)
             continue
@@ -79,16 +79,21 @@ def test_gemm_row_band_planner(built):
             assert kind == 2 and (K // 64) % ls == 0 and epi != 5
     # 4 clips x 2177 tokens: the 256 kernel runs whole rounds of 256 tiles (w2: 32 row tiles x 16 = 2 rounds, the next 2 row tiles
     # as one round of 8 K slices), never the 2.125-round launch
-    (top, mid, ms, last, kind, ls), _ = plan(8708, 4096, 14336, 3)
+    (top, mid, ms, last, kind, ls), _, _ = plan(8708, 4096, 14336, 3)
     assert (top * 16) % 256 == 0 and mid * 16 * ms <= 256 and top + mid == 34
+    # InternViT-6B widths (N = 3200, 9600 = 256 j + 128): the first 256 j columns keep the 256 kernel, 128 columns go to the 128 kernel
+    for N in (3200, 9600):
+        (top, mid, ms, last, kind, ls), _, right = plan(16400, N, 3200, 0)
+        assert right == 128 and (top > 0 or top == -1)
+    assert plan(16400, 12800, 3200, 1)[2] == 0 and plan(100, 384, 128, 0)[2] in (0, 128)
     try:
         native.check(lib.aigv_tune_gemm(1, 0.0))
-        assert plan(8708, 4096, 4096, 3)[0] == [0, 0, 0, 8708, 2, 1]
+        assert plan(8708, 4096, 4096, 3)[0] == [0, 0, 0, 8708, 2, 1] and plan(16400, 3200, 3200, 0)[2] == 0
         native.check(lib.aigv_tune_gemm(2, 0.0))
         assert plan(8708, 4096, 4096, 3)[0][0] == -1
     finally:
         native.check(lib.aigv_tune_gemm(0, 0.0))
-    assert lib.aigv_plan_gemm(100, 100, 64, 0, (ctypes.c_int * 6)(), None) != 0      # N % 128
+    assert lib.aigv_plan_gemm(100, 100, 64, 0, (ctypes.c_int * 7)(), None) != 0      # N % 128
 
 
 def test_product_path_never_imports_the_oracle():
