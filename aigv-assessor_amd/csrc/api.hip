@@ -914,7 +914,8 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
     const LlmLayer& L = c->llm[li];
     HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
     TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
-    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, g + 1, g + 2, nkv, D, s));
+    // RoPE: K in place (one of g + 2 slots per group); the query heads are rotated by the attention kernel as it loads them
+    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, 1, g + 2, nkv, D, s, g));
     if (keep_kv)
       HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, T,
                                      nkv, g, D, k.kv_capacity, s));
@@ -929,6 +930,7 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       a.n_heads = k.llm_heads; a.n_kv_heads = nkv;
       a.q_group_stride = a.kv_head_stride = (g + 2) * D;
       a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
+      a.rope_pos = c->l_pos; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       const bool last_trim = trim && li == k.llm_layers - 1;
       a.q_tail = last_trim ? q_tail : 0;
       if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
@@ -1017,7 +1019,8 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
     const LlmLayer& L = c->llm[li];
     HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
     TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
-    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, g + 1, g + 2, nkv, D, s));
+    // RoPE: K in place (one of g + 2 slots per group); the query heads are rotated by the attention kernel as it loads them
+    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, 1, g + 2, nkv, D, s, g));
     HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, T, nkv, g, D,
                                    k.kv_capacity, s));
     {
@@ -1031,6 +1034,7 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
       a.n_heads = k.llm_heads; a.n_kv_heads = nkv;
       a.q_group_stride = (g + 2) * D;
       a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
+      a.rope_pos = c->l_pos; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
       ProfScope ps(c, AIGV_PROF_ATTN_LLM, attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
       HIPCHK(c, aigv_launch_attention(a, D, s));
@@ -1204,6 +1208,21 @@ int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void
   a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
   a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
   a.causal = causal; a.post_div = post_div; a.q_prescale = q_prescale;
+  if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
+  HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));
+  return 0;
+}
+
+int aigv_op_attention_rope(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                           const int32_t* cu, int n_seq, int max_len, int n_heads, int n_kv_heads, int q_group_stride,
+                           int kv_head_stride, int head_dim, int causal, float post_div, float q_prescale, const int32_t* pos,
+                           const void* cos, const void* sin, void* stream) {
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
+  a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
+  a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
+  a.causal = causal; a.post_div = post_div; a.q_prescale = q_prescale;
+  a.rope_pos = pos; a.rope_cos = (const bf16_t*)cos; a.rope_sin = (const bf16_t*)sin;
   if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));
   return 0;

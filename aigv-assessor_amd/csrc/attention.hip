@@ -85,15 +85,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     const int qr = qw + c;
     const bool ok = qr < len;
     const bf16_t* qp = p.q + (size_t)(row0 + (ok ? qr : 0)) * p.ldq + (size_t)(hq / g) * p.q_group_stride + (hq % g) * D;
+    u16x8 raw[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) raw[ks] = *(const u16x8*)(qp + 16 * ks + 8 * h);
+    if (p.rope_cos) {
+      // rotate_half pairs dimension i with i + D/2: k-steps ks and ks + NKS/2 of the same lane (modeling_internlm2.py:247-261)
+      const size_t tb = (size_t)p.rope_pos[row0 + (ok ? qr : 0)] * (D / 2);
+#pragma unroll
+      for (int ks = 0; ks < NKS / 2; ++ks) {
+        const u16x8 co = *(const u16x8*)(p.rope_cos + tb + 16 * ks + 8 * h), si = *(const u16x8*)(p.rope_sin + tb + 16 * ks + 8 * h);
+        const u16x8 lo = raw[ks], hi = raw[ks + NKS / 2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x1 = bf2f(lo[e]), x2 = bf2f(hi[e]), cc = bf2f(co[e]), ss = bf2f(si[e]);
+          raw[ks][e] = f2bf(rbf(x1 * cc) + rbf(-x2 * ss));
+          raw[ks + NKS / 2][e] = f2bf(rbf(x2 * cc) + rbf(x1 * ss));
+        }
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      u16x8 raw = *(const u16x8*)(qp + 16 * ks + 8 * h);
       if (p.q_prescale != 1.0f) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) raw[e] = f2bf(bf2f(raw[e]) * p.q_prescale);
+        for (int e = 0; e < 8; ++e) raw[ks][e] = f2bf(bf2f(raw[ks][e]) * p.q_prescale);
       }
-      if (!ok) raw = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      qf[ks] = __builtin_bit_cast(bf16x8, raw);
+      if (!ok) raw[ks] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8, raw[ks]);
     }
   }
 
@@ -458,6 +475,7 @@ const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
   if (!a.q || !a.k || !a.v || !a.o || !a.cu) return "attention: null operand";
   if ((a.kv_len_offset != 0 || a.kv_off) && !a.kv_seq_stride) return "attention: a key offset needs K/V in cache layout (kv_seq_stride)";
   if (a.kv_len_offset < 0 || (a.kv_seq_stride % 8)) return "attention: bad key offset / cache stride";
+  if ((a.rope_cos != nullptr) != (a.rope_sin != nullptr) || (a.rope_cos && !a.rope_pos)) return "attention: query RoPE needs positions, cos and sin";
   return nullptr;
 }
 

@@ -62,6 +62,9 @@ struct AttnArgs {
   int causal;
   float post_div;               // score = bf16(bf16(q.k) / post_div)  (LLM: sqrt(d); ViT: 1, q is pre-scaled)
   float q_prescale;             // q <- bf16(q * q_prescale)           (ViT: d^-1/2; LLM: 1)
+  // RoPE applied to the QUERY rows as they are loaded (same three bf16 roundings as rope_kernel); K must already be rotated.
+  // null = queries are used as stored.  rope_pos: position of every packed query row; tables [max_pos, D/2] bf16.
+  const int32_t* rope_pos; const bf16_t* rope_cos; const bf16_t* rope_sin;
   int q_tail;                   // > 0: only the last q_tail query rows of every sequence are computed (others left unwritten)
 };
 const char* aigv_attn_check(const AttnArgs& a, int head_dim);
@@ -89,9 +92,9 @@ hipError_t aigv_launch_im2col(const bf16_t* frames, int F, int C, int S, int P, 
 hipError_t aigv_launch_gather_rows(const bf16_t* src, int ld, const int32_t* idx, int n, bf16_t* dst, int H, hipStream_t s);
 hipError_t aigv_launch_cls_rows(const bf16_t* cls_pos, bf16_t* x, int F, int tokens_per_frame, int H, hipStream_t s);
 // RoPE in place on the fused qkv rows: per kv group, slots 0..g (q heads and K) are rotated.
+// slots [first_rot, first_rot + n_rot) of every group are rotated in place (q heads + K: first_rot 0, n_rot g + 1; K only: g, 1)
 hipError_t aigv_launch_rope(bf16_t* qkv, int ld, const int32_t* pos, const bf16_t* cos, const bf16_t* sin,
-                            int tokens, int n_rot_heads_per_group, int slots_per_group, int n_groups, int D,
-                            hipStream_t s);
+                            int tokens, int n_rot, int slots, int n_groups, int D, hipStream_t s, int first_rot = 0);
 // token embedding + visual/motion scatter: slot[t] < 0 -> tok_emb[ids[t]]; < n_vis -> vis[slot]; else motion
 hipError_t aigv_launch_embed(const int64_t* ids, const int32_t* slot, const bf16_t* emb, const bf16_t* vis,
                              const bf16_t* motion, int n_vis, bf16_t* out, int tokens, int H, hipStream_t s);

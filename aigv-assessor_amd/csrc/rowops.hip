@@ -174,7 +174,7 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ src, int ld, const
 // cos/sin tables are [max_pos, D/2] bf16 (the second half of the reference's table repeats the first).
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int ld, const int32_t* __restrict__ pos,
                                                    const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn,
-                                                   int tokens, int n_rot, int slots, int n_groups, int D) {
+                                                   int tokens, int n_rot, int slots, int n_groups, int D, int first_rot) {
   const int half = D >> 1, cph = half >> 3;            // 16-byte chunks per half head
   const int per_tok = n_groups * n_rot * cph;
   const size_t total = (size_t)tokens * per_tok;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, int
     int r = (int)(i - (size_t)t * per_tok);
     const int c = r % cph; r /= cph;
     const int s = r % n_rot, gidx = r / n_rot;
-    bf16_t* base = qkv + (size_t)t * ld + (size_t)(gidx * slots + s) * D + (c << 3);
+    bf16_t* base = qkv + (size_t)t * ld + (size_t)(gidx * slots + first_rot + s) * D + (c << 3);
     const size_t tb = (size_t)pos[t] * half + (c << 3);
     const u16x8 lo = *(const u16x8*)base, hi = *(const u16x8*)(base + half);
     const u16x8 co = *(const u16x8*)(cs + tb), si = *(const u16x8*)(sn + tb);
@@ -328,13 +328,13 @@ hipError_t aigv_launch_gather_rows(const bf16_t* src, int ld, const int32_t* idx
 }
 
 hipError_t aigv_launch_rope(bf16_t* qkv, int ld, const int32_t* pos, const bf16_t* cos, const bf16_t* sin,
-                            int tokens, int n_rot, int slots, int n_groups, int D, hipStream_t s) {
-  if (tokens <= 0) return hipSuccess;
-  if (D % 16) return hipErrorInvalidValue;
+                            int tokens, int n_rot, int slots, int n_groups, int D, hipStream_t s, int first_rot) {
+  if (tokens <= 0 || n_rot <= 0) return hipSuccess;
+  if (D % 16 || first_rot < 0 || first_rot + n_rot > slots) return hipErrorInvalidValue;
   const size_t total = (size_t)tokens * n_groups * n_rot * (D / 16);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, s, qkv, ld, pos, cos, sin, tokens, n_rot, slots,
-                     n_groups, D);
+                     n_groups, D, first_rot);
   return hipGetLastError();
 }
 

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "aigv_op_rmsnorm": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P]),
     "aigv_op_rope": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "aigv_op_attention": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "aigv_op_attention_rope": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "aigv_op_pixel_shuffle": (_I, [_P, _I, _I, _P, _I, _P]),
     "aigv_op_im2col": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "aigv_op_lm_head_argmax": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P]),

@@ -149,6 +149,12 @@ int aigv_op_rope(void* qkv, int ld, const int32_t* pos, const void* cos, const v
 int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
                       const int32_t* cu, int n_seq, int max_len, int n_heads, int n_kv_heads, int q_group_stride,
                       int kv_head_stride, int head_dim, int causal, float post_div, float q_prescale, void* stream);
+/* the same with RoPE applied to the QUERY rows as they are loaded (pos: DEVICE int32 position of every packed row; cos/sin:
+ * DEVICE bf16 [max_pos, head_dim/2]; three bf16 roundings as aigv_op_rope).  K must already be rotated in memory. */
+int aigv_op_attention_rope(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                           const int32_t* cu, int n_seq, int max_len, int n_heads, int n_kv_heads, int q_group_stride,
+                           int kv_head_stride, int head_dim, int causal, float post_div, float q_prescale, const int32_t* pos,
+                           const void* cos, const void* sin, void* stream);
 int aigv_op_pixel_shuffle(const void* vit_out, int grid, int vit_hidden, void* out, int n_frames, void* stream);
 int aigv_op_im2col(const void* frames, int n_frames, int channels, int image_size, int patch, int kp, void* out,
                    void* stream);

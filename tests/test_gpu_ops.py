@@ -396,6 +396,39 @@ def test_attention_matches_eager_reference(lib, d, causal, h, hk, lens):
         off += n
 
 
+def test_attention_with_fused_query_rope_equals_rope_then_attention(lib):
+    """Query RoPE inside the attention kernel's Q load (K rotated in memory by the rope kernel on its slot only) is
+    bit-identical to rotating q and k in memory first: the same three bf16 roundings, only the place differs."""
+    from aigv_assessor_amd.native import ptr
+    d, h, hk, lens = 128, 8, 2, [300, 77, 129]
+    g = h // hk
+    T, ld = sum(lens), hk * (g + 2) * d
+    gen = torch.Generator().manual_seed(3)
+    qkv = torch.randn(T, ld, generator=gen).to(BF)
+    pos = torch.cat([torch.arange(n) for n in lens]).to(torch.int32)
+    ang = torch.arange(0, 400)[:, None].float() * (1.0 / (10000 ** (torch.arange(0, d // 2).float() / (d // 2))))[None, :]
+    cos, sin = ang.cos().to(BF), ang.sin().to(BF)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    dcu, dpos, dcos, dsin = dev(cu), dev(pos), dev(cos), dev(sin)
+    outs = []
+    for fused in (False, True):
+        x = dev(qkv.clone())
+        base = x.data_ptr()
+        # slots per group: g query heads, K, V
+        sync(lib.aigv_op_rope(base, ld, ptr(dpos), ptr(dcos), ptr(dsin), T, 1 if fused else g + 1, g + 2, hk, d, None) if not fused
+             else lib.aigv_op_rope(base + g * d * 2, ld, ptr(dpos), ptr(dcos), ptr(dsin), T, 1, g + 2, hk, d, None), lib)
+        out = torch.full((T, h * d), float("nan"), dtype=BF, device="cuda")
+        args = (base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(dcu), len(lens), max(lens), h, hk,
+                (g + 2) * d, (g + 2) * d, d, 1, math.sqrt(d), 1.0)
+        if fused:
+            sync(lib.aigv_op_attention_rope(*args, ptr(dpos), ptr(dcos), ptr(dsin), None), lib)
+        else:
+            sync(lib.aigv_op_attention(*args, None), lib)
+        outs.append(out.cpu())
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 # ---------------------------------------------------------------------------------------------------------
 # skinny GEMM / lm-head argmax
 # ---------------------------------------------------------------------------------------------------------
