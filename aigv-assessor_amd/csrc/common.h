@@ -18,9 +18,8 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(uint
 // one bf16 rounding point of the reference's eager bf16 path
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// The same GELU, x * 0.5 * (1 + erf(x / sqrt 2)), for the GEMM epilogues (VALU-bound there: libm erff is ~38 instructions
-// with both of its branches live in a wave, this is 15).  With a = min(|x|, 6):
+// erf GELU, x * 0.5 * (1 + erf(x / sqrt 2)), for the GEMM epilogues (VALU-bound there: libm erff is ~38 instructions with both
+// of its branches live in a wave, this is 15).  With a = min(|x|, 6):
 //   Phi(-a) = 2^-(1 + a R(a)),  R = degree-7 fit of (-log2 Phi(-a) - 1) / a on [0, 6]  (one polynomial, one v_exp_f32)
 //   erf(a / sqrt 2) = 1 - 2 Phi(-a), sign copied from x; the final (1 + erf) keeps the reference formula's cancellation
 // Checked over ALL bf16 inputs against torch's CPU bf16 GELU (tests/test_gpu_ops.py): identical bf16 results except for

@@ -8,7 +8,7 @@ typedef uint16_t bf16_t;
 // ---- GEMM ---------------------------------------------------------------------------------------
 enum GemmEpilogue {
   EPI_STORE = 0,     // C = bf16(acc + bias?)
-  EPI_GELU = 1,      // C = bf16(gelu_erf(bf16(acc + bias?)))
+  EPI_GELU = 1,      // C = bf16(gelu(bf16(acc + bias?)))   erf GELU, common.h gelu_fast
   EPI_LS_RESID = 2,  // C = bf16(resid + bf16(bf16(acc + bias?) * ls))
   EPI_RESID = 3,     // C = bf16(resid + bf16(acc + bias?))
   EPI_SWIGLU = 4,    // W = 16-row interleave of (w1, w3); C[M, N/2] = bf16(bf16(silu(bf16(g))) * bf16(u))
