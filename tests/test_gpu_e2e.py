@@ -166,6 +166,47 @@ def test_shared_prefix_scoring_matches_separate_passes():
     assert flips <= 1, flips
 
 
+def test_shared_prefix_with_ragged_clips_and_prompts():
+    """Clips with different prefix lengths (clip 1 drops 7 leading text tokens and is right-padded) under prompts of different
+    lengths: per-sequence key offsets, positions and cache slots of the continuation pass.  Against separate passes."""
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    seed = 41
+    sd = synth.make_state_dict(cfg, seed=seed, rich=True)
+    model = make_model(cfg, sd)
+    base = synth.canonical_tokens(cfg, 2, 2, seed=seed)
+    model.img_context_token_id = base["img_context_token_id"]
+    prompts = synth.perspective_prompts(base, 3, seed=seed, question_lens=(16, 9, 23))
+    drop = 7
+    ragged = []
+    for p in prompts:
+        ids, lab = p["input_ids"], p["labels"]
+        n = ids.shape[1]
+        ids1 = torch.cat([ids[1, drop:], torch.zeros(drop, dtype=torch.long)])
+        lab1 = torch.cat([lab[1, drop:], torch.full((drop,), -100)])
+        am = torch.ones(2, n, dtype=torch.bool)
+        am[1, n - drop:] = False
+        ragged.append((torch.stack([ids[0], ids1]), am, torch.stack([lab[0], lab1])))
+    pv = synth.synthetic_frames(4, 224, seed=seed)
+    motion = synth.synthetic_motion(2, cfg.motion_dim, seed=seed)
+    flags = torch.ones(4, 1, dtype=torch.long)
+    outs = model.forward_shared_prefix(ragged, pixel_values=pv, image_flags=flags, motion_feature=motion)
+    flips = 0
+    for (ids, am, lab), got in zip(ragged, outs):
+        sep = model(mos=None, pixel_values=pv, input_ids=ids, attention_mask=am, image_flags=flags, labels=lab, motion_feature=motion)
+        want = (lab[:, 1:] != -100).reshape(-1)
+        assert int(want.sum()) == 20
+        flips += int((got["logit"].cpu()[want] != sep["logit"].cpu()[want]).sum())
+        assert bool((got["logit"].cpu()[~want] == -1).all())
+        d = (got["score1"].float() - sep["score1"].float()).abs().cpu()
+        assert bool((d <= 2.0 ** -7 * sep["score1"].float().abs().cpu().clamp_min(0.5)).all()), (d, got["score1"], sep["score1"])
+    assert flips <= 1, flips
+    # prompts that diverge inside the video tokens cannot share a prefix
+    bad = ragged[1][0].clone()
+    bad[0, 41] = 5 if int(bad[0, 41]) != 5 else 6          # a text token in front of the first frame's <img>
+    with pytest.raises(ValueError, match="diverge"):
+        model.forward_shared_prefix([ragged[0], (bad, ragged[1][1], ragged[1][2])], pixel_values=pv, image_flags=flags, motion_feature=motion)
+
+
 def test_extend_continues_a_prefill_exactly_like_a_longer_prefill():
     """aigv_llm_extend with commit: prefill(prompt[:-k]) + extend(prompt[-k:]) yields the next token of prefill(prompt), and a
     decode step after the committed extension agrees with the decode step after the full prefill."""
