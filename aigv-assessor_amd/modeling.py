@@ -531,23 +531,10 @@ class InternVLChatModel(nn.Module):
             out["loss"] = F.l1_loss(score1, mos.to(dev).to(score1.dtype)) if mos is not None else None
         return out
 
-    def forward_shared_prefix(self, prompts, pixel_values: Optional[torch.Tensor] = None, image_flags: Optional[torch.Tensor] = None,
-                              motion_feature: Optional[torch.Tensor] = None, visual_tokens: Optional[torch.Tensor] = None, mos=None):
-        """Score the same clips under several prompts that share their beginning - the reference's four quality
-        perspectives ask four questions BEHIND the same system + frame + motion tokens (SURVEY.md Appendix A; 8f-3) and
-        run four full passes (stage2_eval.py evaluates one jsonl per perspective).  Here the common prefix runs once
-        (ViT, projector, LLM prefill into the KV cache); every prompt then only continues its own few question / answer
-        tokens over the cached keys (``aigv_llm_extend``).  ``prompts``: list of ``(input_ids[B, N_p], attention_mask,
-        labels)``; returns the list of ``forward`` result dicts, one per prompt.  Causal attention makes the prefix rows
-        independent of what follows, so each result is that of a separate ``forward`` call up to kernel summation order."""
-        if self.img_context_token_id is None:
-            raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
-        if not prompts:
-            return []
-        n_frames = visual_tokens.shape[0] if visual_tokens is not None else pixel_values.shape[0]
-        plans = [self._plan(ids, am, lab, image_flags, n_frames) for (ids, am, lab) in prompts]
-        B = prompts[0][0].shape[0]
-        # common prefix per clip: identical tokens in every prompt, all <IMG_CONTEXT> tokens inside, every consumed row outside
+    @staticmethod
+    def _shared_prefix_lengths(plans, B: int) -> List[int]:
+        """Per clip: the number of leading tokens every prompt shares, capped so that every consumed row (answer rows, score
+        row) stays in the continuation; raises if the prompts diverge before the last <IMG_CONTEXT> token (host logic only)."""
         pre = []
         for b in range(B):
             seqs = [pl["ids_packed"][pl["cu"][b]:pl["cu"][b + 1]] for pl in plans]
@@ -566,6 +553,25 @@ class InternVLChatModel(nn.Module):
             if p_b <= max(pl["last_ctx"][b] for pl in plans):
                 raise ValueError(f"clip {b}: the prompts diverge before the last <IMG_CONTEXT> token - no shared video prefix")
             pre.append(p_b)
+        return pre
+
+    def forward_shared_prefix(self, prompts, pixel_values: Optional[torch.Tensor] = None, image_flags: Optional[torch.Tensor] = None,
+                              motion_feature: Optional[torch.Tensor] = None, visual_tokens: Optional[torch.Tensor] = None, mos=None):
+        """Score the same clips under several prompts that share their beginning - the reference's four quality
+        perspectives ask four questions BEHIND the same system + frame + motion tokens (SURVEY.md Appendix A; 8f-3) and
+        run four full passes (stage2_eval.py evaluates one jsonl per perspective).  Here the common prefix runs once
+        (ViT, projector, LLM prefill into the KV cache); every prompt then only continues its own few question / answer
+        tokens over the cached keys (``aigv_llm_extend``).  ``prompts``: list of ``(input_ids[B, N_p], attention_mask,
+        labels)``; returns the list of ``forward`` result dicts, one per prompt.  Causal attention makes the prefix rows
+        independent of what follows, so each result is that of a separate ``forward`` call up to kernel summation order."""
+        if self.img_context_token_id is None:
+            raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
+        if not prompts:
+            return []
+        n_frames = visual_tokens.shape[0] if visual_tokens is not None else pixel_values.shape[0]
+        plans = [self._plan(ids, am, lab, image_flags, n_frames) for (ids, am, lab) in prompts]
+        B = prompts[0][0].shape[0]
+        pre = self._shared_prefix_lengths(plans, B)
         p0 = plans[0]
         ids_prefix = torch.cat([p0["ids_packed"][p0["cu"][b]:p0["cu"][b] + pre[b]] for b in range(B)])
         slot_prefix = torch.cat([p0["slot"][p0["cu"][b]:p0["cu"][b] + pre[b]] for b in range(B)])

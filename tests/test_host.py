@@ -96,6 +96,37 @@ def test_gemm_row_band_planner(built):
     assert lib.aigv_plan_gemm(100, 100, 64, 0, (ctypes.c_int * 7)(), None) != 0      # N % 128
 
 
+def test_shared_prefix_planning_is_host_logic():
+    """forward_shared_prefix's bookkeeping (no GPU): the shared prefix ends where the prompts start to differ, never inside the
+    video tokens, and every consumed row (answer rows, the score row at -4) stays in the continuation."""
+    cfg = pkg.tiny(image_size=224)
+    model = InternVLChatModel(cfg)
+    base = synth.canonical_tokens(cfg, 2, 2, seed=3)
+    model.img_context_token_id = base["img_context_token_id"]
+    prompts = synth.perspective_prompts(base, 3, seed=3, question_lens=(16, 9, 23))
+    flags = torch.ones(4, 1, dtype=torch.long)
+    plans = [model._plan(p["input_ids"], p["attention_mask"], p["labels"], flags, 4) for p in prompts]
+    pre = model._shared_prefix_lengths(plans, 2)
+    n0 = base["input_ids"].shape[1]
+    cut = n0 - 16 - 10                                     # first question token of the canonical layout
+    assert pre == [cut, cut]
+    for pl in plans:
+        for b in range(2):
+            assert pl["last_ctx"][b] < pre[b]              # all <IMG_CONTEXT> tokens inside the prefix
+            rows = [r - pl["cu"][b] for r in pl["logit_rows"] if pl["cu"][b] <= r < pl["cu"][b + 1]] + [pl["score_rows"][b] - pl["cu"][b]]
+            assert min(rows) >= pre[b]
+    # identical prompts: the prefix stops in front of the first consumed row, not at the end
+    same = [plans[0], plans[0]]
+    p_same = model._shared_prefix_lengths(same, 2)
+    assert p_same[0] == min(min(r for r in plans[0]["logit_rows"] if r < plans[0]["cu"][1]), plans[0]["score_rows"][0])
+    # a difference in front of the video tokens leaves nothing to share
+    ids = prompts[1]["input_ids"].clone()
+    ids[0, 3] = 5 if int(ids[0, 3]) != 5 else 6
+    bad = model._plan(ids, prompts[1]["attention_mask"], prompts[1]["labels"], flags, 4)
+    with pytest.raises(ValueError, match="diverge"):
+        model._shared_prefix_lengths([plans[0], bad], 2)
+
+
 def test_product_path_never_imports_the_oracle():
     for root, _, files in os.walk(os.path.join(ROOT, "aigv-assessor_amd")):
         for f in files:
