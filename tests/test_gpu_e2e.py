@@ -207,6 +207,37 @@ def test_shared_prefix_with_ragged_clips_and_prompts():
         model.forward_shared_prefix([ragged[0], (bad, ragged[1][1], ragged[1][2])], pixel_values=pv, image_flags=flags, motion_feature=motion)
 
 
+def test_shared_prefix_with_a_long_continuation():
+    """A 210-token question: the continuation spans two 128-row query blocks of the attention kernel, each with the cached
+    prefix in front (key offsets + causal masking across the block boundary)."""
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    seed = 43
+    sd = synth.make_state_dict(cfg, seed=seed, rich=True)
+    model = make_model(cfg, sd)
+    base = synth.canonical_tokens(cfg, 2, 2, seed=seed)
+    model.img_context_token_id = base["img_context_token_id"]
+    prompts = synth.perspective_prompts(base, 2, seed=seed, question_lens=(16, 210))
+    pv = synth.synthetic_frames(4, 224, seed=seed)
+    motion = synth.synthetic_motion(2, cfg.motion_dim, seed=seed)
+    flags = torch.ones(4, 1, dtype=torch.long)
+    outs = model.forward_shared_prefix([(p["input_ids"], p["attention_mask"], p["labels"]) for p in prompts], pixel_values=pv,
+                                       image_flags=flags, motion_feature=motion)
+    flips = 0
+    for p, got in zip(prompts, outs):
+        sep = model(mos=None, pixel_values=pv, input_ids=p["input_ids"], attention_mask=p["attention_mask"], image_flags=flags,
+                    labels=p["labels"], motion_feature=motion)
+        want = (p["labels"][:, 1:] != -100).reshape(-1)
+        flips += int((got["logit"].cpu()[want] != sep["logit"].cpu()[want]).sum())
+        d = (got["score1"].float() - sep["score1"].float()).abs().cpu()
+        assert bool((d <= 2.0 ** -7 * sep["score1"].float().abs().cpu().clamp_min(0.5)).all()), (d, got["score1"], sep["score1"])
+    assert flips <= 1, flips
+    # the long prompt also agrees with the oracle run on its own
+    ref = O.forward_eval(sd, cfg, pv, prompts[1]["input_ids"], prompts[1]["attention_mask"], flags, prompts[1]["labels"], motion,
+                         prompts[1]["img_context_token_id"], mos=None, stage=2, return_intermediates=True)
+    check_levels(outs[1], ref)
+    score_ok(outs[1]["score1"], ref["score1"])
+
+
 def test_extend_continues_a_prefill_exactly_like_a_longer_prefill():
     """aigv_llm_extend with commit: prefill(prompt[:-k]) + extend(prompt[-k:]) yields the next token of prefill(prompt), and a
     decode step after the committed extension agrees with the decode step after the full prefill."""
