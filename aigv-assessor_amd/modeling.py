@@ -467,7 +467,7 @@ class InternVLChatModel(nn.Module):
                                     plan["score_rows"], plan["logit_rows"])
         return self._outputs(plan, B, N, score, amax, mos)
 
-    def _plan(self, input_ids, attention_mask, labels, image_flags, n_frames, full_logits=False):
+    def _plan(self, input_ids, attention_mask, labels, image_flags, n_frames, full_logits=False, drop_dead_tail=None):
         """Host-side token bookkeeping of one pass: packed ids, which packed row takes which visual / motion token
         (modeling_internvl_chat.py:351-378), and the rows whose outputs are consumed."""
         B, N = input_ids.shape
@@ -504,6 +504,36 @@ class InternVLChatModel(nn.Module):
         score_rows = [cu[i + 1] - 4 for i in range(B)] if self.stage == 2 else None
         if score_rows is not None and min(lens) < 4:
             raise ValueError("clips need at least 4 tokens for the score row hidden[:, -4]")
+        # Dead trailing tokens: with causal attention a token influences only later rows, so whatever follows a clip's last
+        # consumed row (the closing <|im_end|>, whose own logits the reference drops with shift_logits = logits[:, :-1],
+        # modeling_internvl_chat.py:451-455) changes no returned value.  Such text tokens are not run at all - for the
+        # canonical clip 2177 -> 2176 = 17 x 128 rows, which also removes the ragged row tile / query block of every kernel.
+        if drop_dead_tail is None:
+            drop_dead_tail = getattr(self, "drop_dead_tail", True)
+        if drop_dead_tail and not full_logits:
+            last_needed = [cu[b] for b in range(B)]
+            for r in logit_rows + (score_rows or []):
+                b = int(seq_of[r])
+                last_needed[b] = max(last_needed[b], r + 1)
+            keep_row = torch.zeros(ids_packed.numel(), dtype=torch.bool)
+            for b in range(B):
+                end = max(last_needed[b], cu[b] + 1)
+                if bool((slot[end:cu[b + 1]] >= 0).any()):      # never drop a visual / motion slot
+                    end = cu[b + 1]
+                keep_row[cu[b]:end] = True
+            if not bool(keep_row.all()):
+                new_index = torch.cumsum(keep_row.long(), 0) - 1
+                remap = lambda rows: [int(new_index[r]) for r in rows]
+                logit_rows = remap(logit_rows)
+                score_rows = remap(score_rows) if score_rows is not None else None
+                last_pos = new_index[last_pos]
+                kept = keep_row.nonzero().flatten()
+                row_of = torch.where(row_of >= 0, torch.where(keep_row[row_of.clamp_min(0)], new_index[row_of.clamp_min(0)], torch.full_like(row_of, -1)), row_of)
+                ids_packed, slot, seq_of = ids_packed[kept], slot[kept], seq_of[kept]
+                lens = [int((seq_of == b).sum()) for b in range(B)]
+                cu = [0]
+                for x in lens:
+                    cu.append(cu[-1] + x)
         return dict(ids_h=ids_h, mask_h=mask_h, labels_h=labels_h, flags_h=flags_h, ids_packed=ids_packed, cu=cu, row_of=row_of,
                     lens=lens, slot=slot, n_vis=n_vis, keep=keep, n_frames=n_frames, want=want, logit_rows=logit_rows,
                     score_rows=score_rows, last_ctx=(last_pos - torch.tensor(cu[:-1])).tolist())
@@ -803,6 +833,7 @@ class InternVLChatModel(nn.Module):
         through every layer, as the reference computes it; the returned values are the same."""
         lib, ctx = self._native()
         native.check(lib.aigv_set_row_trimming(ctx, int(on)), ctx)
+        self.drop_dead_tail = bool(on)      # the host-side half: tokens behind a clip's last consumed row are not run
 
     # ---- measurement ---------------------------------------------------------------------------------------
     def prof_enable(self, on: bool = True):

@@ -47,9 +47,13 @@ def flops_per_clip(cfg, T, N, answer_rows):
     # independent after attention, so the rest of that layer is as dead as the unused logits rows.  `executed` is the work
     # this build runs (row trimming on); `total` stays SURVEY.md's figure, the one `achieved` rates are quoted on.
     rows = answer_rows + 1
-    dead = (N - rows) * (2 * H * H + 6 * H * I) + 4 * H * (N * (N + 1) / 2 - rows * N)
+    # the closing <|im_end|> of every clip is dead in every layer (nothing consumed attends to it; the reference drops its logits
+    # with shift_logits): the build runs N - 1 rows per clip
+    Ne = N - 1
+    llm_e = Ne * L * (2 * H * (l.num_attention_heads + 2 * l.num_key_value_heads) * d + 2 * H * H + 6 * H * I) + L * 4 * H * Ne * (Ne + 1) / 2
+    dead = (Ne - rows) * (2 * H * H + 6 * H * I) + 4 * H * (Ne * (Ne + 1) / 2 - rows * Ne)
     return dict(vit=vit, projector=proj, llm=llm, logits=logits, total=vit + proj + llm + logits,
-                executed=vit + proj + llm + logits - dead)
+                executed=vit + proj + llm_e + logits - dead)
 
 
 def cpu_baseline(cfg, T, N, budget_s=30.0):
