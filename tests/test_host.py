@@ -127,6 +127,41 @@ def test_shared_prefix_planning_is_host_logic():
         model._shared_prefix_lengths([plans[0], bad], 2)
 
 
+def test_dead_trailing_tokens_are_planned_away():
+    """Host bookkeeping (no GPU): tokens behind a clip's last consumed row are dropped from the packed batch, consumed rows keep
+    pointing at the same tokens, visual slots are never dropped, and the switch restores the reference's full row set."""
+    cfg = pkg.tiny(image_size=224)
+    model = InternVLChatModel(cfg)
+    t = synth.canonical_tokens(cfg, 2, 2, seed=5)
+    model.img_context_token_id = t["img_context_token_id"]
+    flags = torch.ones(4, 1, dtype=torch.long)
+    n = t["input_ids"].shape[1]
+    full = model._plan(t["input_ids"], t["attention_mask"], t["labels"], flags, 4, drop_dead_tail=False)
+    trim = model._plan(t["input_ids"], t["attention_mask"], t["labels"], flags, 4)
+    assert full["lens"] == [n, n] and trim["lens"] == [n - 1, n - 1]            # only the closing <|im_end|> is dead
+    assert len(trim["logit_rows"]) == len(full["logit_rows"]) == 20
+    for rt, rf in zip(trim["logit_rows"] + trim["score_rows"], full["logit_rows"] + full["score_rows"]):
+        assert int(trim["ids_packed"][rt]) == int(full["ids_packed"][rf])       # same token behind every consumed row
+    assert torch.equal(trim["slot"][trim["slot"] >= 0], full["slot"][full["slot"] >= 0])
+    assert trim["last_ctx"] == full["last_ctx"]
+    # nothing consumed behind the prompt (stage-2 score only): rows after the score row (-4) go
+    nolab = model._plan(t["input_ids"], t["attention_mask"], torch.full_like(t["labels"], -100), flags, 4)
+    assert nolab["lens"] == [n - 3, n - 3] and nolab["score_rows"] == [n - 4, 2 * (n - 3) - 1]
+    # full_logits keeps every row; the model-level switch too
+    assert model._plan(t["input_ids"], t["attention_mask"], t["labels"], flags, 4, full_logits=True)["lens"] == [n, n]
+    model.drop_dead_tail = False
+    assert model._plan(t["input_ids"], t["attention_mask"], t["labels"], flags, 4)["lens"] == [n, n]
+    model.drop_dead_tail = True
+    # a visual slot behind the last consumed row protects the tail of that clip
+    ids = t["input_ids"].clone()
+    lab = torch.full_like(t["labels"], -100)
+    m1 = InternVLChatModel(cfg, stage=1)
+    m1.img_context_token_id = t["img_context_token_id"]
+    lab[:, 10] = ids[:, 10]                                                       # one early answer row, image tokens follow
+    early = m1._plan(ids, t["attention_mask"], lab, flags, 4)
+    assert early["lens"] == [n, n]
+
+
 def test_product_path_never_imports_the_oracle():
     for root, _, files in os.walk(os.path.join(ROOT, "aigv-assessor_amd")):
         for f in files:
