@@ -1126,9 +1126,8 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
     const LlmLayer& L = c->llm[li];
     HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, B, H, k.rms_eps, nullptr, s));
     TRY(run_skinny(c, c->l_t, H, B, L.wqkv, H, c->qkv_out, H, nullptr, nullptr, 0, c->l_qkv, c->qkv_out, 0, s));
-    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->dec_pos, c->rope_cos, c->rope_sin, B, g + 1, g + 2, nkv, D, s));
-    HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->dec_seq, c->dec_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, B,
-                                   nkv, g, D, k.kv_capacity, s));
+    HIPCHK(c, aigv_launch_rope_kv_store(c->l_qkv, c->qkv_out, c->dec_seq, c->dec_pos, c->rope_cos, c->rope_sin, c->kc + li * kv_layer,
+                                        c->vc + li * kv_layer, B, nkv, g, D, k.kv_capacity, s));
     HIPCHK(c, aigv_launch_attention_decode(c->l_qkv, c->qkv_out, (g + 2) * D, c->kc + li * kv_layer, c->vc + li * kv_layer,
                                            c->dec_kvlen, k.kv_capacity, c->l_ao, H, B, nkv, g, D, sqrtf((float)D), max_vis,
                                            c->dec_ws, s));

@@ -115,6 +115,10 @@ struct ScoreHeadArgs {
 // scratch: 3 * B * max(dims) bf16; B <= 64 per call
 hipError_t aigv_launch_score_head(const ScoreHeadArgs& a, bf16_t* scratch, hipStream_t s);
 // KV-cache append for decode: copies the K/V slots of fused qkv rows into [n_seq, n_kv, cap, D] caches
+// decode: RoPE (q heads in place, K) + K / V cache append in one launch
+hipError_t aigv_launch_rope_kv_store(bf16_t* qkv, int ld, const int32_t* seq_of_tok, const int32_t* pos, const bf16_t* cos,
+                                     const bf16_t* sin, bf16_t* kc, bf16_t* vc, int tokens, int n_groups, int g, int D, int cap,
+                                     hipStream_t s);
 hipError_t aigv_launch_kv_store(const bf16_t* qkv, int ld, const int32_t* seq_of_tok, const int32_t* pos,
                                 bf16_t* kc, bf16_t* vc, int tokens, int n_groups, int g, int D, int cap,
                                 hipStream_t s);

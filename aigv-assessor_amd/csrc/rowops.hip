@@ -227,6 +227,45 @@ __global__ __launch_bounds__(256) void kv_store_kernel(const bf16_t* __restrict_
   }
 }
 
+// Decode step: RoPE of the new token's q heads and K in place, then K / V appended to the cache - one launch instead of two
+// (a decode layer is a chain of small launches; each costs its latency).  One workgroup per token; chunk c of slot s.
+__global__ __launch_bounds__(256) void rope_kv_store_kernel(bf16_t* __restrict__ qkv, int ld, const int32_t* __restrict__ seq_of_tok,
+                                                            const int32_t* __restrict__ pos, const bf16_t* __restrict__ cs,
+                                                            const bf16_t* __restrict__ sn, bf16_t* __restrict__ kc,
+                                                            bf16_t* __restrict__ vc, int n_groups, int g, int D, int cap) {
+  const int t = blockIdx.x;
+  const int sq = seq_of_tok[t], p = pos[t];
+  const int half = D >> 1, cph = half >> 3, slots = g + 2;
+  // rotated slots: q heads 0..g-1 and K (slot g); V (slot g+1) is copied as is
+  for (int i = threadIdx.x; i < n_groups * (g + 1) * cph; i += 256) {
+    const int c = i % cph, r = i / cph, s = r % (g + 1), gi = r / (g + 1);
+    bf16_t* base = qkv + (size_t)t * ld + (size_t)(gi * slots + s) * D + (c << 3);
+    const size_t tb = (size_t)p * half + (c << 3);
+    const u16x8 lo = *(const u16x8*)base, hi = *(const u16x8*)(base + half);
+    const u16x8 co = *(const u16x8*)(cs + tb), si = *(const u16x8*)(sn + tb);
+    u16x8 olo, ohi;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x1 = bf2f(lo[e]), x2 = bf2f(hi[e]), cc = bf2f(co[e]), ss = bf2f(si[e]);
+      olo[e] = f2bf(rbf(x1 * cc) + rbf(-x2 * ss));
+      ohi[e] = f2bf(rbf(x2 * cc) + rbf(x1 * ss));
+    }
+    if (s < g) {
+      *(u16x8*)base = olo;
+      *(u16x8*)(base + half) = ohi;
+    } else {   // K: straight into the cache (the qkv row's K slot is not read again in a decode step)
+      bf16_t* dst = kc + (((size_t)sq * n_groups + gi) * cap + p) * D + (c << 3);
+      *(u16x8*)dst = olo;
+      *(u16x8*)(dst + half) = ohi;
+    }
+  }
+  for (int i = threadIdx.x; i < n_groups * (D >> 3); i += 256) {
+    const int c = i % (D >> 3), gi = i / (D >> 3);
+    *(u16x8*)(vc + (((size_t)sq * n_groups + gi) * cap + p) * D + (c << 3)) =
+        *(const u16x8*)(qkv + (size_t)t * ld + (size_t)(gi * slots + g + 1) * D + (c << 3));
+  }
+}
+
 // Host bookkeeping arrays travel as KERNEL ARGUMENTS (<= 4 KB), not as memcpys: a pageable hipMemcpyAsync makes the
 // host wait for the stream, which would stop the CPU from running ahead of the GPU.
 __global__ __launch_bounds__(256) void seqpos_kernel(const SmallInts cu, int n_seq, int32_t* __restrict__ pos,
@@ -335,6 +374,15 @@ hipError_t aigv_launch_rope(bf16_t* qkv, int ld, const int32_t* pos, const bf16_
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, s, qkv, ld, pos, cos, sin, tokens, n_rot, slots,
                      n_groups, D, first_rot);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_rope_kv_store(bf16_t* qkv, int ld, const int32_t* seq_of_tok, const int32_t* pos, const bf16_t* cos,
+                                     const bf16_t* sin, bf16_t* kc, bf16_t* vc, int tokens, int n_groups, int g, int D, int cap,
+                                     hipStream_t s) {
+  if (tokens <= 0) return hipSuccess;
+  if (D % 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rope_kv_store_kernel, dim3(tokens), dim3(256), 0, s, qkv, ld, seq_of_tok, pos, cos, sin, kc, vc, n_groups, g, D, cap);
   return hipGetLastError();
 }
 
