@@ -66,7 +66,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     const int total = (int)gridDim.x, bid = blockIdx.x, xcd = bid & 7, q8 = total >> 3, r8 = total & 7;
     v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   }
-  const int qb = v % nqb, hq = (v / nqb) % p.n_heads, seq = v / (nqb * p.n_heads);
+  int qb = v % nqb, grp = v / nqb;
+  if (!CAUSAL && (p.max_len % QB) != 0 && (p.max_len % QB) <= 32 && nqb > 1 && ((int)gridDim.x % (8 * nqb)) == 0) {
+    // Non-causal with a nearly empty last query block per head (ViT: 1025 rows): each XCD runs its full blocks first and the
+    // cheap ragged ones (key-split below) at the end, so the launch drains on short workgroups instead of on full ones.
+    const int chunk = (int)gridDim.x >> 3, gpc = chunk / nqb, j = blockIdx.x >> 3, x = blockIdx.x & 7;
+    const int full = gpc * (nqb - 1);
+    const int gl = j < full ? j / (nqb - 1) : j - full;
+    qb = j < full ? j % (nqb - 1) : nqb - 1;
+    grp = x * gpc + gl;
+  }
+  const int hq = grp % p.n_heads, seq = grp / p.n_heads;
   const int g = p.n_heads / p.n_kv_heads;
   const int hk = hq / g;
   const int row0 = p.cu[seq];
@@ -77,7 +87,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
   if (p.q_tail > 0 && q0 + QB <= len - p.q_tail) return;   // this block's rows are not consumed (last-layer row trimming)
   const int kv_off = p.kv_off ? p.kv_off[seq] : p.kv_len_offset;   // keys in front of this sequence's first query row
   const int kv_len = len + kv_off;                // keys visible in total (plain prefill: offset 0)
-  const int qw = q0 + wave * 32;                  // first query row of this wave
+  // Ragged last block of a NON-causal sequence with at most 32 rows (ViT: 1025 = 8 x 128 + 1): instead of one wave doing the
+  // whole key range for those rows while three idle - the block would last as long as a full one - all waves take the SAME
+  // query slice and every NW-th key tile each; their softmax states are merged through LDS at the end (key split).
+  const bool ksplit = !CAUSAL && NW == 4 && p.q_tail == 0 && (len - q0) <= 32;   // (NW = 4: three published states fit the ring)
+  const int qw = ksplit ? q0 : q0 + wave * 32;    // first query row of this wave
 
   // ---- Q^T fragments: lane (c,h) holds Q[qw+c][16*ks + 8h + j] --------------------------------------
   bf16x8 qf[NKS];
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     // of every tile and joins the barriers, but leaves its SIMD's issue slots to the co-resident workgroups.
     if (CAUSAL && key0 > qw + 31 + kv_off) continue;
     if (qw >= len || (p.q_tail > 0 && qw + 32 <= len - p.q_tail)) continue;
+    if (ksplit && (kt % NW) != wave) continue;
 
     // ---- S^T = K · Q^T -------------------------------------------------------------------------
     f32x16 sacc[2];
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     f32x2 psum2 = f32x2{0.f, 0.f};
     const f32x2 sc2 = f32x2{sc, sc}, nmc2 = f32x2{-mc, -mc};
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < 2; ++st) {
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
         const f32x2 t = __builtin_elementwise_fma(f32x2{sacc[st][e], sacc[st][e + 1]}, sc2, nmc2);
@@ -263,13 +278,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
         sacc[st][e] = pv.x;
         sacc[st][e + 1] = pv.y;
       }
+    }
     float psum = psum2.x + psum2.y;
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
 
     // ---- O^T += V^T · P^T ---------------------------------------------------------------------------
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < 2; ++st) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         typedef __attribute__((ext_vector_type(8))) float f32x8;
@@ -290,6 +306,41 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[dt], 0, 0, 0);
         }
       }
+    }
+  }
+
+  if (ksplit) {
+    // ---- merge the NW key-split states: waves 1.. publish (m, l, O^T) in the K/V ring (free now), wave 0 combines in wave order ----
+    __syncthreads();
+    constexpr int PER_LANE = NDT * 16 + 2;               // floats per lane
+    float* pub = (float*)smem;
+    if (wave > 0) {
+      float* mine = pub + ((size_t)(wave - 1) * 64 + lane) * PER_LANE;
+      mine[0] = m_run; mine[1] = l_run;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine[2 + i * 16 + e] = oacc[i][e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float M = m_run;
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, pub[((size_t)(w - 1) * 64 + lane) * PER_LANE]);
+    const float a0 = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - M) * sc);
+    l_run *= a0;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[i][e] *= a0;
+    for (int w = 1; w < NW; ++w) {
+      const float* o = pub + ((size_t)(w - 1) * 64 + lane) * PER_LANE;
+      const float aw = (o[0] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((o[0] - M) * sc);
+      l_run += o[1] * aw;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[i][e] += o[2 + i * 16 + e] * aw;
+    }
   }
 
   // ---- normalise and store: lane (c,h) owns O[qw+c][32*dt + 8*(e>>2) + 4h + (e&3)] -------------------------
