@@ -26,7 +26,9 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
                                                      int ldr, bf16_t* __restrict__ out, int ldo,
                                                      unsigned long long* __restrict__ packed,
                                                      const bf16_t* __restrict__ ls) {
-  constexpr int NS = (EPI == SK_SWIGLU) ? 2 : 1;   // W slabs per workgroup
+  // W slabs (16 rows each) per workgroup.  The lm-head on the answer rows (40+ x rows) is bound by re-reading the x fragments
+  // from L2 once per workgroup, not by streaming W: four slabs per workgroup share them.
+  constexpr int NS = (EPI == SK_SWIGLU) ? 2 : (EPI == SK_ARGMAX && RT >= 2) ? 4 : 1;
   __shared__ float part[3][NS][RT][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -100,13 +102,15 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
     if constexpr (EPI == SK_ARGMAX) {
       unsigned long long best = 0ull;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = n0 + 4 * fq + e;
-        if (n < N) {
-          const unsigned long long key = ((unsigned long long)ord_f32(rbf(acc[0][t][e])) << 32) | (0xFFFFFFFFu - (unsigned)n);
-          best = key > best ? key : best;
+      for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + sl * 16 + 4 * fq + e;
+          if (n < N) {
+            const unsigned long long key = ((unsigned long long)ord_f32(rbf(acc[sl][t][e])) << 32) | (0xFFFFFFFFu - (unsigned)n);
+            best = key > best ? key : best;
+          }
         }
-      }
       unsigned long long o = __shfl_xor(best, 16, 64); best = o > best ? o : best;
       o = __shfl_xor(best, 32, 64); best = o > best ? o : best;
       if (fq == 0 && r < R) atomicMax(packed + r, best);
@@ -224,9 +228,9 @@ template <int EPI>
 hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
                          const bf16_t* resid, int ldr, bf16_t* out, int ldo, unsigned long long* packed,
                          hipStream_t s, const bf16_t* ls = nullptr) {
-  const int ns = (EPI == SK_SWIGLU) ? 2 : 1;
-  const int blocks = (N + 16 * ns - 1) / (16 * ns);
   const int rt = (R + 15) / 16;
+  const int ns = (EPI == SK_SWIGLU) ? 2 : (EPI == SK_ARGMAX && rt >= 2) ? 4 : 1;   // = NS of the kernel
+  const int blocks = (N + 16 * ns - 1) / (16 * ns);
 #define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, EPI>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls)
   switch (rt) {
     case 1: GO(1); break;
