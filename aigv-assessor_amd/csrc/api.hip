@@ -390,11 +390,6 @@ int run_skinny(aigv_ctx* c, const bf16_t* x, int ldx, int R, const bf16_t* W, in
   return 0;
 }
 
-const bf16_t* W(aigv_ctx* c, const std::string& name) {
-  auto it = c->w.find(name);
-  return it == c->w.end() ? nullptr : (const bf16_t*)it->second.p;
-}
-
 int need(aigv_ctx* c, const std::string& name, size_t elems, const bf16_t** out) {
   auto it = c->w.find(name);
   if (it == c->w.end()) return fail(c, AIGV_ERR_STATE, "weight '%s' was never loaded", name.c_str());

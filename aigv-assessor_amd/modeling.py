@@ -25,10 +25,8 @@ Documented deviations from the reference (all outside what its eval scripts exer
 from __future__ import annotations
 
 import ctypes as C
-import json
 import os
-import warnings
-from typing import Dict, Iterable, List, Optional, Tuple
+from typing import Dict, List, Optional
 
 import torch
 import torch.nn as nn

@@ -13,7 +13,7 @@ The canonical token layout is SURVEY.md §8d / Appendix A:  N = 73 + (7 + tokens
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Tuple
 
 import torch
 
