@@ -12,6 +12,10 @@
  * token rows cu_seqlens[b] .. cu_seqlens[b+1]-1 and its positions restart at 0 — what the reference
  * computes for un-padded rows (modeling_internlm2.py:907-912) and for left/right padded batches
  * (:1141-1147).
+ *
+ * Threading: one process per GPU, one launch stream per process (the reference's eval loop is single-threaded too).  A context
+ * is not re-entrant, and the split-K slab scratch and the frame-resize coefficient tables are per-process, grown on first use:
+ * calls on different streams or from different threads must not overlap.
  */
 #ifndef AIGV_AMD_H
 #define AIGV_AMD_H
