@@ -48,19 +48,21 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // 4 k-steps (4 x 16 B per lane per operand) are loaded before their MFMAs so several loads are in flight
+  // DEPTH k-steps (DEPTH x 16 B per lane per operand) are loaded before their MFMAs so several loads are in flight; a decode
+  // GEMV (one x row tile, few workgroups per CU when N is small) needs the deeper form to cover the HBM latency
+  constexpr int DEPTH = (RT == 1 && NS == 1) ? 8 : 4;
   int k = 0;
-  for (; k + 128 <= kper; k += 128) {
-    bf16x8 wf[4][NS], xf[4][RT];
+  for (; k + 32 * DEPTH <= kper; k += 32 * DEPTH) {
+    bf16x8 wf[DEPTH][NS], xf[DEPTH][RT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < DEPTH; ++u) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) wf[u][s] = *(const bf16x8*)(wrow[s] + k + 32 * u);
 #pragma unroll
       for (int t = 0; t < RT; ++t) xf[u][t] = *(const bf16x8*)(xrow[t] + k + 32 * u);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < DEPTH; ++u)
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
