@@ -1167,6 +1167,26 @@ int aigv_op_gemm_splitk256(const void* A, int lda, const void* W_, int ldw, void
   return 0;
 }
 
+int aigv_op_quant_fp8_rows(const void* x_bf16, int ldx, int rows, int K, void* q_e4m3, int ldq, float* row_scale, void* stream) {
+  hipError_t e = aigv_launch_quant_fp8_rows((const bf16_t*)x_bf16, ldx, rows, K, (uint8_t*)q_e4m3, ldq, row_scale, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(nullptr, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "fp8 row quantisation (rows=%d K=%d): %s", rows, K, hipGetErrorString(e));
+  return 0;
+}
+
+int aigv_op_gemm_fp8(const void* A_e4m3, int lda, const void* W_e4m3, int ldw, void* C, int ldc, const float* row_scale,
+                     const float* col_scale, const void* bias, int M, int N, int K, void* stream) {
+  GemmArgs a{};
+  a.A = (const bf16_t*)A_e4m3; a.lda = lda; a.W = (const bf16_t*)W_e4m3; a.ldw = ldw; a.C = (bf16_t*)C; a.ldc = ldc;
+  a.M = M; a.N = N; a.K = K; a.bias = (const bf16_t*)bias; a.row_scale = row_scale; a.col_scale = col_scale;
+  if (ldc < N || (ldc % 4) || lda < K || ldw < K)
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_op_gemm_fp8: bad leading dimension (M=%d N=%d K=%d)", M, N, K);
+  hipError_t e = aigv_launch_gemm256_fp8(a, (hipStream_t)stream);
+  if (e != hipSuccess)
+    return fail(nullptr, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP,
+                "fp8 gemm (M=%d N=%d K=%d; needs N %% 256 == 0, K %% 128 == 0, 16-byte row strides, both scale vectors): %s", M, N, K, hipGetErrorString(e));
+  return 0;
+}
+
 int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W_, int ldw, int N, int K, const void* bias,
                         const void* resid, int ldr, void* out, int ldo, int epi, void* stream) {
   return run_skinny(nullptr, (const bf16_t*)x, ldx, R, (const bf16_t*)W_, ldw, N, K, (const bf16_t*)bias,

@@ -58,8 +58,12 @@ __device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uni
 // VAR bit 1: no s_setprio around the MFMA cluster
 // VAR bit 2: epilogue staged through LDS: each wave transposes its tile so that global loads/stores are 16 B per lane
 //            over whole 128-B row segments (half the store instructions of the 8-B-per-lane direct form)
-template <int EPI, int VAR>
+// FP8 (EPI_STORE only): A / W rows hold e4m3 bytes; the 128-byte K-tile rows, the LDS image and the DMA stream are unchanged (a
+//      64-deep bf16 K-tile and a 128-deep fp8 K-tile are the same bytes), a phase issues eight v_mfma_scale_f32_16x16x128_f8f6f4 with
+//      unit block scales instead of sixteen bf16 MFMAs, and the epilogue multiplies by the per-row and per-column fp32 scales.
+template <int EPI, int VAR, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
+  static_assert(!FP8 || (EPI == EPI_STORE && (VAR & 4) != 0), "the fp8 form has the plain staged epilogue only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,7 +141,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   int offA[2], offB[2];
 #pragma unroll
   for (int kh = 0; kh < 2; ++kh) {
-    const int phys = (kh * 4 + fq) ^ sw;
+    // bf16: k-half kh, 16-B chunk fq of it; fp8: k-group fq owns bytes [32 fq, 32 fq + 32) = chunks 2 fq, 2 fq + 1
+    const int phys = (FP8 ? (2 * fq + kh) : (kh * 4 + fq)) ^ sw;
     offA[kh] = (g * 64 + fr) * 128 + phys * 16;     // + mt*16*128
     offB[kh] = (wc * 32 + fr) * 128 + phys * 16;    // + nt*16*128
   }
@@ -173,8 +178,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) fa[mt][kh] = *(const bf16x8*)(sb + unit * UNIT + offA[kh] + mt * 2048);
   };
+  typedef int v8i_t __attribute__((ext_vector_type(8)));
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  auto cat = [](bf16x8 lo, bf16x8 hi) {   // two 16-B fragment reads = the 32 e4m3 bytes of one lane's k-group
+    const v4i_t l = __builtin_bit_cast(v4i_t, lo), h = __builtin_bit_cast(v4i_t, hi);
+    return v8i_t{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+  };
   auto mfma16 = [&](auto J, auto SET) {
     constexpr int j = decltype(J)::value, st = decltype(SET)::value;
+    if constexpr (FP8) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const v8i_t fav = cat(fa[mt][0], fa[mt][1]);
+          if constexpr (j == 0) acc[0][mt][0][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(fb0[st][nt][0], fb0[st][nt][1]), fav, acc[0][mt][0][nt], 0, 0, 0, 127, 0, 127);
+          if constexpr (j == 1) acc[0][mt][1][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(fb1[nt][0], fb1[nt][1]), fav, acc[0][mt][1][nt], 0, 0, 0, 127, 0, 127);
+          if constexpr (j == 2) acc[1][mt][1][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(fb1[nt][0], fb1[nt][1]), fav, acc[1][mt][1][nt], 0, 0, 0, 127, 0, 127);
+          if constexpr (j == 3) acc[1][mt][0][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(fb0[st][nt][0], fb0[st][nt][1]), fav, acc[1][mt][0][nt], 0, 0, 0, 127, 0, 127);
+        }
+      return;
+    }
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -371,6 +395,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           bcol[nh][nt] = p.bias ? *(const u32x2*)(p.bias + n) : u32x2{0u, 0u};
         }
     }
+    f32x4 wsc[2][2];   // fp8: per-column scales of this lane's 4 + 4 + 4 + 4 columns
+    if constexpr (FP8) {
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) wsc[nh][nt] = *(const f32x4*)(p.col_scale + n0 + wc * 64 + nh * 32 + nt * 16 + fq * 4);
+    }
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
@@ -399,6 +430,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
               for (int h = 0; h < 2; ++h) {
                 f32x2 v = f32x2{acc[mh][mt][nh][nt][2 * h], acc[mh][mt][nh][nt][2 * h + 1]};
+                if constexpr (FP8) {   // (acc * row scale) * column scale, fp32
+                  const float rs = p.row_scale[min(m0 + g * 128 + mh * 64 + mt * 16 + fr, p.M - 1)];
+                  v = (v * rs) * f32x2{wsc[nh][nt][2 * h], wsc[nh][nt][2 * h + 1]};
+                }
                 if (p.bias) v += unpack_bf2(bcol[nh][nt][h]);   // wave-uniform branch
                 if constexpr (EPI == EPI_GELU) v = gelu_fast2(rbf2(v));
                 o[h] = pack_bf2(v);
@@ -534,6 +569,23 @@ bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % T
 
 // split-K slices of the 256 kernel: grid.y = a.k_slices workgroups per tile, each writes fp32 partial sums of its K range into
 // a.part[slice][M][N] (summed in slice order by gemm_finalize_kernel, gemm.hip)
+// fp8: a.K / a.lda / a.ldw arrive in e4m3 ELEMENTS; the kernel addresses the same bytes as pairs (its bf16_t unit)
+hipError_t aigv_launch_gemm256_fp8(const GemmArgs& a, hipStream_t s) {
+  if (a.M < 1 || a.N % TN || a.K % 128 || (a.lda % 16) || (a.ldw % 16) || !a.row_scale || !a.col_scale || !a.A || !a.W || !a.C)
+    return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_STORE, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  GemmArgs b = a;
+  b.K = a.K / 2; b.lda = a.lda / 2; b.ldw = a.ldw / 2;
+  const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
+  hipLaunchKernelGGL((gemm256_kernel<EPI_STORE, 7, true>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, b);
+  return hipGetLastError();
+}
+
 hipError_t aigv_launch_gemm256_partial(const GemmArgs& a, hipStream_t s) {
   if (!aigv_gemm256_supported(a) || a.k_slices < 1 || (a.K / TK) % a.k_slices || !a.part) return hipErrorInvalidValue;
   static bool attr_set = false;

@@ -29,6 +29,10 @@ struct GemmArgs {
   int np;                       // patches per frame (EPI_PATCH)
   float* part;                  // EPI_PARTIAL: fp32 slabs [k_slices][M][N]
   int k_slices;                 // EPI_PARTIAL: grid.y; each slice covers K / k_slices (a multiple of 64)
+  // fp8 operands (aigv_launch_gemm256_fp8): A / W hold e4m3 bytes (K, lda, ldw counted in PAIRS of bytes so that the rows are the
+  // same 128-byte K-tiles), C = bf16(acc * row_scale[m] * col_scale[n] + bias)
+  const float* row_scale;
+  const float* col_scale;
 };
 
 const char* aigv_gemm_check(const GemmArgs& a, int epi);   // nullptr if the shapes fit the kernel
@@ -38,6 +42,10 @@ hipError_t aigv_launch_gemm(const GemmArgs& a, int epi, hipStream_t s);         
 // (tile256: the slices come from the 256x256 kernel - needs N % 256 == 0)
 hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s, bool tile256 = false);
 hipError_t aigv_launch_gemm256_partial(const GemmArgs& a, hipStream_t s);   // a.part / a.k_slices filled in
+// e4m3 operands on the block-scaled fp8 MFMA (unit block scales; per-row x per-column fp32 scales in the epilogue), EPI_STORE only
+hipError_t aigv_launch_gemm256_fp8(const GemmArgs& a, hipStream_t s);
+// bf16 rows -> e4m3 bytes + one fp32 scale per row (amax / 448); q = e4m3_rne(x * (448 / amax))
+hipError_t aigv_launch_quant_fp8_rows(const bf16_t* x, int ldx, int rows, int K, uint8_t* q, int ldq, float* scale, hipStream_t s);
 bool aigv_gemm256_supported(const GemmArgs& a);
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);        // 256x256 phase-interleaved kernel
 

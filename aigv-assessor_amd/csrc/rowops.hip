@@ -266,6 +266,39 @@ __global__ __launch_bounds__(256) void rope_kv_store_kernel(bf16_t* __restrict__
   }
 }
 
+// ---- fp8 row quantisation (groundwork for BASELINE config 5; not on the bf16 scoring path) ------------------------------------
+// One workgroup per row: amax over the row, scale = amax / 448 (e4m3 max), q = e4m3_rne(x * (448 / amax)) - OCP e4m3 (gfx950's
+// v_cvt_pk_fp8_f32), the same three fp32 operations as the torch oracle in tests/test_gpu_ops.py; an all-zero row gets scale 1.
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ x, int ldx, int K, uint8_t* __restrict__ q,
+                                                             int ldq, float* __restrict__ scale) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  float amax = 0.f;
+  for (int c = threadIdx.x; c < (K >> 3); c += 256) {
+    const u16x8 v = *(const u16x8*)(xr + (c << 3));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f(v[e])));
+  }
+  amax = wave_max(amax);
+  if (lane == 0) red[wave] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float inv = amax > 0.f ? __fdiv_rn(448.0f, amax) : 1.0f;
+  if (threadIdx.x == 0) scale[row] = amax > 0.f ? __fdiv_rn(amax, 448.0f) : 1.0f;
+  uint8_t* qr = q + (size_t)row * ldq;
+  for (int c = threadIdx.x; c < (K >> 3); c += 256) {
+    const u16x8 v = *(const u16x8*)(xr + (c << 3));
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[0]) * inv, bf2f(v[1]) * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[2]) * inv, bf2f(v[3]) * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[4]) * inv, bf2f(v[5]) * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[6]) * inv, bf2f(v[7]) * inv, hi, true);
+    typedef __attribute__((ext_vector_type(2))) int i32x2;
+    *(i32x2*)(qr + (c << 3)) = i32x2{lo, hi};
+  }
+}
+
 // Host bookkeeping arrays travel as KERNEL ARGUMENTS (<= 4 KB), not as memcpys: a pageable hipMemcpyAsync makes the
 // host wait for the stream, which would stop the CPU from running ahead of the GPU.
 __global__ __launch_bounds__(256) void seqpos_kernel(const SmallInts cu, int n_seq, int32_t* __restrict__ pos,
@@ -374,6 +407,13 @@ hipError_t aigv_launch_rope(bf16_t* qkv, int ld, const int32_t* pos, const bf16_
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, s, qkv, ld, pos, cos, sin, tokens, n_rot, slots,
                      n_groups, D, first_rot);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_quant_fp8_rows(const bf16_t* x, int ldx, int rows, int K, uint8_t* q, int ldq, float* scale, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (K <= 0 || K % 8 || ldx % 8 || ldq % 8 || !x || !q || !scale) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(rows), dim3(256), 0, s, x, ldx, K, q, ldq, scale);
   return hipGetLastError();
 }
 

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "aigv_op_gemm": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "aigv_op_gemm_splitk": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "aigv_op_gemm_splitk256": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "aigv_op_quant_fp8_rows": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
+    "aigv_op_gemm_fp8": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "aigv_op_skinny_gemm": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "aigv_op_layernorm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
     "aigv_op_rmsnorm": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P]),

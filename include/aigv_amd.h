@@ -141,6 +141,17 @@ int aigv_op_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C,
 /* the same with the slices computed by the 256x256 kernel (N % 256 == 0): whole row tiles that would not fill a round */
 int aigv_op_gemm_splitk256(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
                            const void* resid, int ldr, int M, int N, int K, int epi, int k_slices, void* ws_f32, void* stream);
+/* fp8 groundwork for BASELINE config 5 (NOT used by the bf16 scoring path; the reference has no fp8 path, so these two are defined by
+ * their own arithmetic and tested against a torch restatement of it):
+ *   aigv_op_quant_fp8_rows: bf16 [rows, K] -> OCP e4m3 bytes [rows, K] + row_scale[rows] = amax / 448 (1 for an all-zero row);
+ *                           q = e4m3_rne(x * (448 / amax)), three fp32 operations, round-to-nearest-even.  K % 8 == 0.
+ *   aigv_op_gemm_fp8:       C[M, N] = bf16((sum_k A[m,k] W[n,k]) * row_scale[m] * col_scale[n] + bias[n]) with e4m3 A [M, K] and
+ *                           W [N, K] (K contiguous), products exact and accumulated in fp32 on v_mfma_scale_f32_16x16x128_f8f6f4
+ *                           (unit block scales) with the 256x256 schedule of the bf16 kernel.  N % 256 == 0, K % 128 == 0,
+ *                           lda / ldw in bytes and multiples of 16; row_scale / col_scale DEVICE float. */
+int aigv_op_quant_fp8_rows(const void* x_bf16, int ldx, int rows, int K, void* q_e4m3, int ldq, float* row_scale, void* stream);
+int aigv_op_gemm_fp8(const void* A_e4m3, int lda, const void* W_e4m3, int ldw, void* C, int ldc, const float* row_scale,
+                     const float* col_scale, const void* bias, int M, int N, int K, void* stream);
 int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W, int ldw, int N, int K, const void* bias,
                         const void* resid, int ldr, void* out, int ldo, int epi, void* stream);
 int aigv_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H,

@@ -552,3 +552,74 @@ def test_frame_resize_rejects_bad_arguments(lib):
     assert lib.aigv_op_frame_resize_ingest(t.data_ptr(), 1, 2, 2, 2, 2, None, None, t.data_ptr(), None, None, None) != 0   # no output
     assert lib.aigv_op_frame_resize_ingest(t.data_ptr(), 1, 0, 2, 2, 2, None, None, t.data_ptr(), t.data_ptr(), None, None) != 0
     assert lib.aigv_op_frame_resize_ingest(t.data_ptr(), 1, 2, 2, 2, 2, None, None, t.data_ptr(), None, t.data_ptr(), None) != 0   # nchw needs mean/std
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp8 groundwork (BASELINE config 5): row quantisation and the e4m3 GEMM, each against a torch restatement of its arithmetic
+# ---------------------------------------------------------------------------------------------------------
+def _quant_ref(x_bf16):
+    x = x_bf16.float()
+    amax = x.abs().amax(dim=-1, keepdim=True)
+    inv = torch.where(amax > 0, torch.full_like(amax, 448.0) / amax, torch.ones_like(amax))   # a true IEEE division (scalar / tensor is rcp * scalar)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return (x * inv).to(torch.float8_e4m3fn), scale.reshape(-1)
+
+
+@pytest.mark.parametrize("rows,K", [(7, 128), (300, 4096), (33, 14336), (5, 1032)])
+def test_fp8_row_quantisation_is_bit_exact(lib, rows, K):
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(rows + K)
+    x = (torch.randn(rows, K, generator=g) * torch.rand(rows, 1, generator=g) * 8).to(BF)
+    x[0, : K // 2] = 0
+    if rows > 3:
+        x[3] = 0                                                    # an all-zero row: scale 1, bytes 0
+        x[2, 5] = 300.0                                             # an outlier: everything else lands in the low binades
+    q_ref, s_ref = _quant_ref(x)
+    q = torch.full((rows, K), 0x55, dtype=torch.uint8, device="cuda")
+    sc = torch.full((rows,), -1.0, dtype=torch.float32, device="cuda")
+    sync(lib.aigv_op_quant_fp8_rows(ptr(dev(x)), K, rows, K, ptr(q), K, ptr(sc), None), lib)
+    assert torch.equal(sc.cpu(), s_ref)
+    got, want = q.cpu(), q_ref.view(torch.uint8)
+    same = got == want
+    zero_sign = ((got & 0x7f) == 0) & ((want & 0x7f) == 0)          # +0 / -0 are the same value
+    assert bool((same | zero_sign).all()), int((~(same | zero_sign)).sum())
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(256, 256, 128, False), (300, 512, 1024, True), (1029, 768, 384, False), (2048, 1024, 4096, True)])
+def test_fp8_gemm_matches_its_arithmetic(lib, M, N, K, bias):
+    """e4m3 x e4m3 products are exact in fp32 and the MFMA accumulates in fp32: against the dequantised fp32 matmul, scaled and rounded
+    to bf16 the same way, only the summation order differs -> at most 1 bf16 ulp on a small fraction of the elements."""
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.7).to(BF)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF)
+    b = (torch.randn(N, generator=g) * 0.1).to(BF) if bias else None
+    qa, sa = _quant_ref(a)
+    qw, sw = _quant_ref(w)
+    acc = qa.float().double() @ qw.float().double().t()            # exact products, fp64 sum
+    ref = (acc.float() * sa[:, None]) * sw[None, :]
+    if bias:
+        ref = ref + b.float()
+    want = rb(ref)
+    dA, dW = dev(qa.view(torch.uint8)), dev(qw.view(torch.uint8))
+    dsa, dsw = dev(sa), dev(sw)
+    C = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    sync(lib.aigv_op_gemm_fp8(ptr(dA), K, ptr(dW), K, ptr(C), N, ptr(dsa), ptr(dsw), ptr(dev(b)) if bias else None, M, N, K, None), lib)
+    ulp_check(C, want, frac=0.02, max_ulps=1, atol_rel=2e-5)
+    # and through the quantisation kernel end to end: the same bytes come out of aigv_op_quant_fp8_rows
+    q = torch.empty((M, K), dtype=torch.uint8, device="cuda"); sc = torch.empty(M, dtype=torch.float32, device="cuda")
+    sync(lib.aigv_op_quant_fp8_rows(ptr(dev(a)), K, M, K, ptr(q), K, ptr(sc), None), lib)
+    C2 = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    sync(lib.aigv_op_gemm_fp8(ptr(q), K, ptr(dW), K, ptr(C2), N, ptr(sc), ptr(dsw), ptr(dev(b)) if bias else None, M, N, K, None), lib)
+    assert torch.equal(C2, C)
+
+
+def test_fp8_gemm_rejects_bad_shapes(lib):
+    t = torch.zeros(256 * 256, dtype=torch.uint8, device="cuda")
+    f = torch.ones(256, dtype=torch.float32, device="cuda")
+    c = torch.empty(256, 256, dtype=BF, device="cuda")
+    ok = lambda **kw: lib.aigv_op_gemm_fp8(t.data_ptr(), kw.get("K", 128), t.data_ptr(), kw.get("K", 128), c.data_ptr(), 256, kw.get("sa", f.data_ptr()),
+                                           f.data_ptr(), None, 256, kw.get("N", 256), kw.get("K", 128), None)
+    assert ok() == 0
+    assert ok(N=128) != 0 and ok(K=64) != 0 and ok(sa=None) != 0
+    torch.cuda.synchronize()
