@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "rowops.hip", "head.hip", "ingest.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "rowops.hip", "head.hip", "ingest.hip", "slowfast.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "aigv_amd.h")]
 OUT = os.path.join(HERE, "libaigv_amd.so")
 

@@ -404,6 +404,8 @@ int need(aigv_ctx* c, const std::string& name, size_t elems, const bf16_t** out)
 extern int g_gemm256_variant;
 extern int g_attn_waves;
 
+void aigv_set_error(const char* msg) { g_err = msg ? msg : ""; }
+
 // ==========================================================================================================
 extern "C" {
 

@@ -138,6 +138,8 @@ hipError_t aigv_launch_frame_ingest(const uint8_t* hwc, int n_frames, int H, int
 hipError_t aigv_launch_frame_resize_ingest(const uint8_t* hwc, int n_frames, int in_h, int in_w, int out_h, int out_w,
                                            const float* mean, const float* stdv, uint8_t* tmp_u8, uint8_t* out_u8, bf16_t* out_nchw,
                                            hipStream_t s);
+// records a message for aigv_last_error(NULL) from translation units other than api.hip (thread-local, like every handle-less error)
+void aigv_set_error(const char* msg);
 // a[i] += 1, b[i] += 1 for i < n (decode bookkeeping kept on the device: positions and visible KV lengths)
 hipError_t aigv_launch_advance(int32_t* a, int32_t* b, int n, hipStream_t s);
 // small host int arrays passed by value as kernel arguments (no memcpy, no implicit host/stream sync)

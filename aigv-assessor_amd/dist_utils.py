@@ -95,7 +95,7 @@ def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch
 
 
 def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
-                   image_flags: Optional[torch.Tensor], labels: torch.Tensor, motion_feature: torch.Tensor,
+                   image_flags: Optional[torch.Tensor], labels: torch.Tensor, motion_feature: Optional[torch.Tensor],
                    mos: Optional[torch.Tensor] = None, group=None) -> Dict[str, torch.Tensor]:
     """Score a batch of B clips (F frames in total) over all ranks of `group`; every rank passes the same host
     tensors and gets the full result: {'score1' [B], 'logit' [B*(N-1)], 'label' [B*(N-1)]}.
@@ -129,10 +129,12 @@ def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, a
     if chi > clo:
         sl = slice(clo, chi)
         fl = slice(clo * fpc, chi * fpc)
+        # the SlowFast branch needs all frames of a clip, so it runs with the clip shard (motion_feature=None: the model's own branch)
+        motion_l = motion_feature[sl] if motion_feature is not None else model.motion_feature(pixel_values[fl], chi - clo)
         out = model(mos=None if mos is None else mos[sl], pixel_values=None, input_ids=input_ids[sl],
                     attention_mask=None if attention_mask is None else attention_mask[sl],
                     image_flags=None if image_flags is None else image_flags[fl], labels=labels[sl],
-                    motion_feature=motion_feature[sl], visual_tokens=tokens[fl])
+                    motion_feature=motion_l, visual_tokens=tokens[fl])
         logit_l = out["logit"]
         if "score1" in out:
             score_l = out["score1"].float()

@@ -18,8 +18,10 @@ Documented deviations from the reference (all outside what its eval scripts exer
     slices, stage2_eval.py:940-941); other positions are -1 unless ``full_logits=True``.
   * the score row ``hidden[:, -4]`` is taken relative to each clip's true (un-padded) end.
   * a visual-token count mismatch raises instead of overwriting a prefix (modeling_internvl_chat.py:381-386).
-  * the SlowFast motion branch is an input: pass ``motion_feature=[B, 2304]`` or set ``slowfast_model`` to a
-    callable with the reference's interface (pytorchvideo is an un-vendored third-party dependency).
+  * the SlowFast motion branch (``slowfast_model``) is the native ``SlowFastR50`` when the state dict carries
+    ``slowfast_model.*`` tensors (the reference downloads them from pytorchvideo's hub at construction time,
+    which cannot happen offline); otherwise pass ``motion_feature=[B, 2304]`` or set ``slowfast_model`` to a
+    callable with the reference's interface.
   * ``generate`` is greedy (the reference defers to HF ``generate``; its eval configs use do_sample=False).
 """
 from __future__ import annotations
@@ -196,7 +198,7 @@ class InternVLChatModel(nn.Module):
     @classmethod
     def from_pretrained(cls, path, torch_dtype=torch.bfloat16, config: Optional[InternVLChatConfig] = None, **kw):
         """Load ``config.json`` + ``*.safetensors`` / ``pytorch_model*.bin`` shards with the reference's
-        state-dict names (stage2_eval.py:779-780).  SlowFast weights (``slowfast_model.*``) are ignored."""
+        state-dict names (stage2_eval.py:779-780); ``slowfast_model.*`` tensors build the native motion branch."""
         if config is None:
             config = InternVLChatConfig.from_pretrained(path)
         model = cls(config, dtype=torch_dtype, **kw)
@@ -215,6 +217,10 @@ class InternVLChatModel(nn.Module):
         return model
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sf = {k: v for k, v in state_dict.items() if k.startswith("slowfast_model.")}
+        if sf:   # the motion branch's backbone travels in the reference's checkpoints (modeling_internvl_chat.py:253)
+            from .slowfast import SlowFastR50
+            self.slowfast_model = SlowFastR50(sf)
         sd = {k: v for k, v in state_dict.items() if not k.startswith("slowfast_model.")}
         if self.stage == 1:
             sd = {k: v for k, v in sd.items() if not k.startswith("mlpscore.")}
@@ -391,13 +397,19 @@ class InternVLChatModel(nn.Module):
         native.check(lib.aigv_motion_project(ctx, m.data_ptr(), b, out.data_ptr(), native.stream_ptr()), ctx)
         return out
 
+    def motion_feature(self, pixel_values: torch.Tensor, batch: int) -> torch.Tensor:
+        """SlowFast feature [batch, motion_dim] of the clips in ``pixel_values`` [batch * T, 3, S, S] (modeling_internvl_chat.py:336-343)."""
+        return self._motion_feature(pixel_values, batch, None)
+
     def _motion_feature(self, pixel_values, batch, motion_feature):
         if motion_feature is not None:
             return motion_feature
         if self.slowfast_model is None:
             raise RuntimeError("the SlowFast motion branch is an input of this path: pass motion_feature=[B, "
                                f"{self.config.motion_dim}] or set model.slowfast_model (SURVEY.md §2 row 6)")
-        # reference data flow (modeling_internvl_chat.py:337-344, pack_pathway_output :97-133)
+        if hasattr(self.slowfast_model, "features"):     # the native branch reads pixel_values as they are and samples the slow pathway itself
+            return self.slowfast_model.features(pixel_values.to(self.device), batch)
+        # a user-supplied callable: reference data flow (modeling_internvl_chat.py:337-344, pack_pathway_output :97-133)
         S = self.config.image_size
         frames = pixel_values.view(batch, pixel_values.shape[0] // batch, 3, S, S).permute(0, 2, 1, 3, 4)
         idx = torch.linspace(0, frames.shape[2] - 1, frames.shape[2] // 4).long().to(frames.device)

@@ -59,6 +59,13 @@ PROTOTYPES = {
     "aigv_op_gemm": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "aigv_op_gemm_splitk": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "aigv_op_gemm_splitk256": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "aigv_slowfast_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "aigv_slowfast_destroy": (None, [_P]),
+    "aigv_slowfast_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I, _I]),
+    "aigv_slowfast_finalize": (_I, [_P]),
+    "aigv_slowfast_forward": (_I, [_P, _P, _I, _P, _P]),
+    "aigv_slowfast_flops_per_clip": (C.c_double, [_P]),
+    "aigv_op_conv3d": (_I, [_P, _I, _I, _I, C.POINTER(_I), _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "aigv_op_quant_fp8_rows": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "aigv_op_gemm_fp8": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "aigv_op_skinny_gemm": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
@@ -90,6 +97,7 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise NativeError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
                           "there is no CPU fallback for the product path")
+    import torch  # noqa: F401  - before the library: it must bind to the HIP runtime torch has loaded (two runtimes in one process do not share devices)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -212,3 +212,57 @@ def synthetic_motion(n_clips: int, motion_dim: int, seed: int = 0, dtype=torch.b
     """SlowFast feature stand-in (the SlowFast branch is an INPUT: SURVEY.md §2 row 6)."""
     g = torch.Generator(device=device).manual_seed(4321 + seed)
     return torch.rand((n_clips, motion_dim), generator=g, device=device, dtype=torch.float32).to(dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SlowFast-R50 motion branch (SURVEY.md §8f-1): synthetic weights under the reference's state-dict path
+# ---------------------------------------------------------------------------------------------------------
+SLOWFAST_PREFIX = "slowfast_model.feature_extraction."
+SLOWFAST_DEPTHS = (3, 4, 6, 3)
+
+
+def slowfast_conv_shapes() -> List[Tuple[str, str, Tuple[int, ...]]]:
+    """(conv name, norm name, weight shape [Cout, Cin, kt, kh, kw]) for blocks 0..4 of pytorchvideo's ``slowfast_r50`` - the
+    sub-modules the reference keeps (modeling_internvl_chat.py:164-173) - names relative to ``feature_extraction.``."""
+    out: List[Tuple[str, str, Tuple[int, ...]]] = []
+    out.append(("0.multipathway_blocks.0.conv", "0.multipathway_blocks.0.norm", (64, 3, 1, 7, 7)))
+    out.append(("0.multipathway_blocks.1.conv", "0.multipathway_blocks.1.norm", (8, 3, 5, 7, 7)))
+    out.append(("0.multipathway_fusion.conv_fast_to_slow", "0.multipathway_fusion.norm", (16, 8, 7, 1, 1)))
+    cin = [64 + 16, 8]
+    for stage in range(4):
+        for path in (0, 1):
+            inner = (8 if path else 64) << stage
+            cout = 4 * inner
+            kt = 3 if (path == 1 or stage >= 2) else 1
+            for blk in range(SLOWFAST_DEPTHS[stage]):
+                p = f"{stage + 1}.multipathway_blocks.{path}.res_blocks.{blk}."
+                c = cin[path] if blk == 0 else cout
+                if blk == 0:
+                    out.append((p + "branch1_conv", p + "branch1_norm", (cout, c, 1, 1, 1)))
+                out.append((p + "branch2.conv_a", p + "branch2.norm_a", (inner, c, kt, 1, 1)))
+                out.append((p + "branch2.conv_b", p + "branch2.norm_b", (inner, inner, 1, 3, 3)))
+                out.append((p + "branch2.conv_c", p + "branch2.norm_c", (cout, inner, 1, 1, 1)))
+            cin[path] = cout
+        if stage < 3:
+            cf = 32 << stage
+            out.append((f"{stage + 1}.multipathway_fusion.conv_fast_to_slow", f"{stage + 1}.multipathway_fusion.norm", (2 * cf, cf, 7, 1, 1)))
+            cin[0] += 2 * cf
+    return out
+
+
+def slowfast_state_dict(seed: int = 0, prefix: str = SLOWFAST_PREFIX) -> Dict[str, torch.Tensor]:
+    """fp32 tensors: He-initialised convs and perturbed BatchNorm statistics; the last norm of every branch is scaled down
+    so that 16 residual blocks keep activations O(1) in bf16."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    for conv, norm, shape in slowfast_conv_shapes():
+        fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+        sd[prefix + conv + ".weight"] = torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5
+        c = shape[0]
+        gain = 0.25 if norm.endswith("norm_c") else 1.0
+        sd[prefix + norm + ".weight"] = (0.75 + 0.5 * torch.rand(c, generator=g)) * gain
+        sd[prefix + norm + ".bias"] = 0.1 * torch.randn(c, generator=g)
+        sd[prefix + norm + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
+        sd[prefix + norm + ".running_var"] = 0.5 + torch.rand(c, generator=g)
+        sd[prefix + norm + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.int64)
+    return sd

@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--model", default="8b", choices=["8b", "26b", "tiny"],
                     help="8b = the headline config; 26b = BASELINE config 4 widths (InternViT-6B + InternLM2-20B; use --frames 16 --clips-per-gpu 1)")
+    ap.add_argument("--motion", default="slowfast", choices=["slowfast", "input"],
+                    help="slowfast: the SlowFast-R50 branch runs on the frames inside the step, as in the reference's forward; "
+                         "input: motion_feature is a resident synthetic [B, 2304] tensor (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event roofline measurement")
     ap.add_argument("--all-rows", action="store_true", help="A/B: run every row through the last decoder layer (no row trimming)")
@@ -179,7 +182,10 @@ def main():
         model.set_row_trimming(False)
     # inputs resident in HBM before the timed region (token ids are host data in the reference loop; tiny either way)
     pv = synth.synthetic_frames(B * T, cfg.image_size, seed=0, device=dev)
-    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=0, device=dev)
+    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=0, device=dev) if args.motion == "input" else None
+    if args.motion == "slowfast":
+        from aigv_assessor_amd.slowfast import SlowFastR50
+        model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=0))
     flags = torch.ones(B * T, 1, dtype=torch.long)
     ids, labels, am = toks["input_ids"], toks["labels"], toks["attention_mask"]
 
@@ -236,8 +242,10 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"InternVL2-{args.model.upper()} stage-2 score eval, {Bl} clips/GPU x {T} frames x {cfg.image_size}px, "
                                    f"N={N} tokens/clip, canonical token layout (SURVEY.md 8d); random-init weights",
+                       "motion_branch": "SlowFast-R50 on the frames, inside the step" if args.motion == "slowfast" else "synthetic motion_feature input",
                        "global_batch_clips": B, "frames_per_clip": T, "tokens_per_clip": N,
                        "parallelism": f"frame/clip-dp{world}" + (" + RCCL all-gather of visual tokens" if world > 1 else "")},
+            "slowfast_tflop_per_clip": (model.slowfast_model.flops_per_clip() / 1e12 if args.motion == "slowfast" else 0.0),   # not in the figures below
             "algorithmic_tflop_per_clip": fl["total"] / 1e12,
             "executed_tflop_per_clip": (fl["total"] if args.all_rows else fl["executed"]) / 1e12,
             "achieved_tflops_whole_step_per_gpu": (fl["total"] if args.all_rows else fl["executed"]) * B / dt / 1e12 / world * args.steps,

@@ -214,6 +214,29 @@ int aigv_prof_enable(aigv_ctx* ctx, int on);
  * FLOPs (2*M*N*K; attention 4*sum(len_q*len_kv_visible)*d*heads) and bytes per class. */
 int aigv_prof_read(aigv_ctx* ctx, int cls, int64_t* launches, double* total_ms, double* flops, double* bytes);
 
+/* ---- SlowFast-R50 motion branch ---------------------------------------------------------------------
+ * Replaces the reference's ``slowfast`` module + pack_pathway_output (internvl/model/internvl_chat_eval2/modeling_internvl_chat.py:97-193):
+ * frames -> [clips, 2304] motion feature, the input of motion_mlp (aigv_motion_project).  Its own handle: the branch shares nothing
+ * with the scorer context but the frames tensor.  Weights arrive by their state-dict names under
+ * ``slowfast_model.feature_extraction.`` (that prefix, ``feature_extraction.`` or pytorchvideo's ``blocks.`` are all accepted):
+ * conv ``.weight`` [Cout, Cin, kt, kh, kw] and BatchNorm ``.weight/.bias/.running_mean/.running_var``; finalize folds the eval-mode
+ * norms into the convs, packs for the kernel, uploads, and reports missing / mis-shaped tensors by name.
+ *   frames: DEVICE bf16 [clips * T, 3, H, W] NCHW, clip-major (the pixel_values tensor of the scorer); feature: DEVICE bf16 [clips, 2304].
+ *   T a multiple of 4 in [8, 32] (slow pathway = frames linspace(0, T-1, T/4).long()); H, W multiples of 32 in [224, 1024].
+ * Parity with pytorchvideo itself cannot be pinned offline (oracle/slowfast.py restates the published architecture). */
+typedef struct aigv_slowfast aigv_slowfast;
+int aigv_slowfast_create(int device, int max_clips, int frames_per_clip, int height, int width, aigv_slowfast** out);
+void aigv_slowfast_destroy(aigv_slowfast* sf);
+int aigv_slowfast_load_weight(aigv_slowfast* sf, const char* name, const void* host_data, const int64_t* shape, int ndim, int dtype);
+int aigv_slowfast_finalize(aigv_slowfast* sf);
+int aigv_slowfast_forward(aigv_slowfast* sf, const void* frames_nchw_bf16, int clips, void* feature_bf16, void* stream);
+double aigv_slowfast_flops_per_clip(const aigv_slowfast* sf);
+/* one convolution with the branch's implicit-GEMM kernel (tests / profiling): x channels-last bf16 [B, Ti, Hi, Wi, ld_in];
+ * w_packed bf16 [ceil16(Cout), Kp], k = ((dt * kh + dy) * kw + dx) * Cin + ci zero padded to Kp (multiple of 64); bias fp32 [Cout];
+ * dims = {Ti, Hi, Wi, kt, kh, kw, st, sh, sw, pt, ph, pw}; out[row, c_off + c] = relu?(conv + bias + res[row, c]) */
+int aigv_op_conv3d(const void* x, int ld_in, int Cin, int B, const int* dims, const void* w_packed, int Kp, const float* bias, int Cout,
+                   const void* res, int ld_res, void* out, int ld_out, int c_off, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,3 +165,51 @@ def test_frame_resize_restatement_matches_pillow():
     for (h, w, oh, ow) in [(720, 1280, 448, 448), (224, 224, 448, 448), (448, 448, 448, 448), (101, 77, 50, 120)]:
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         assert np.array_equal(resize_bicubic_u8(img, oh, ow), np.asarray(Image.fromarray(img).resize((ow, oh)))), (h, w, oh, ow)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SlowFast-R50 motion branch (oracle/slowfast.py): PARITY UNPINNED against pytorchvideo (absent offline).  What can be
+# anchored: the published parameter count of the architecture, the reference's own pathway packing, and the algebra of
+# the reference's pooling tail that the HIP branch relies on.
+# ---------------------------------------------------------------------------------------------------------
+def test_slowfast_restatement_has_the_published_parameter_count():
+    """pytorchvideo's model zoo lists SlowFast R50 8x8 at 34.57 M parameters; the reference drops the 2304 -> 400 classifier
+    (modeling_internvl_chat.py:171-177), the rest is what oracle/slowfast.py and the HIP branch implement."""
+    from aigv_assessor_amd import synth
+    sd = synth.slowfast_state_dict(0)
+    n = sum(v.numel() for k, v in sd.items() if k.endswith(".weight") or k.endswith(".bias"))
+    assert n == 33_644_488
+    assert round((n + 2304 * 400 + 400) / 1e6, 2) == 34.57
+
+
+def test_slowfast_pathway_packing_and_shapes():
+    from aigv_assessor_amd import synth
+    from oracle import slowfast as osf
+    x = torch.arange(16).float().view(1, 1, 16, 1, 1).expand(1, 3, 16, 1, 1)
+    slow, fast = osf.pack_pathways(x)                                   # modeling_internvl_chat.py:109-115
+    assert slow[0, 0, :, 0, 0].tolist() == [0, 5, 10, 15] and fast.shape[2] == 16
+    sd = synth.slowfast_state_dict(1)
+    frames = torch.randn(1, 3, 8, 224, 224, generator=torch.Generator().manual_seed(0))
+    xs, xf = osf.slowfast_blocks(sd, frames)
+    assert xs.shape == (1, 2048, 2, 7, 7) and xf.shape == (1, 256, 8, 7, 7)
+    assert osf.slowfast_features(sd, frames).shape == (1, 2304)
+
+
+def test_slowfast_pool_tail_is_a_separable_weighted_mean():
+    """repeat_interleave(4) -> AvgPool3d((k,7,7), stride 1) -> AdaptiveAvgPool3d(1) (modeling_internvl_chat.py:183-189) equals
+    sum_t,y,x w_t w_y w_x x[t,y,x] with w = (number of windows covering the position) / (windows x window size): the form
+    the HIP branch computes in one kernel (csrc/slowfast.hip, sf_pool_kernel)."""
+    import torch.nn.functional as F
+
+    def cover(n, k):
+        return torch.tensor([min(i, n - k) - max(i - k + 1, 0) + 1 for i in range(n)], dtype=torch.float64)
+
+    g = torch.Generator().manual_seed(3)
+    for T, k, H, W in ((2, 8, 14, 14), (8, 32, 14, 14), (4, 8, 9, 8), (16, 32, 7, 10)):
+        x = torch.randn(2, 5, T, H, W, generator=g, dtype=torch.float64)
+        want = F.adaptive_avg_pool3d(F.avg_pool3d(x.repeat_interleave(4, dim=2), (k, 7, 7), (1, 1, 1)), 1).flatten(1)
+        L = 4 * T
+        wt = cover(L, k).view(T, 4).sum(1) / ((L - k + 1) * k)
+        wy, wx = cover(H, 7) / ((H - 6) * 7), cover(W, 7) / ((W - 6) * 7)
+        got = torch.einsum("bcthw,t,h,w->bc", x, wt, wy, wx)
+        assert torch.allclose(got, want, rtol=1e-12, atol=1e-12)
