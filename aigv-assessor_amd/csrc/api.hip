@@ -32,6 +32,11 @@ struct LlmLayer {
   const bf16_t *wqkv, *wo, *w13, *w2, *an, *fn;
 };
 
+struct LlmLayerFp8 {   // e4m3 copies of a decoder layer's weights, one fp32 scale per output channel (aigv_set_precision)
+  uint8_t *wqkv = nullptr, *wo = nullptr, *w13 = nullptr, *w2 = nullptr;
+  float *s_wqkv = nullptr, *s_wo = nullptr, *s_w13 = nullptr, *s_w2 = nullptr;
+};
+
 struct ProfRec {
   int cls;
   hipEvent_t a, b;
@@ -65,6 +70,11 @@ struct aigv_ctx {
   int32_t *l_pos = nullptr, *l_seq = nullptr, *l_cu = nullptr, *l_rowidx = nullptr, *l_kvlen = nullptr;
   unsigned long long* l_packed = nullptr;
   int32_t* l_neg1 = nullptr;   // max_tokens x int32 -1: the "plain text token" slot map of aigv_llm_extend
+  // fp8 mode of the InternLM2 prefill GEMMs (aigv_set_precision): weights quantised once, activations per row on the fly
+  bool fp8_llm = false;
+  std::vector<LlmLayerFp8> llm8;
+  uint8_t* q8 = nullptr;       // [max_tokens, max(H, I)] e4m3 activations of the GEMM about to run
+  float* q8_scale = nullptr;   // [max_tokens]
   bool trim_last_layer = true;
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 3 (attention out, hidden, normed) + [64, I]
   bf16_t* l_score_ws = nullptr;
@@ -381,6 +391,65 @@ GemmArgs gemm_args(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C
   return a;
 }
 
+// One InternLM2 linear in fp8 mode: quantise the bf16 activation rows (per-row amax / 448), then the e4m3 form of the 256 kernel with
+// the bf16 path's epilogue.  The quantisation pass is outside the profiled launch (it is not GEMM work).
+int run_gemm_fp8(aigv_ctx* c, const bf16_t* A, int lda, int K, const uint8_t* W8, const float* w_scale, bf16_t* C, int ldc, int T, int N,
+                 int epi, const bf16_t* resid, int ldr, hipStream_t s) {
+  hipError_t e = hipSuccess;
+  if (A) {   // A == nullptr: c->q8 / c->q8_scale already hold the quantised rows (RMSNorm fused with the quantisation)
+    e = aigv_launch_quant_fp8_rows(A, lda, T, K, c->q8, K, c->q8_scale, s);
+    if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "fp8 activation quantisation (T=%d K=%d): %s", T, K, hipGetErrorString(e));
+  }
+  GemmArgs a{};
+  a.A = (const bf16_t*)c->q8; a.lda = K; a.W = (const bf16_t*)W8; a.ldw = K; a.C = C; a.ldc = ldc; a.M = T; a.N = N; a.K = K;
+  a.row_scale = c->q8_scale; a.col_scale = w_scale; a.resid = resid; a.ldr = ldr;
+  ProfScope ps(c, AIGV_PROF_GEMM_FP8, 2.0 * T * (double)N * K, (double)T * K + (double)N * K + 2.0 * T * (epi == EPI_SWIGLU ? N / 2 : N), s);
+  // Row bands as in run_gemm: the rows that make WHOLE rounds of 256 tiles in one launch; the rest - a partial round - as K slices
+  // (scaled fp32 slabs + the bf16 path's finalize pass) when that fills the chip better, else as one more plain launch.
+  auto rows8 = [&](int row0, int rows) {   // row_slice for byte-addressed A
+    GemmArgs b = a;
+    b.M = rows;
+    b.A = (const bf16_t*)(c->q8 + (size_t)row0 * K);
+    b.C = a.C + (size_t)row0 * a.ldc;
+    b.row_scale = a.row_scale + row0;
+    if (a.resid) b.resid = a.resid + (size_t)row0 * a.ldr;
+    return b;
+  };
+  const int tn = N / 256, rt = (T + 255) / 256, nk = K / 128;
+  int unit = 256;   // row tiles per whole number of rounds: 256 / gcd(256, tn)
+  for (int g2 = 256; g2 >= 1; g2 >>= 1)
+    if (tn % g2 == 0) { unit = 256 / g2; break; }
+  int R = (T / 256) / unit * unit;
+  if ((rt - R) * tn > 128) R = 0;   // a tail of more than half a round runs best inside ONE launch (measured: w1|w3 at batch 4, 14.875 rounds)
+  int row = 0;
+  if (R > 0) {
+    e = aigv_launch_gemm256_fp8(rows8(0, R * 256), epi, s);
+    if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "fp8 gemm (M=%d N=%d K=%d epi=%d): %s", T, N, K, epi, hipGetErrorString(e));
+    row = R * 256;
+  }
+  if (row < T) {
+    const GemmArgs b = rows8(row, T - row);
+    const int tail_tiles = (rt - R) * tn;
+    int S = 1;
+    if (tail_tiles <= 128 && R > 0)
+      for (int cand : {8, 6, 4, 3, 2})
+        if (nk % cand == 0 && nk / cand >= 4 && tail_tiles * cand <= 288 && (size_t)cand * b.M * N <= SPLITK_MAX_FLOATS) { S = cand; break; }
+    if (S >= 2) {
+      const size_t need = (size_t)S * b.M * N;
+      if (need > g_splitk_floats) {
+        if (g_splitk_ws) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(g_splitk_ws)); g_splitk_ws = nullptr; g_splitk_floats = 0; }
+        HIPCHK(c, hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
+        g_splitk_floats = need;
+      }
+      e = aigv_launch_gemm_splitk_fp8(b, epi, S, g_splitk_ws, s);
+    } else {
+      e = aigv_launch_gemm256_fp8(b, epi, s);
+    }
+    if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "fp8 gemm tail (M=%d N=%d K=%d epi=%d): %s", b.M, N, K, epi, hipGetErrorString(e));
+  }
+  return 0;
+}
+
 int run_skinny(aigv_ctx* c, const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
                const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi, hipStream_t s) {
   ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * R * (double)N * K, 2.0 * (double)N * K, s);
@@ -610,6 +679,20 @@ int aigv_load_weight(aigv_ctx* c, const char* name, const void* data, const int6
 int aigv_finalize_weights(aigv_ctx* c) {
   if (!c) return fail(c, AIGV_ERR_ARG, "null ctx");
   HIPCHK(c, hipSetDevice(c->device));
+  if (!c->llm8.empty()) {   // weights were (re)loaded: the e4m3 copies are stale - drop them; aigv_set_precision quantises again
+    HIPCHK(c, hipDeviceSynchronize());
+    auto drop = [&](void* p) {
+      if (!p) return;
+      auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
+      if (it != c->allocs.end()) c->allocs.erase(it);
+      hipFree(p);
+    };
+    for (auto& q : c->llm8) { drop(q.wqkv); drop(q.wo); drop(q.w13); drop(q.w2); drop(q.s_wqkv); drop(q.s_wo); drop(q.s_w13); drop(q.s_w2); }
+    drop(c->q8); drop(c->q8_scale);
+    c->q8 = nullptr; c->q8_scale = nullptr;
+    c->llm8.clear();
+  }
+  c->fp8_llm = false;
   const aigv_config& k = c->cfg;
   const size_t Hv = k.vit_hidden, Iv = k.vit_inter, H = k.llm_hidden, I = k.llm_inter;
   const std::string e = "vision_model.embeddings.";
@@ -909,8 +992,16 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
   for (int li = 0; li < k.llm_layers; ++li) {
     const LlmLayer& L = c->llm[li];
-    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
-    TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
+    // fp8 mode: every linear of the layer except the post-attention half of the LAST layer (wo, w1|w3, w2 there act on the few
+    // consumed rows - weight streaming, nothing for fp8 MFMA to gain - and stay bf16 with or without row trimming)
+    const bool f8 = c->fp8_llm, f8_post = f8 && li != k.llm_layers - 1;
+    if (f8) {
+      HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.an, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
+      TRY(run_gemm_fp8(c, nullptr, H, H, c->llm8[li].wqkv, c->llm8[li].s_wqkv, c->l_qkv, c->qkv_out, T, c->qkv_out, EPI_STORE, nullptr, 0, s));
+    } else {
+      HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
+      TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
+    }
     // RoPE: K in place (one of g + 2 slots per group); the query heads are rotated by the attention kernel as it loads them
     HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, 1, g + 2, nkv, D, s, g));
     if (keep_kv)
@@ -944,6 +1035,14 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       TRY(run_skinny(c, t_ffn, I, n_out, L.w2, I, H, I, nullptr, t_h, H, t_h, H, 1, s));
       TRY(final_rows(c, score, B, R, argmax, t_h, true, s));
       break;
+    }
+    if (f8_post) {
+      const LlmLayerFp8& Q = c->llm8[li];
+      TRY(run_gemm_fp8(c, c->l_ao, H, H, Q.wo, Q.s_wo, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
+      HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.fn, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
+      TRY(run_gemm_fp8(c, nullptr, H, H, Q.w13, Q.s_w13, c->l_ffn, I, T, 2 * I, EPI_SWIGLU, nullptr, 0, s));
+      TRY(run_gemm_fp8(c, c->l_ffn, I, I, Q.w2, Q.s_w2, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
+      continue;
     }
     {
       GemmArgs a = gemm_args(c->l_ao, H, L.wo, H, c->l_h, H, T, H, H);
@@ -1096,6 +1195,39 @@ int aigv_kv_fork(aigv_ctx* c, int copies, void* stream) {
   return 0;
 }
 
+int aigv_set_precision(aigv_ctx* c, int mode) {
+  if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_precision: null context");
+  if (mode != AIGV_PRECISION_BF16 && mode != AIGV_PRECISION_FP8_LLM) return fail(c, AIGV_ERR_ARG, "aigv_set_precision: unknown mode %d", mode);
+  if (mode == AIGV_PRECISION_BF16) { c->fp8_llm = false; return 0; }
+  if (c->llm.empty()) return fail(c, AIGV_ERR_STATE, "aigv_set_precision: call aigv_finalize_weights first");
+  const aigv_config& k = c->cfg;
+  const int H = k.llm_hidden, I = k.llm_inter, Q = c->qkv_out;
+  if (H % 256 || Q % 256 || (2 * I) % 256 || H % 128 || I % 128)
+    return fail(c, AIGV_ERR_ARG, "aigv_set_precision: the fp8 kernel needs output widths in multiples of 256 and depths in multiples of 128 (H=%d I=%d qkv=%d)", H, I, Q);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->llm8.empty()) {   // quantise once: one row of W[N, K] = one output channel
+    std::vector<LlmLayerFp8> q(k.llm_layers);
+    TRY(dalloc(c, &c->q8, (size_t)k.max_tokens * (size_t)std::max(H, I)));
+    TRY(dalloc(c, &c->q8_scale, (size_t)k.max_tokens));
+    for (int li = 0; li < k.llm_layers; ++li) {
+      const LlmLayer& L = c->llm[li];
+      struct { const bf16_t* w; int n, kk; uint8_t** q; float** sc; } items[4] = {
+          {L.wqkv, Q, H, &q[li].wqkv, &q[li].s_wqkv}, {L.wo, H, H, &q[li].wo, &q[li].s_wo},
+          {L.w13, 2 * I, H, &q[li].w13, &q[li].s_w13}, {L.w2, H, I, &q[li].w2, &q[li].s_w2}};
+      for (auto& it : items) {
+        TRY(dalloc(c, it.q, (size_t)it.n * it.kk));
+        TRY(dalloc(c, it.sc, (size_t)it.n));
+        hipError_t e = aigv_launch_quant_fp8_rows(it.w, it.kk, it.n, it.kk, *it.q, it.kk, *it.sc, nullptr);
+        if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "weight quantisation failed: %s", hipGetErrorString(e));
+      }
+    }
+    HIPCHK(c, hipDeviceSynchronize());
+    c->llm8 = std::move(q);
+  }
+  c->fp8_llm = true;
+  return 0;
+}
+
 int aigv_set_row_trimming(aigv_ctx* c, int on) {
   if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_row_trimming: null context");
   c->trim_last_layer = on != 0;
@@ -1176,16 +1308,21 @@ int aigv_op_quant_fp8_rows(const void* x_bf16, int ldx, int rows, int K, void* q
 }
 
 int aigv_op_gemm_fp8(const void* A_e4m3, int lda, const void* W_e4m3, int ldw, void* C, int ldc, const float* row_scale,
-                     const float* col_scale, const void* bias, int M, int N, int K, void* stream) {
+                     const float* col_scale, const void* bias, const void* ls, const void* resid, int ldr, int M, int N, int K, int epi,
+                     int k_slices, void* ws_f32, void* stream) {
   GemmArgs a{};
   a.A = (const bf16_t*)A_e4m3; a.lda = lda; a.W = (const bf16_t*)W_e4m3; a.ldw = ldw; a.C = (bf16_t*)C; a.ldc = ldc;
   a.M = M; a.N = N; a.K = K; a.bias = (const bf16_t*)bias; a.row_scale = row_scale; a.col_scale = col_scale;
-  if (ldc < N || (ldc % 4) || lda < K || ldw < K)
+  a.ls = (const bf16_t*)ls; a.resid = (const bf16_t*)resid; a.ldr = ldr;
+  const int n_out = epi == EPI_SWIGLU ? N / 2 : N;
+  if (ldc < n_out || (ldc % 8) || lda < K || ldw < K)
     return fail(nullptr, AIGV_ERR_ARG, "aigv_op_gemm_fp8: bad leading dimension (M=%d N=%d K=%d)", M, N, K);
-  hipError_t e = aigv_launch_gemm256_fp8(a, (hipStream_t)stream);
+  hipError_t e = k_slices > 1 ? aigv_launch_gemm_splitk_fp8(a, epi, k_slices, (float*)ws_f32, (hipStream_t)stream)
+                              : aigv_launch_gemm256_fp8(a, epi, (hipStream_t)stream);
   if (e != hipSuccess)
     return fail(nullptr, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP,
-                "fp8 gemm (M=%d N=%d K=%d; needs N %% 256 == 0, K %% 128 == 0, 16-byte row strides, both scale vectors): %s", M, N, K, hipGetErrorString(e));
+                "fp8 gemm (M=%d N=%d K=%d epi=%d; needs N %% 256 == 0, K %% 128 == 0, 16-byte row strides, both scale vectors, epi in "
+                "{store, gelu, ls_resid, resid, swiglu}): %s", M, N, K, epi, hipGetErrorString(e));
   return 0;
 }
 

@@ -283,6 +283,25 @@ const char* aigv_gemm_check(const GemmArgs& a, int epi) {
   return nullptr;
 }
 
+// the fp8 form's split-K: scaled fp32 slabs from the e4m3 kernel, then the same fixed-order finalize pass as the bf16 path
+hipError_t aigv_launch_gemm_splitk_fp8(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s) {
+  if (k_slices < 2 || !ws) return hipErrorInvalidValue;
+  GemmArgs b = a;
+  b.part = ws;
+  b.k_slices = k_slices;
+  hipError_t e = aigv_launch_gemm256_fp8_partial(b, s);
+  if (e != hipSuccess) return e;
+  switch (epi) {
+    case EPI_STORE: launch_finalize<EPI_STORE>(a, ws, k_slices, s); break;
+    case EPI_GELU: launch_finalize<EPI_GELU>(a, ws, k_slices, s); break;
+    case EPI_LS_RESID: launch_finalize<EPI_LS_RESID>(a, ws, k_slices, s); break;
+    case EPI_RESID: launch_finalize<EPI_RESID>(a, ws, k_slices, s); break;
+    case EPI_SWIGLU: launch_finalize<EPI_SWIGLU>(a, ws, k_slices, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s, bool tile256) {
   if (k_slices < 2 || (a.K / BK) % k_slices || !ws || epi == EPI_PATCH || epi >= EPI_COUNT) return hipErrorInvalidValue;
   if (tile256) {

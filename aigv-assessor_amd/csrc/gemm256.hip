@@ -63,7 +63,7 @@ __device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uni
 //      unit block scales instead of sixteen bf16 MFMAs, and the epilogue multiplies by the per-row and per-column fp32 scales.
 template <int EPI, int VAR, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
-  static_assert(!FP8 || (EPI == EPI_STORE && (VAR & 4) != 0), "the fp8 form has the plain staged epilogue only");
+  static_assert(!FP8 || ((VAR & 4) != 0 && EPI != EPI_PATCH), "the fp8 form uses the LDS-staged epilogue (or writes split-K slabs)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // on the source side): half mh = 0 into the K buffer the last tile does not use, issued from that tile's phases 1 and 2
   // (its units were last read >= 3 intervals earlier, the refill rule of the header); half mh = 1 into the last tile's own
   // buffer once the K loop has drained.  The HBM latency of the residual is then hidden behind MFMA work / the first half.
-  constexpr bool RESID_PF = ((VAR & 4) != 0) && (EPI == EPI_RESID || EPI == EPI_LS_RESID);
+  // (the fp8 form adds its residual in stage 2 of the staged epilogue instead: the prefetching path has no registers left for the scales)
+  constexpr bool RESID_PF = ((VAR & 4) != 0) && (EPI == EPI_RESID || EPI == EPI_LS_RESID) && !FP8;
   const char* rtile = RESID_PF ? (const char*)(p.resid + (size_t)m0 * p.ldr + n0 + wc * 64) : nullptr;
   auto resid_dma = [&](int mh, int i0, int cnt) {   // instructions i0 .. i0+cnt-1 of half mh (8 rows each)
     const int buf = (mh == 0) ? ((nk - 1) & 1) ^ 1 : ((nk - 1) & 1);
@@ -300,10 +301,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         const int m = m0 + g * 128 + mh * 64 + mt * 16 + fr;
         if (m >= p.M) continue;
         float* row = p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n0 + wc * 64 + fq * 4;
+        // fp8: the slabs hold SCALED partial sums ((acc * row scale) * column scale is linear in acc), so the finalize pass is the bf16 one
+        const float rs = FP8 ? p.row_scale[m] : 1.f;
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) *(f32x4*)(row + nh * 32 + nt * 16) = acc[mh][mt][nh][nt];
+          for (int nt = 0; nt < 2; ++nt) {
+            f32x4 v = acc[mh][mt][nh][nt];
+            if constexpr (FP8) v = (v * rs) * *(const f32x4*)(p.col_scale + n0 + wc * 64 + nh * 32 + nt * 16 + fq * 4);
+            *(f32x4*)(row + nh * 32 + nt * 16) = v;
+          }
       }
     return;
   } else if constexpr (RESID_PF) {
@@ -384,8 +391,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     // per-column bias depends on (nh, nt, fq) only: loaded once, not once per row block.  (EPI_RESID / EPI_LS_RESID take the
     // prefetching epilogue above when VAR has bit 2, so this path carries no layer-scale.)
     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-    static_assert(EPI != EPI_RESID && EPI != EPI_LS_RESID, "residual epilogues use the prefetching path");
+    static_assert(FP8 || (EPI != EPI_RESID && EPI != EPI_LS_RESID), "bf16 residual epilogues use the prefetching path");
     u32x2 bcol[2][2];
+    u32x2 scol[2][2];   // layer-scale (fp8 LS_RESID only)
+    if constexpr (EPI == EPI_LS_RESID) {
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) scol[nh][nt] = *(const u32x2*)(p.ls + n0 + wc * 64 + nh * 32 + nt * 16 + fq * 4);
+    }
     if constexpr (EPI != EPI_SWIGLU) {
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
@@ -414,8 +428,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             u32x2 o;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const f32x2 gt = rbf2(f32x2{acc[mh][mt][nh][0][2 * h], acc[mh][mt][nh][0][2 * h + 1]});
-              const f32x2 up = rbf2(f32x2{acc[mh][mt][nh][1][2 * h], acc[mh][mt][nh][1][2 * h + 1]});
+              f32x2 gt = f32x2{acc[mh][mt][nh][0][2 * h], acc[mh][mt][nh][0][2 * h + 1]};
+              f32x2 up = f32x2{acc[mh][mt][nh][1][2 * h], acc[mh][mt][nh][1][2 * h + 1]};
+              if constexpr (FP8) {
+                const float rs = p.row_scale[min(m0 + g * 128 + mh * 64 + mt * 16 + fr, p.M - 1)];
+                gt = (gt * rs) * f32x2{wsc[nh][0][2 * h], wsc[nh][0][2 * h + 1]};
+                up = (up * rs) * f32x2{wsc[nh][1][2 * h], wsc[nh][1][2 * h + 1]};
+              }
+              gt = rbf2(gt);
+              up = rbf2(up);
               o[h] = pack_bf2(rbf2(silu2(gt)) * up);
             }
             *(u32x2*)(rowp + (nh * 16 + fq * 4) * 2) = o;
@@ -436,6 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
                 }
                 if (p.bias) v += unpack_bf2(bcol[nh][nt][h]);   // wave-uniform branch
                 if constexpr (EPI == EPI_GELU) v = gelu_fast2(rbf2(v));
+                if constexpr (EPI == EPI_LS_RESID) v = rbf2(v) * unpack_bf2(scol[nh][nt][h]);
                 o[h] = pack_bf2(v);
               }
               *(u32x2*)(rowp + cl * 2) = o;
@@ -458,6 +480,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             const u16x8 ps = *(const u16x8*)(p.pos + (size_t)(pi + 1) * p.N + n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) val[e] = f2bf(bf2f(val[e]) + bf2f(ps[e]));
+          }
+          if constexpr (EPI == EPI_RESID || EPI == EPI_LS_RESID) {   // fp8 form only (bf16 takes the prefetching path)
+            const u16x8 rs = *(const u16x8*)(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = f2bf(bf2f(rs[e]) + bf2f(val[e]));
           }
           *(u16x8*)(p.C + orow * p.ldc + n) = val;
         }
@@ -570,19 +597,52 @@ bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % T
 // split-K slices of the 256 kernel: grid.y = a.k_slices workgroups per tile, each writes fp32 partial sums of its K range into
 // a.part[slice][M][N] (summed in slice order by gemm_finalize_kernel, gemm.hip)
 // fp8: a.K / a.lda / a.ldw arrive in e4m3 ELEMENTS; the kernel addresses the same bytes as pairs (its bf16_t unit)
-hipError_t aigv_launch_gemm256_fp8(const GemmArgs& a, hipStream_t s) {
+template <int EPI>
+hipError_t launch256_fp8(const GemmArgs& b, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int nbm = (b.M + TM - 1) / TM, nbn = b.N / TN;
+  hipLaunchKernelGGL((gemm256_kernel<EPI, 7, true>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, b);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_gemm256_fp8(const GemmArgs& a, int epi, hipStream_t s) {
   if (a.M < 1 || a.N % TN || a.K % 128 || (a.lda % 16) || (a.ldw % 16) || !a.row_scale || !a.col_scale || !a.A || !a.W || !a.C)
+    return hipErrorInvalidValue;
+  if ((epi == EPI_RESID || epi == EPI_LS_RESID) && (!a.resid || a.ldr % 8)) return hipErrorInvalidValue;
+  if (epi == EPI_LS_RESID && !a.ls) return hipErrorInvalidValue;
+  if (epi == EPI_SWIGLU && a.bias) return hipErrorInvalidValue;
+  GemmArgs b = a;
+  b.K = a.K / 2; b.lda = a.lda / 2; b.ldw = a.ldw / 2;
+  switch (epi) {
+    case EPI_STORE: return launch256_fp8<EPI_STORE>(b, s);
+    case EPI_GELU: return launch256_fp8<EPI_GELU>(b, s);
+    case EPI_LS_RESID: return launch256_fp8<EPI_LS_RESID>(b, s);
+    case EPI_RESID: return launch256_fp8<EPI_RESID>(b, s);
+    case EPI_SWIGLU: return launch256_fp8<EPI_SWIGLU>(b, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// split-K slices of the fp8 form (a.K / lda / ldw in e4m3 elements; a.part / a.k_slices filled in; K / 128 divisible by the slices)
+hipError_t aigv_launch_gemm256_fp8_partial(const GemmArgs& a, hipStream_t s) {
+  if (a.M < 1 || a.N % TN || a.K % 128 || (a.lda % 16) || (a.ldw % 16) || !a.row_scale || !a.col_scale || !a.A || !a.W || !a.part || a.k_slices < 1 ||
+      (a.K / 128) % a.k_slices)
     return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_STORE, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_PARTIAL, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   GemmArgs b = a;
   b.K = a.K / 2; b.lda = a.lda / 2; b.ldw = a.ldw / 2;
   const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
-  hipLaunchKernelGGL((gemm256_kernel<EPI_STORE, 7, true>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, b);
+  hipLaunchKernelGGL((gemm256_kernel<EPI_PARTIAL, 7, true>), dim3(nbm * nbn, a.k_slices), dim3(512), LDS_BYTES, s, b);
   return hipGetLastError();
 }
 

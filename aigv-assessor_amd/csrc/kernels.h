@@ -42,9 +42,15 @@ hipError_t aigv_launch_gemm(const GemmArgs& a, int epi, hipStream_t s);         
 // (tile256: the slices come from the 256x256 kernel - needs N % 256 == 0)
 hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s, bool tile256 = false);
 hipError_t aigv_launch_gemm256_partial(const GemmArgs& a, hipStream_t s);   // a.part / a.k_slices filled in
-// e4m3 operands on the block-scaled fp8 MFMA (unit block scales; per-row x per-column fp32 scales in the epilogue), EPI_STORE only
-hipError_t aigv_launch_gemm256_fp8(const GemmArgs& a, hipStream_t s);
+// e4m3 operands on the block-scaled fp8 MFMA (unit block scales; per-row x per-column fp32 scales applied to the accumulator before the
+// epilogue proper); epi = STORE, GELU, LS_RESID, RESID or SWIGLU with the bf16 kernel's rounding points
+hipError_t aigv_launch_gemm256_fp8(const GemmArgs& a, int epi, hipStream_t s);
+hipError_t aigv_launch_gemm256_fp8_partial(const GemmArgs& a, hipStream_t s);   // a.part / a.k_slices filled in; slabs hold scaled sums
+hipError_t aigv_launch_gemm_splitk_fp8(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s);
 // bf16 rows -> e4m3 bytes + one fp32 scale per row (amax / 448); q = e4m3_rne(x * (448 / amax))
+// RMSNorm whose result goes straight to e4m3 rows + row scales (== aigv_launch_rmsnorm then aigv_launch_quant_fp8_rows, bit for bit)
+hipError_t aigv_launch_rmsnorm_quant_fp8(const bf16_t* x, int ldx, const bf16_t* w, uint8_t* q, int ldq, float* scale, int rows, int H, float eps,
+                                         hipStream_t s);
 hipError_t aigv_launch_quant_fp8_rows(const bf16_t* x, int ldx, int rows, int K, uint8_t* q, int ldq, float* scale, hipStream_t s);
 bool aigv_gemm256_supported(const GemmArgs& a);
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);        // 256x256 phase-interleaved kernel

@@ -120,6 +120,60 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
   }
 }
 
+// RMSNorm fused with the fp8 row quantisation of its result (fp8 mode of the InternLM2 linears): the bf16 value the plain kernel
+// would store is quantised from registers - bit-identical to rmsnorm_kernel followed by quant_fp8_rows_kernel, one pass instead of two.
+__global__ __launch_bounds__(256) void rmsnorm_quant_fp8_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w,
+                                                                uint8_t* __restrict__ q, int ldq, float* __restrict__ scale, int H, float eps) {
+  __shared__ float red[4];
+  __shared__ float redm[4];
+  const int row = blockIdx.x;
+  const int nchunk = H >> 3;
+  float v[MAXC][8];
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      const u16x8 raw = *(const u16x8*)(x + (size_t)row * ldx + (ch << 3));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[c][e] = bf2f(raw[e]); sq += v[c][e] * v[c][e]; }
+    }
+  }
+  const float rstd = rsqrtf(block_sum_256(sq, red) / (float)H + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      const u16x8 ww = *(const u16x8*)(w + (ch << 3));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[c][e] = rbf(bf2f(ww[e]) * rbf(v[c][e] * rstd));
+        amax = fmaxf(amax, fabsf(v[c][e]));
+      }
+    }
+  }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  const float inv = amax > 0.f ? __fdiv_rn(448.0f, amax) : 1.0f;
+  if (threadIdx.x == 0) scale[row] = amax > 0.f ? __fdiv_rn(amax, 448.0f) : 1.0f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * inv, v[c][5] * inv, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * inv, v[c][7] * inv, hi, true);
+      typedef __attribute__((ext_vector_type(2))) int i32x2;
+      *(i32x2*)(q + (size_t)row * ldq + (ch << 3)) = i32x2{lo, hi};
+    }
+  }
+}
+
 // ---- drop cls + pixel_shuffle v2 (modeling_internvl_chat.py:492-506,520-527): pre-projector tokens -------
 // out token (i2, j2) of frame f = concat over (di, dj) of vit[f, 1 + (2*i2+di)*grid + 2*j2+dj, :]
 __global__ void pixel_shuffle_kernel(const bf16_t* __restrict__ vit, int grid, int Hv, bf16_t* __restrict__ out,
@@ -367,6 +421,14 @@ hipError_t aigv_launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t
   if (rows <= 0) return hipSuccess;
   if (H % 8 || H > MAXC * 256 * 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, y, ldy, H, eps, row_idx);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_rmsnorm_quant_fp8(const bf16_t* x, int ldx, const bf16_t* w, uint8_t* q, int ldq, float* scale, int rows, int H, float eps,
+                                         hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (H % 8 || H > MAXC * 256 * 8 || ldq % 8 || !q || !scale) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_quant_fp8_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, q, ldq, scale, H, eps);
   return hipGetLastError();
 }
 

@@ -324,6 +324,8 @@ class InternVLChatModel(nn.Module):
         put("rope.cos", cos)
         put("rope.sin", sin)
         native.check(lib.aigv_finalize_weights(ctx), ctx)
+        # finalize resets the context to bf16 and drops stale e4m3 weight copies: a re-created context or reloaded weights keep the mode
+        native.check(lib.aigv_set_precision(ctx, 1 if getattr(self, "_precision", "bf16") == "fp8" else 0), ctx)
         self._dirty = False
 
     def __del__(self):
@@ -837,6 +839,16 @@ class InternVLChatModel(nn.Module):
         responses = tokenizer.batch_decode(out, skip_special_tokens=True)
         return [r.split(template.sep)[0].strip() for r in responses]
 
+    def set_precision(self, mode: str = "bf16"):
+        """"bf16" (default: the reference's dtype flow) or "fp8": the InternLM2 prefill linears of ``forward`` on the e4m3 MFMA with
+        per-channel weight scales and per-token activation scales (BASELINE config 5; aigv_set_precision in include/aigv_amd.h).
+        The reference has no fp8 path; scores move by the quantisation noise documented in DESIGN.md."""
+        if mode not in ("bf16", "fp8"):
+            raise ValueError("precision must be 'bf16' or 'fp8'")
+        self._precision = mode
+        if self._ctx is not None and not self._dirty:
+            native.check(native.load().aigv_set_precision(self._ctx, 1 if mode == "fp8" else 0), self._ctx)
+
     def set_row_trimming(self, on: bool = True):
         """Last-layer row trimming (default on): the last decoder layer finishes only the rows whose hidden state is
         consumed (score row + answer rows; stage2_eval.py:940-941, modeling_internvl_chat.py:469-481).  Off = every row
@@ -853,7 +865,7 @@ class InternVLChatModel(nn.Module):
     def prof_read(self) -> Dict[str, Dict[str, float]]:
         lib, ctx = self._native()
         out = {}
-        for cls, name in enumerate(("gemm", "attn_vit", "attn_llm", "skinny")):
+        for cls, name in enumerate(("gemm", "attn_vit", "attn_llm", "skinny", "gemm_fp8")):
             n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
             native.check(lib.aigv_prof_read(ctx, cls, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), ctx)
             out[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)

@@ -66,8 +66,9 @@ PROTOTYPES = {
     "aigv_slowfast_forward": (_I, [_P, _P, _I, _P, _P]),
     "aigv_slowfast_flops_per_clip": (C.c_double, [_P]),
     "aigv_op_conv3d": (_I, [_P, _I, _I, _I, C.POINTER(_I), _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "aigv_set_precision": (_I, [_P, _I]),
     "aigv_op_quant_fp8_rows": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
-    "aigv_op_gemm_fp8": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "aigv_op_gemm_fp8": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "aigv_op_skinny_gemm": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "aigv_op_layernorm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
     "aigv_op_rmsnorm": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P]),

@@ -120,6 +120,16 @@ int aigv_llm_extend(aigv_ctx* ctx, const int64_t* ids, const int32_t* cu, int n_
  * which streams the decoder weights once for all of them. */
 int aigv_kv_fork(aigv_ctx* ctx, int copies, void* stream);
 
+/* Arithmetic of the InternLM2 PREFILL linears (aigv_llm_prefill; BASELINE config 5).  AIGV_PRECISION_BF16 (default) is the reference's
+ * dtype flow.  AIGV_PRECISION_FP8_LLM: wqkv, wo, w1|w3, w2 of every decoder layer - except wo / w1|w3 / w2 of the LAST layer, which act on
+ * the few consumed rows - run on the e4m3 MFMA: weights quantised once per output channel (scale = amax / 448), activations per token row
+ * on the fly (aigv_op_quant_fp8_rows), fp32 accumulation, the bf16 path's epilogues and rounding points after the scaled accumulator.
+ * Attention, norms, RoPE, residual stream, lm-head and score head stay bf16, and so do aigv_llm_extend / aigv_decode_step.  The reference
+ * has no fp8 path: results move by the quantisation noise (oracle/fp8.py restates this mode; measured drift in DESIGN.md).  First call
+ * quantises the weights (extra memory: one byte per InternLM2 linear weight).  Needs H, qkv width, 2*I multiples of 256.
+ * aigv_finalize_weights (i.e. any reload of weights) drops the e4m3 copies and returns the context to bf16: set the mode again after it. */
+enum aigv_precision { AIGV_PRECISION_BF16 = 0, AIGV_PRECISION_FP8_LLM = 1 };
+int aigv_set_precision(aigv_ctx* ctx, int mode);
 /* Last-layer row trimming in aigv_llm_prefill (default on): when at most 64 rows are consumed (score rows + logit rows), the
  * last decoder layer computes attention only for the query blocks holding them and finishes wo / MLP / final norm on a compact
  * copy of those rows.  Rows are independent after attention, so the outputs are those of the untrimmed pass (up to the fp32
@@ -148,10 +158,13 @@ int aigv_op_gemm_splitk256(const void* A, int lda, const void* W, int ldw, void*
  *   aigv_op_gemm_fp8:       C[M, N] = bf16((sum_k A[m,k] W[n,k]) * row_scale[m] * col_scale[n] + bias[n]) with e4m3 A [M, K] and
  *                           W [N, K] (K contiguous), products exact and accumulated in fp32 on v_mfma_scale_f32_16x16x128_f8f6f4
  *                           (unit block scales) with the 256x256 schedule of the bf16 kernel.  N % 256 == 0, K % 128 == 0,
- *                           lda / ldw in bytes and multiples of 16; row_scale / col_scale DEVICE float. */
+ *                           lda / ldw in bytes and multiples of 16; row_scale / col_scale DEVICE float.  epi = AIGV_EPI_STORE, _GELU,
+ *                           _LS_RESID, _RESID or _SWIGLU: the scaled accumulator takes the place of the bf16 kernel's accumulator,
+ *                           every later rounding point is that of aigv_op_gemm. */
 int aigv_op_quant_fp8_rows(const void* x_bf16, int ldx, int rows, int K, void* q_e4m3, int ldq, float* row_scale, void* stream);
 int aigv_op_gemm_fp8(const void* A_e4m3, int lda, const void* W_e4m3, int ldw, void* C, int ldc, const float* row_scale,
-                     const float* col_scale, const void* bias, int M, int N, int K, void* stream);
+                     const float* col_scale, const void* bias, const void* ls, const void* resid, int ldr, int M, int N, int K, int epi,
+                     int k_slices, void* ws_f32, void* stream);   /* k_slices > 1: split-K, ws_f32 = k_slices * M * N floats, K/128 % k_slices == 0 */
 int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W, int ldw, int N, int K, const void* bias,
                         const void* resid, int ldr, void* out, int ldo, int epi, void* stream);
 int aigv_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H,
@@ -208,7 +221,7 @@ int aigv_tune_attention(int waves);
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* When enabled every GEMM / attention launch of the hot path is bracketed by HIP events on the launch stream. */
 enum aigv_prof_class { AIGV_PROF_GEMM = 0, AIGV_PROF_ATTN_VIT = 1, AIGV_PROF_ATTN_LLM = 2, AIGV_PROF_SKINNY = 3,
-                       AIGV_PROF_COUNT = 4 };
+                       AIGV_PROF_GEMM_FP8 = 4, AIGV_PROF_COUNT = 5 };
 int aigv_prof_enable(aigv_ctx* ctx, int on);
 /* Synchronises the recorded events and returns (and clears) launches, total milliseconds and algorithmic
  * FLOPs (2*M*N*K; attention 4*sum(len_q*len_kv_visible)*d*heads) and bytes per class. */

@@ -243,6 +243,16 @@ def additive_mask(attention_mask: Tensor, q_len: int, past_len: int, dtype) -> T
     return pad
 
 
+# Hook for the build's own fp8 mode (oracle/fp8.py): None = the reference's F.linear.  Called as hook(x, weight, layer, name).
+LLM_LINEAR_HOOK = None
+
+
+def _llm_linear(x: Tensor, w: Tensor, layer: int, name: str) -> Tensor:
+    if LLM_LINEAR_HOOK is not None:
+        return LLM_LINEAR_HOOK(x, w, layer, name)
+    return F.linear(x, w)
+
+
 def llm_attention(sd: SD, cfg, i: int, x: Tensor, mask: Tensor, position_ids: Tensor,
                   past: Optional[Tuple[Tensor, Tensor]] = None):
     """InternLM2Attention.forward, eager (LM:355-440).  wqkv output features are ordered
@@ -252,7 +262,7 @@ def llm_attention(sd: SD, cfg, i: int, x: Tensor, mask: Tensor, position_ids: Te
     b, n, _ = x.shape
     nh, nkv, d = l.num_attention_heads, l.num_key_value_heads, l.head_dim
     g = nh // nkv
-    qkv = F.linear(x, sd[p + "wqkv.weight"]).view(b, n, nkv, g + 2, d)
+    qkv = _llm_linear(x, sd[p + "wqkv.weight"], i, "wqkv").view(b, n, nkv, g + 2, d)
     q = qkv[..., :g, :].reshape(b, n, nh, d).transpose(1, 2)
     k = qkv[..., g, :].transpose(1, 2)
     v = qkv[..., g + 1, :].transpose(1, 2)
@@ -269,14 +279,14 @@ def llm_attention(sd: SD, cfg, i: int, x: Tensor, mask: Tensor, position_ids: Te
     w = w + mask
     w = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
     y = torch.matmul(w, vr).transpose(1, 2).contiguous().reshape(b, n, nh * d)
-    return F.linear(y, sd[p + "wo.weight"]), present
+    return _llm_linear(y, sd[p + "wo.weight"], i, "wo"), present
 
 
 def llm_mlp(sd: SD, i: int, x: Tensor) -> Tensor:
     """InternLM2MLP.forward (LM:264-278): w2(silu(w1 x) * w3 x)."""
     p = f"language_model.model.layers.{i}.feed_forward."
-    return F.linear(F.silu(F.linear(x, sd[p + "w1.weight"])) * F.linear(x, sd[p + "w3.weight"]),
-                    sd[p + "w2.weight"])
+    return _llm_linear(F.silu(_llm_linear(x, sd[p + "w1.weight"], i, "w1")) * _llm_linear(x, sd[p + "w3.weight"], i, "w3"),
+                       sd[p + "w2.weight"], i, "w2")
 
 
 def llm_layer(sd: SD, cfg, i: int, x: Tensor, mask: Tensor, position_ids: Tensor, past=None):

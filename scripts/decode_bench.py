@@ -1,6 +1,6 @@
 """generate() throughput on the 8B model: prefill + greedy decode steps (HBM-bound weight streaming)."""
-import sys, time, torch
-sys.path.insert(0, '.')
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import aigv_assessor_amd as pkg
 from aigv_assessor_amd import synth
 from aigv_assessor_amd.modeling import InternVLChatModel

@@ -27,7 +27,7 @@ for rep in range(2):
         native.check(lib.aigv_op_quant_fp8_rows(ptr(W), K, N, K, ptr(qw), K, ptr(sw), None))
         quant = lambda: native.check(lib.aigv_op_quant_fp8_rows(ptr(A), K, M, K, ptr(qa), K, ptr(sa), None))
         bf = lambda: native.check(lib.aigv_op_gemm(ptr(A), K, ptr(W), K, ptr(C), N, None, None, None, N, None, 0, M, N, K, 0, None))
-        f8 = lambda: native.check(lib.aigv_op_gemm_fp8(ptr(qa), K, ptr(qw), K, ptr(C8), N, ptr(sa), ptr(sw), None, M, N, K, None))
+        f8 = lambda: native.check(lib.aigv_op_gemm_fp8(ptr(qa), K, ptr(qw), K, ptr(C8), N, ptr(sa), ptr(sw), None, None, None, 0, M, N, K, 0, 0, None, None))
         quant(); t_bf = timed(bf); t_f8 = timed(f8); t_q = timed(quant)
         rel = ((C8.float() - C.float()).norm() / C.float().norm()).item()
         fl = 2 * M * N * K / 1e9

@@ -604,14 +604,61 @@ def test_fp8_gemm_matches_its_arithmetic(lib, M, N, K, bias):
     dA, dW = dev(qa.view(torch.uint8)), dev(qw.view(torch.uint8))
     dsa, dsw = dev(sa), dev(sw)
     C = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
-    sync(lib.aigv_op_gemm_fp8(ptr(dA), K, ptr(dW), K, ptr(C), N, ptr(dsa), ptr(dsw), ptr(dev(b)) if bias else None, M, N, K, None), lib)
+    sync(lib.aigv_op_gemm_fp8(ptr(dA), K, ptr(dW), K, ptr(C), N, ptr(dsa), ptr(dsw), ptr(dev(b)) if bias else None, None, None, 0, M, N, K, 0, 0, None, None), lib)
     ulp_check(C, want, frac=0.02, max_ulps=1, atol_rel=2e-5)
     # and through the quantisation kernel end to end: the same bytes come out of aigv_op_quant_fp8_rows
     q = torch.empty((M, K), dtype=torch.uint8, device="cuda"); sc = torch.empty(M, dtype=torch.float32, device="cuda")
     sync(lib.aigv_op_quant_fp8_rows(ptr(dev(a)), K, M, K, ptr(q), K, ptr(sc), None), lib)
     C2 = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
-    sync(lib.aigv_op_gemm_fp8(ptr(q), K, ptr(dW), K, ptr(C2), N, ptr(sc), ptr(dsw), ptr(dev(b)) if bias else None, M, N, K, None), lib)
+    sync(lib.aigv_op_gemm_fp8(ptr(q), K, ptr(dW), K, ptr(C2), N, ptr(sc), ptr(dsw), ptr(dev(b)) if bias else None, None, None, 0, M, N, K, 0, 0, None, None), lib)
     assert torch.equal(C2, C)
+
+
+def _epilogue_ref(acc, epi, bias=None, ls=None, resid=None):
+    """gemm_ref's rounding chain applied to a given fp32 accumulator."""
+    if epi == 4:
+        blk = acc.view(acc.shape[0], acc.shape[1] // 32, 2, 16)
+        g, u = rb(blk[:, :, 0, :]).reshape(acc.shape[0], -1), rb(blk[:, :, 1, :]).reshape(acc.shape[0], -1)
+        return rb(rb(torch.nn.functional.silu(g)) * u)
+    if bias is not None:
+        acc = acc + bias.float()
+    y = rb(acc)
+    if epi == 1:
+        y = rb(torch.nn.functional.gelu(y))
+    if epi == 2:
+        y = rb(y * ls.float())
+    if epi in (2, 3):
+        y = rb(resid.float() + y)
+    return y
+
+
+@pytest.mark.parametrize("epi", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (1029, 768, 1024)])
+def test_fp8_gemm_epilogues(lib, M, N, K, epi):
+    """The fp8 form keeps every rounding point of the bf16 kernel's epilogues; its scaled accumulator replaces the bf16 accumulator."""
+    from aigv_assessor_amd.native import ptr
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    a = (torch.randn(M, K, generator=g) * 0.7).to(BF)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF) if epi in (1, 2) else None
+    ls = (torch.rand(N, generator=g) + 0.5).to(BF) if epi == 2 else None
+    nout = N // 2 if epi == 4 else N
+    resid = torch.randn(M, nout, generator=g).to(BF) if epi in (2, 3) else None
+    qa, sa = _quant_ref(a)
+    qw, sw = _quant_ref(w)
+    acc = ((qa.float().double() @ qw.float().double().t()).float() * sa[:, None]) * sw[None, :]
+    want = _epilogue_ref(acc, epi, bias, ls, resid)
+    C = torch.full((M, nout), float("nan"), dtype=BF, device="cuda")
+    db, dl, dr = (dev(t) if t is not None else None for t in (bias, ls, resid))
+    sync(lib.aigv_op_gemm_fp8(ptr(dev(qa.view(torch.uint8))), K, ptr(dev(qw.view(torch.uint8))), K, ptr(C), nout, ptr(dev(sa)), ptr(dev(sw)),
+                              ptr(db), ptr(dl), ptr(dr), nout, M, N, K, epi, 0, None, None), lib)
+    ulp_check(C, want, frac=0.03 if epi in (1, 4) else 0.02, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
+    # split-K form (scaled fp32 slabs + the bf16 path's finalize pass): same result up to the summation order
+    ws = torch.empty(2 * M * N, dtype=torch.float32, device="cuda")
+    C2 = torch.full((M, nout), float("nan"), dtype=BF, device="cuda")
+    sync(lib.aigv_op_gemm_fp8(ptr(dev(qa.view(torch.uint8))), K, ptr(dev(qw.view(torch.uint8))), K, ptr(C2), nout, ptr(dev(sa)), ptr(dev(sw)),
+                              ptr(db), ptr(dl), ptr(dr), nout, M, N, K, epi, 2, ptr(ws), None), lib)
+    ulp_check(C2, want, frac=0.03 if epi in (1, 4) else 0.02, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
 def test_fp8_gemm_rejects_bad_shapes(lib):
@@ -619,7 +666,7 @@ def test_fp8_gemm_rejects_bad_shapes(lib):
     f = torch.ones(256, dtype=torch.float32, device="cuda")
     c = torch.empty(256, 256, dtype=BF, device="cuda")
     ok = lambda **kw: lib.aigv_op_gemm_fp8(t.data_ptr(), kw.get("K", 128), t.data_ptr(), kw.get("K", 128), c.data_ptr(), 256, kw.get("sa", f.data_ptr()),
-                                           f.data_ptr(), None, 256, kw.get("N", 256), kw.get("K", 128), None)
+                                           f.data_ptr(), None, None, None, 0, 256, kw.get("N", 256), kw.get("K", 128), 0, 0, None, None)
     assert ok() == 0
     assert ok(N=128) != 0 and ok(K=64) != 0 and ok(sa=None) != 0
     torch.cuda.synchronize()

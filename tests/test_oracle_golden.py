@@ -213,3 +213,28 @@ def test_slowfast_pool_tail_is_a_separable_weighted_mean():
         wy, wx = cover(H, 7) / ((H - 6) * 7), cover(W, 7) / ((W - 6) * 7)
         got = torch.einsum("bcthw,t,h,w->bc", x, wt, wy, wx)
         assert torch.allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp8 mode restatement (oracle/fp8.py): the build's own definition - the reference has no fp8 path
+# ---------------------------------------------------------------------------------------------------------
+def test_fp8_oracle_linear_and_hook_scope():
+    import torch.nn.functional as F
+    from oracle import fp8 as O8
+    from oracle import oracle as O
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 256, generator=g).bfloat16()
+    w = (torch.randn(64, 256, generator=g) / 16).bfloat16()
+    q, s = O8.quant_rows(x)
+    assert q.dtype == torch.float8_e4m3fn and float(q.float().abs().max()) == 448.0          # every row uses the full e4m3 range
+    assert torch.allclose(q.float() * s[:, None], x.float(), rtol=2 ** -3, atol=float(s.max()) * 2 ** -9 * 448)   # 3 mantissa bits
+    y8, y = O8.fp8_linear(x, w).float(), F.linear(x, w).float()
+    rel = float((y8 - y).norm() / y.norm())
+    assert 0.005 < rel < 0.06, rel                                                            # e4m3 noise: a few percent, not zero
+    assert O.LLM_LINEAR_HOOK is None
+    with O8.fp8_llm(2):
+        assert O.LLM_LINEAR_HOOK is not None
+        assert torch.equal(O._llm_linear(x, w, 0, "wo"), O8.fp8_linear(x, w))
+        assert torch.equal(O._llm_linear(x, w, 1, "wo"), F.linear(x, w))                     # post-attention half of the last layer: bf16
+        assert torch.equal(O._llm_linear(x, w, 1, "wqkv"), O8.fp8_linear(x, w))
+    assert O.LLM_LINEAR_HOOK is None
