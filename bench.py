@@ -56,7 +56,7 @@ def flops_per_clip(cfg, T, N, answer_rows):
                 executed=vit + proj + llm_e + logits - dead)
 
 
-def cpu_baseline(cfg, T, N, budget_s=30.0):
+def cpu_baseline(cfg, T, N, budget_s=30.0, slowfast=False):
     """Time the CPU oracle on this host: one full-width ViT layer over T frames, one full-width LLM layer over N
     tokens, the lm-head over all N rows (as the reference computes it) and the projector; scale by layer counts."""
     import aigv_assessor_amd as pkg
@@ -93,12 +93,19 @@ def cpu_baseline(cfg, T, N, budget_s=30.0):
         tok = O.shuffled_tokens(xv, cfg.downsample_ratio)
         t_proj = timed(lambda: O.projector(sd, "mlp1", tok), reps=1)
         t_logits = timed(lambda: O.lm_logits(sd, xl).argmax(-1), reps=1)
-    per_clip = t_vit_layer * v.num_hidden_layers + t_llm_layer * l.num_hidden_layers + t_embed + t_proj + t_logits
+    t_sf = 0.0
+    if slowfast:   # the motion branch of the same clip (oracle/slowfast.py, bf16 modules as in the reference)
+        from oracle import slowfast as OSF
+        sf_sd = synth.slowfast_state_dict(seed=1)
+        clip = frames.view(1, T, 3, cfg.image_size, cfg.image_size).permute(0, 2, 1, 3, 4)
+        with torch.no_grad():
+            t_sf = timed(lambda: OSF.slowfast_features(sf_sd, clip), reps=1)
+    per_clip = t_vit_layer * v.num_hidden_layers + t_llm_layer * l.num_hidden_layers + t_embed + t_proj + t_logits + t_sf
     return {
         "value": 1.0 / per_clip, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": (f"oracle (torch CPU bf16 eager restatement of the reference path), 1 clip: 1 full-width ViT layer x{v.num_hidden_layers} "
                    f"({t_vit_layer:.2f}s each) + 1 full-width LLM layer x{l.num_hidden_layers} ({t_llm_layer:.2f}s each, N={N}) + patch-embed "
-                   f"{t_embed:.2f}s + projector {t_proj:.2f}s + lm-head on all rows {t_logits:.2f}s; weight gen {gen_s:.0f}s untimed"),
+                   f"{t_embed:.2f}s + projector {t_proj:.2f}s + lm-head on all rows {t_logits:.2f}s + SlowFast-R50 branch {t_sf:.2f}s; weight gen {gen_s:.0f}s untimed"),
         "s_per_clip": per_clip,
     }
 
@@ -289,7 +296,7 @@ def main():
         if prof:
             line["device_calibration"] = device_calibration(dev)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, T, N)
+            line["cpu_baseline"] = cpu_baseline(cfg, T, N, slowfast=args.motion == "slowfast")
             line["gpu_over_cpu"] = clips_per_s / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if dist.is_initialized():

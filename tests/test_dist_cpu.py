@@ -25,6 +25,10 @@ class OracleBackedModel:
     def vit_tokens(self, pv):
         return O.shuffled_tokens(O.vit_forward(self.sd, self.cfg, pv), self.cfg.downsample_ratio)
 
+    def motion_feature(self, pixel_values, clips):
+        """Stand-in for the SlowFast branch: a feature that depends on EVERY frame of the clip (so a wrong frame shard shows)."""
+        return _clip_feature(pixel_values, clips, self.cfg.motion_dim)
+
     def __call__(self, mos, pixel_values, input_ids, attention_mask, image_flags, labels, motion_feature, visual_tokens):
         vit = O.projector(self.sd, "mlp1", visual_tokens)
         vit = vit[image_flags.squeeze(-1) == 1]
@@ -38,6 +42,13 @@ class OracleBackedModel:
         return {"logit": logit, "score1": O.score_head(self.sd, self.cfg, hidden[:, -4, :]).squeeze(1)}
 
 
+def _clip_feature(pixel_values, clips, dim):
+    x = pixel_values.float().reshape(clips, -1)
+    w = torch.linspace(0.5, 1.5, x.shape[1])
+    base = (x * w).mean(dim=1, keepdim=True)
+    return (base + torch.linspace(0, 1, dim)[None, :]).to(torch.float32)
+
+
 def _case():
     cfg = pkg.tiny(vit_hidden=64, vit_heads=1, vit_layers=1, vit_inter=128, llm_hidden=256, llm_heads=2, llm_kv_heads=1,
                    llm_layers=1, llm_inter=256, vocab=256, image_size=56, score_dims=(32, 1), motion_dim=128)
@@ -49,21 +60,26 @@ def _case():
     return cfg, sd, toks, pv, motion, B, T
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, use_branch=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     dist_utils.init_dist("pytorch", backend="gloo")
     cfg, sd, toks, pv, motion, B, T = _case()
     model = OracleBackedModel(cfg, sd, toks["img_context_token_id"])
     out = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
-                                    toks["labels"], motion)
+                                    toks["labels"], None if use_branch else motion)
     q.put((rank, out["score1"].float().tolist(), out["logit"].tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_frame_dp_two_ranks_equals_single_process():
+@pytest.mark.parametrize("use_branch", [False, True])
+def test_frame_dp_two_ranks_equals_single_process(use_branch):
+    """use_branch: motion_feature=None - every rank runs the model's own motion branch on the frames of ITS clips (the native SlowFast
+    branch in the product; a frame-dependent stand-in here)."""
     cfg, sd, toks, pv, motion, B, T = _case()
+    if use_branch:
+        motion = _clip_feature(pv, B, cfg.motion_dim)
     ref = O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
                          toks["labels"], motion, toks["img_context_token_id"], stage=2)
     s = socket.socket()
@@ -72,7 +88,7 @@ def test_frame_dp_two_ranks_equals_single_process():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_branch)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
