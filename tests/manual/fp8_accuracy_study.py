@@ -5,11 +5,11 @@ accumulated in fp32, output rounded to bf16 like the real layer.  Recipes:
   token/channel : one scale per activation row and per weight row (amax / 448)   - unit MFMA scales, scaling in the epilogue
   mx32          : OCP MX blocks of 32 along K with power-of-two (E8M0) scales     - v_mfma_scale_* block scales
 Synthetic random-init weights (the only ones available offline): this measures NUMERICAL drift of the forward pass, not task accuracy.
-    PYTHONPATH=. python scripts/probes/fp8_accuracy_study.py"""
+    PYTHONPATH=. python tests/manual/fp8_accuracy_study.py"""
 import math, sys
 import torch
 import torch.nn.functional as F
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import aigv_assessor_amd as pkg
 from aigv_assessor_amd import synth
 from oracle import oracle as O

@@ -1,10 +1,10 @@
 """Full-size parity run (InternVL2-8B widths and depths, one 8-frame 448x448 clip, N = 2177): the CPU oracle (torch bf16 eager
 restatement of the reference path, all 24 + 32 layers, ~1-2 min on the GPU box's host cores) against the HIP path on the same
-seeded weights and inputs.  Too slow for the test suite; run by hand:   python scripts/full_size_parity.py [seed]
+seeded weights and inputs.  Too slow for the test suite; run by hand:   python tests/manual/full_size_parity.py [seed]
 Result of round 1: profiles/parity_full_size_r1.txt"""
 import sys, time
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import aigv_assessor_amd as pkg
 from aigv_assessor_amd import synth
 from aigv_assessor_amd.modeling import InternVLChatModel

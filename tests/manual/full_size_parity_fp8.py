@@ -1,9 +1,9 @@
 """Full-size check of the fp8 mode (InternVL2-8B widths and depths, one 8-frame 448x448 clip): the HIP path in fp8 mode against
 oracle/fp8.py (the same definition evaluated on the CPU, all 32 layers), with the bf16 oracle as the yardstick for what the mode costs.
-Run by hand on the GPU box:   python scripts/full_size_parity_fp8.py [seed]      (result of round 1: profiles/parity_fp8_mode_r1.txt)"""
+Run by hand on the GPU box:   python tests/manual/full_size_parity_fp8.py [seed]      (result of round 1: profiles/parity_fp8_mode_r1.txt)"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import aigv_assessor_amd as pkg
 from aigv_assessor_amd import synth
 from aigv_assessor_amd.modeling import InternVLChatModel

@@ -1,6 +1,6 @@
 """Diagnostic: how far are the HIP path and the oracle's bf16 path from the fp32 oracle on score1? (several seeds)"""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import aigv_assessor_amd as pkg
 from aigv_assessor_amd import synth
 from aigv_assessor_amd.modeling import InternVLChatModel
