@@ -9,7 +9,8 @@
      (a single clip's 8 frames spread over 8 GPUs in latency mode);
   2. every rank runs InternViT + pixel-shuffle on its frames;
   3. ONE all-gather of the pre-projector visual tokens [F_local, 256, 4*Hv] bf16 makes all tokens visible
-     everywhere (xGMI is a full mesh: RCCL's all-gather moves each shard once over each peer link);
+     everywhere (xGMI is a full mesh: RCCL's all-gather moves each shard once over each peer link); it is started
+     asynchronously and the SlowFast motion branch of this rank's clips runs on the compute stream meanwhile;
   4. clips are split over the ranks; each rank runs projector + motion token + LLM pass + heads for its clips;
   5. a tiny all-gather returns (score, answer-row argmax) to every rank.
 Weights are replicated (8B: 16 GB, 26B: 51 GB << 288 GB HBM): no tensor/pipeline parallelism.
@@ -76,22 +77,36 @@ def even_split(n: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
-    """All-gather along dim 0 with per-rank row counts (equal counts take the single-buffer fast path)."""
+def all_gather_rows_begin(local: torch.Tensor, counts: List[int], group=None):
+    """Start an all-gather along dim 0 with per-rank row counts (equal counts take the single-buffer fast path) and return a
+    function that completes it.  Between the two calls the collective runs on RCCL's own stream: work enqueued on the compute
+    stream in the meantime overlaps with it (the completion only makes the compute stream wait, the host does not block)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return local
+        return lambda: local
     tail = tuple(local.shape[1:])
     if len(set(counts)) == 1:
         out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
+        work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=True)
+
+        def finish_equal():
+            work.wait()
+            return out
+        return finish_equal
     m = max(counts)
     pad = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    work = dist.all_gather(bufs, pad, group=group, async_op=True)
+
+    def finish_ragged():
+        work.wait()
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return finish_ragged
+
+
+def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+    return all_gather_rows_begin(local, counts, group)()
 
 
 def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
@@ -117,20 +132,23 @@ def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, a
     else:
         probe = model.vit_tokens(pixel_values[:1])     # keeps shapes/dtypes uniform on idle ranks
         local = probe[:0]
-    # 3. all-gather of pre-projector tokens
-    tokens = all_gather_rows(local, [h - l for l, h in fsplit], group)
-    # 4. clip shard -> projector + LLM pass
+    # 3. all-gather of pre-projector tokens (RCCL stream), overlapped with the motion branch of this rank's clips (compute stream)
+    gathered = all_gather_rows_begin(local, [h - l for l, h in fsplit], group)
     csplit = even_split(B, world)
     clo, chi = csplit[rank]
+    sl = slice(clo, chi)
+    fl = slice(clo * fpc, chi * fpc)
+    motion_l = None
+    if chi > clo:
+        # the SlowFast branch needs all frames of a clip, so it runs with the clip shard (motion_feature=None: the model's own branch)
+        motion_l = motion_feature[sl] if motion_feature is not None else model.motion_feature(pixel_values[fl], chi - clo)
+    tokens = gathered()
+    # 4. clip shard -> projector + LLM pass
     dev = local.device
     n1 = N - 1
     score_l = torch.zeros((chi - clo,), dtype=torch.float32, device=dev)
     logit_l = torch.full(((chi - clo) * n1,), -1, dtype=torch.long, device=dev)
     if chi > clo:
-        sl = slice(clo, chi)
-        fl = slice(clo * fpc, chi * fpc)
-        # the SlowFast branch needs all frames of a clip, so it runs with the clip shard (motion_feature=None: the model's own branch)
-        motion_l = motion_feature[sl] if motion_feature is not None else model.motion_feature(pixel_values[fl], chi - clo)
         out = model(mos=None if mos is None else mos[sl], pixel_values=None, input_ids=input_ids[sl],
                     attention_mask=None if attention_mask is None else attention_mask[sl],
                     image_flags=None if image_flags is None else image_flags[fl], labels=labels[sl],
