@@ -9,8 +9,8 @@
      (a single clip's 8 frames spread over 8 GPUs in latency mode);
   2. every rank runs InternViT + pixel-shuffle on its frames;
   3. ONE all-gather of the pre-projector visual tokens [F_local, 256, 4*Hv] bf16 makes all tokens visible
-     everywhere (xGMI is a full mesh: RCCL's all-gather moves each shard once over each peer link); it is started
-     asynchronously and the SlowFast motion branch of this rank's clips runs on the compute stream meanwhile;
+     everywhere (xGMI is a full mesh: RCCL's all-gather moves each shard once over each peer link); the SlowFast motion
+     branch of this rank's clips was started before step 2 on a side stream and runs beside the ViT shard and this collective;
   4. clips are split over the ranks; each rank runs projector + motion token + LLM pass + heads for its clips;
   5. a tiny all-gather returns (score, answer-row argmax) to every rank.
 Weights are replicated (8B: 16 GB, 26B: 51 GB << 288 GB HBM): no tensor/pipeline parallelism.
@@ -123,6 +123,16 @@ def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, a
     if F_total % B:
         raise ValueError("frames must divide evenly over the clips")
     fpc = F_total // B
+    csplit = even_split(B, world)
+    clo, chi = csplit[rank]
+    sl = slice(clo, chi)
+    fl = slice(clo * fpc, chi * fpc)
+    # 0. the motion branch of this rank's CLIPS (it needs all frames of a clip) depends on the frames only: start it first - on the
+    #    product model it runs on a side stream beside the ViT shard and the all-gather, and is joined where its result is consumed
+    motion_l = None
+    if chi > clo:
+        motion_l = motion_feature[sl] if motion_feature is not None else \
+            getattr(model, "motion_feature_async", model.motion_feature)(pixel_values[fl], chi - clo)
     # 1-2. frame shard -> ViT tokens
     fsplit = even_split(F_total, world)
     lo, hi = fsplit[rank]
@@ -132,17 +142,8 @@ def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, a
     else:
         probe = model.vit_tokens(pixel_values[:1])     # keeps shapes/dtypes uniform on idle ranks
         local = probe[:0]
-    # 3. all-gather of pre-projector tokens (RCCL stream), overlapped with the motion branch of this rank's clips (compute stream)
-    gathered = all_gather_rows_begin(local, [h - l for l, h in fsplit], group)
-    csplit = even_split(B, world)
-    clo, chi = csplit[rank]
-    sl = slice(clo, chi)
-    fl = slice(clo * fpc, chi * fpc)
-    motion_l = None
-    if chi > clo:
-        # the SlowFast branch needs all frames of a clip, so it runs with the clip shard (motion_feature=None: the model's own branch)
-        motion_l = motion_feature[sl] if motion_feature is not None else model.motion_feature(pixel_values[fl], chi - clo)
-    tokens = gathered()
+    # 3. all-gather of pre-projector tokens
+    tokens = all_gather_rows(local, [h - l for l, h in fsplit], group)
     # 4. clip shard -> projector + LLM pass
     dev = local.device
     n1 = N - 1

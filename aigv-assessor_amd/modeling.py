@@ -391,6 +391,7 @@ class InternVLChatModel(nn.Module):
     def motion_embed(self, motion_feature: torch.Tensor) -> torch.Tensor:
         """motion_mlp on the SlowFast feature [B, motion_dim] -> [B, H] (modeling_internvl_chat.py:344-345)."""
         b = motion_feature.shape[0]
+        self._join_side_stream()
         lib, ctx = self._native(n_clips=b)
         m = motion_feature.reshape(b, -1).to(device=self.device, dtype=torch.bfloat16).contiguous()
         if m.shape[1] != self.config.motion_dim:
@@ -401,7 +402,19 @@ class InternVLChatModel(nn.Module):
 
     def motion_feature(self, pixel_values: torch.Tensor, batch: int) -> torch.Tensor:
         """SlowFast feature [batch, motion_dim] of the clips in ``pixel_values`` [batch * T, 3, S, S] (modeling_internvl_chat.py:336-343)."""
+        out = self._motion_feature(pixel_values, batch, None)
+        self._join_side_stream()
+        return out
+
+    def motion_feature_async(self, pixel_values: torch.Tensor, batch: int) -> torch.Tensor:
+        """The same, without joining the side stream: the tensor is only safe to consume through ``forward(motion_feature=...)`` /
+        ``motion_embed``, which join it (used by the data-parallel scorer to start the branch before its ViT shard)."""
         return self._motion_feature(pixel_values, batch, None)
+
+    def _join_side_stream(self):
+        if getattr(self, "_side_pending", False):
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+            self._side_pending = False
 
     def _motion_feature(self, pixel_values, batch, motion_feature):
         if motion_feature is not None:
@@ -410,7 +423,22 @@ class InternVLChatModel(nn.Module):
             raise RuntimeError("the SlowFast motion branch is an input of this path: pass motion_feature=[B, "
                                f"{self.config.motion_dim}] or set model.slowfast_model (SURVEY.md §2 row 6)")
         if hasattr(self.slowfast_model, "features"):     # the native branch reads pixel_values as they are and samples the slow pathway itself
-            return self.slowfast_model.features(pixel_values.to(self.device), batch)
+            pv = pixel_values.to(self.device)
+            if not getattr(self, "overlap_motion_branch", True):
+                return self.slowfast_model.features(pv, batch)
+            # The branch depends on the frames only and its result is needed after ViT + projector: enqueue it on a side stream so that its
+            # low-occupancy kernels (the slow pathway's deep layers run ~100 workgroups) fill in around the ViT's; motion_embed() joins.
+            cur = torch.cuda.current_stream()
+            side = getattr(self, "_side_stream", None)
+            if side is None:
+                side = self._side_stream = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                feat = self.slowfast_model.features(pv, batch)
+            feat.record_stream(cur)
+            pv.record_stream(side)
+            self._side_pending = True
+            return feat
         # a user-supplied callable: reference data flow (modeling_internvl_chat.py:337-344, pack_pathway_output :97-133)
         S = self.config.image_size
         frames = pixel_values.view(batch, pixel_values.shape[0] // batch, 3, S, S).permute(0, 2, 1, 3, 4)
