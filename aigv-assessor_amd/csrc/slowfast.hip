@@ -12,6 +12,7 @@
 // The branch is ~0.05 TFLOP per clip (0.15 % of the scorer): the kernel is sized for simplicity, not for the MFMA roofline.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -37,6 +38,8 @@ struct ConvArgs {
   int To, Ho, Wo, Cout, CoutPad, Kp;
   int ld_res, ld_out, c_off, relu;
   long rows;             // B * To * Ho * Wo
+  float* part;           // split-K: fp32 slabs [k_slices][rows][Cout] (k_slices > 1), finished by conv_finalize_kernel
+  int k_slices;          // gridDim.z; Kp / 64 divisible by it
 };
 
 // Tile: 128 output positions x BN output channels per workgroup (4 waves x 32 positions), K in steps of 64 (two MFMA K-blocks per
@@ -51,6 +54,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+  // split-K: the deep layers of the slow pathway have ~100 tiles and K up to 6144 - slice z takes K range [kb, ke)
+  const int kspan = p.Kp / p.k_slices, kb = blockIdx.z * kspan;
   const int kc = tid & 7;    // which 8-wide K chunk of the 64 this thread gathers
   const int r0 = tid >> 3;   // rows r0 + 32 j
   long base[4];
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs p) {
     base[j] = b * p.Ti * p.Hi * p.Wi;
   }
   // this thread's position inside the tap grid, advanced by 64 K-elements per step
-  int c = kc * 8, dx = 0, dy = 0, dt = 0;
+  int c = kb + kc * 8, dx = 0, dy = 0, dt = 0;
   auto normalise = [&]() {
     while (c >= p.Cin) {
       c -= p.Cin;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs p) {
   for (int j = 0; j < WJ; ++j) {
     const int wrow = r0 + 32 * j;
     wv[j] = wrow < BN && (n0 + wrow) < p.CoutPad;
-    wsrc[j] = p.w + (size_t)(n0 + (wv[j] ? wrow : 0)) * p.Kp + kc * 8;
+    wsrc[j] = p.w + (size_t)(n0 + (wv[j] ? wrow : 0)) * p.Kp + kb + kc * 8;
   }
   f32x4 acc[2][NT];
 #pragma unroll
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs p) {
 #pragma unroll
   for (int j = 0; j < WJ; ++j) rw[j] = wv[j] ? *(const u16x8*)wsrc[j] : zero;
   const int slot = (kc ^ (r0 & 7)) * 8;   // (r0 + 32 j) & 7 == r0 & 7
-  for (int k0 = 0; k0 < p.Kp; k0 += BK) {
+  for (int k0 = 0; k0 < kspan; k0 += BK) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) *(u16x8*)&sA[(r0 + 32 * j) * BK + slot] = ra[j];
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs p) {
     for (int j = 0; j < WJ; ++j)
       if (r0 + 32 * j < BN) *(u16x8*)&sW[(r0 + 32 * j) * BK + slot] = rw[j];
     __syncthreads();
-    if (k0 + BK < p.Kp) {   // prefetch the next step while the MFMAs run
+    if (k0 + BK < kspan) {   // prefetch the next step while the MFMAs run
       c += BK;
       normalise();
 #pragma unroll
@@ -151,6 +156,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs p) {
     for (int n = 0; n < NT; ++n) {
       const int ch = n0 + n * 16 + (lane >> 4) * 4;
       if (ch >= p.Cout) continue;   // Cout is a multiple of 4
+      if (p.k_slices > 1) {
+        *(f32x4*)(p.part + ((size_t)blockIdx.z * p.rows + m) * p.Cout + ch) = acc[i][n];
+        continue;
+      }
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[i][n][e] + p.bias[ch + e];
@@ -165,6 +174,28 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(ConvArgs p) {
       *(u16x4*)(p.out + m * p.ld_out + p.c_off + ch) = o;
     }
   }
+}
+
+// split-K tail: slabs summed in slice order, then the same bias / residual / ReLU epilogue (deterministic)
+__global__ __launch_bounds__(256) void conv_finalize_kernel(ConvArgs p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // over rows * Cout / 4
+  const int cq = p.Cout >> 2;
+  if (i >= p.rows * cq) return;
+  const long m = i / cq;
+  const int ch = (int)(i - m * cq) * 4;
+  f32x4 v = *(const f32x4*)(p.part + (size_t)m * p.Cout + ch);
+  for (int z = 1; z < p.k_slices; ++z) v += *(const f32x4*)(p.part + ((size_t)z * p.rows + m) * p.Cout + ch);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] += p.bias[ch + e];
+  if (p.res) {
+    const u16x4 r = *(const u16x4*)(p.res + m * p.ld_res + ch);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += bf2f(r[e]);
+  }
+  u16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(p.relu ? fmaxf(v[e], 0.f) : v[e]);
+  *(u16x4*)(p.out + m * p.ld_out + p.c_off + ch) = o;
 }
 
 // frames [B*T, 3, H, W] bf16 NCHW (the tensor the ViT also reads) -> channels-last with 4 channels per pixel (3 real + 1 zero) for the
@@ -251,15 +282,38 @@ __global__ __launch_bounds__(256) void sf_pool_kernel(const bf16_t* __restrict__
   }
 }
 
-hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
+constexpr long SPLITK_MAX_ROWS = 8192;   // per launch; only the deep, narrow-M layers are split
+
+// K slices for a conv with `tiles` output tiles: enough workgroups to hide the gather latency, slices of >= 4 K-steps
+int conv_k_slices(long rows, int CoutPad, int Kp) {   // rows of ONE clip
+  if (rows > SPLITK_MAX_ROWS || Kp < 1024) return 1;
+  const int bn = CoutPad >= 64 ? 64 : CoutPad >= 32 ? 32 : 16;
+  const long tiles = ((rows + 127) / 128) * ((CoutPad + bn - 1) / bn);
+  if (tiles >= 64) return 1;
+  const int steps = Kp / 64;
+  for (int S : {8, 6, 4, 3, 2})
+    if (steps % S == 0 && steps / S >= 4 && tiles * S <= 512) return S;
+  return 1;
+}
+
+// S: K slices decided by the caller (from the PER-CLIP shape, so that a clip's bits do not depend on its batch mates); 1 without workspace
+hipError_t launch_conv(const ConvArgs& a_in, hipStream_t s, int S = 1, float* ws = nullptr, size_t ws_floats = 0) {
+  ConvArgs a = a_in;
   if (a.rows <= 0) return hipSuccess;
   if (a.Cin % 8 || a.ld_in % 8 || a.Cout % 4 || a.ld_out % 4 || a.c_off % 4 || a.Kp % 64 || a.CoutPad % 16 || (a.res && a.ld_res % 4) ||
       a.Kp < a.kt * a.kh * a.kw * a.Cin)
     return hipErrorInvalidValue;
+  if (!ws || S < 1 || (a.Kp / 64) % S || (size_t)S * a.rows * a.Cout > ws_floats) S = 1;
+  a.k_slices = S;
+  a.part = S > 1 ? ws : nullptr;
   const unsigned gx = (unsigned)((a.rows + 127) / 128);
-  if (a.CoutPad >= 64) hipLaunchKernelGGL(conv3d_mfma_kernel<64>, dim3(gx, (a.CoutPad + 63) / 64), dim3(256), 0, s, a);
-  else if (a.CoutPad >= 32) hipLaunchKernelGGL(conv3d_mfma_kernel<32>, dim3(gx, (a.CoutPad + 31) / 32), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(conv3d_mfma_kernel<16>, dim3(gx, 1), dim3(256), 0, s, a);
+  if (a.CoutPad >= 64) hipLaunchKernelGGL(conv3d_mfma_kernel<64>, dim3(gx, (a.CoutPad + 63) / 64, S), dim3(256), 0, s, a);
+  else if (a.CoutPad >= 32) hipLaunchKernelGGL(conv3d_mfma_kernel<32>, dim3(gx, (a.CoutPad + 31) / 32, S), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv3d_mfma_kernel<16>, dim3(gx, 1, S), dim3(256), 0, s, a);
+  if (S > 1) {
+    const long total = a.rows * (a.Cout / 4);
+    hipLaunchKernelGGL(conv_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 
@@ -289,6 +343,7 @@ struct Op {
   int in_buf = -1, out_buf = -1, res_buf = -1;
   size_t w_off = 0, b_off = 0;
   long rows_per_clip = 0;
+  int k_slices = 1;
   // OP_MAXPOOL / OP_POOL
   int C = 0, T = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0, ld_out = 0, c_off = 0;
   PoolW pw{};
@@ -315,6 +370,8 @@ struct aigv_slowfast {
   std::vector<bf16_t*> bufs;
   bf16_t* d_w = nullptr;
   float* d_b = nullptr;
+  float* d_part = nullptr;   // split-K slabs
+  size_t part_floats = 0;
   FrameIdx slow_idx{};
   double flops_per_clip = 0;
 };
@@ -441,6 +498,7 @@ void aigv_slowfast_destroy(aigv_slowfast* sf) {
   for (bf16_t* p : sf->bufs) hipFree(p);
   hipFree(sf->d_w);
   hipFree(sf->d_b);
+  hipFree(sf->d_part);
   delete sf;
 }
 
@@ -577,6 +635,16 @@ int aigv_slowfast_finalize(aigv_slowfast* sf) {
     if (hipMalloc((void**)&sf->bufs[i], bytes) != hipSuccess) return sf_fail(AIGV_ERR_ALLOC, "aigv_slowfast_finalize: hipMalloc(%zu) failed", bytes);
     if (hipMemset(sf->bufs[i], 0, bytes) != hipSuccess) return sf_fail(AIGV_ERR_HIP, "hipMemset failed");
   }
+  // split-K workspace: the largest slab set any eligible conv can ask for at full capacity
+  size_t need = 0;
+  for (Op& op : sf->ops) {
+    if (op.kind != OP_CONV) continue;
+    op.k_slices = conv_k_slices(op.rows_per_clip, op.a.CoutPad, op.a.Kp);
+    if (op.k_slices > 1) need = std::max(need, (size_t)op.k_slices * op.rows_per_clip * sf->Bcap * op.a.Cout);
+  }
+  sf->part_floats = need;
+  if (sf->part_floats && hipMalloc((void**)&sf->d_part, sf->part_floats * sizeof(float)) != hipSuccess)
+    return sf_fail(AIGV_ERR_ALLOC, "aigv_slowfast_finalize: hipMalloc of the split-K workspace failed");
   sf->host.clear();
   sf->finalized = true;
   return 0;
@@ -604,7 +672,7 @@ int aigv_slowfast_forward(aigv_slowfast* sf, const void* frames_nchw_bf16, int c
         a.in = sf->bufs[op.in_buf]; a.out = sf->bufs[op.out_buf]; a.res = op.res_buf >= 0 ? sf->bufs[op.res_buf] : nullptr;
         a.w = sf->d_w + op.w_off; a.bias = sf->d_b + op.b_off;
         a.rows = op.rows_per_clip * clips;
-        e = launch_conv(a, s);
+        e = launch_conv(a, s, op.k_slices, sf->d_part, sf->part_floats);
         break;
       }
       case OP_MAXPOOL: {
