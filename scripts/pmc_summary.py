@@ -7,10 +7,10 @@ of the bytes of wide coalesced streaming reads (16 B/lane, global_load and LDS-D
 for 16-B stores (the epilogue here stores 8 B per lane: taken as reported).  The counters sit on the L2's fabric side, so
 Infinity-Cache hits are included: this is L2<->fabric traffic, an upper bound on HBM traffic.
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 def load(d):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    f = max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime)   # the latest pass if the directory holds several
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
