@@ -275,3 +275,44 @@ def test_oracle_frame_normalisation_definition():
     assert y.shape == (2, 3, 4, 6) and y.dtype == torch.bfloat16
     x = u[1, 2, 3, 1].float() / 255
     assert y[1, 1, 2, 3] == ((x - 0.456) / 0.224).to(torch.bfloat16)
+
+
+def test_slowfast_host_mirror_state_dict_handling():
+    """Host side of the motion branch (no GPU): prefix normalisation, dropped tensors, the freeze-loop surface, loud failure on CPU."""
+    import pytest
+    import torch
+    from aigv_assessor_amd import synth
+    from aigv_assessor_amd.slowfast import PREFIX, SlowFastR50
+    sd = synth.slowfast_state_dict(seed=2)
+    sf = SlowFastR50(sd)
+    n_w = sum(1 for k in sd if not k.endswith("num_batches_tracked"))
+    assert len(sf.state_dict()) == n_w and all(k.startswith(PREFIX) for k in sf.state_dict())
+    # pytorchvideo's own names (blocks.N....) and the classifier / pool blocks 5, 6 that the reference drops
+    pv = {"blocks." + k[len(PREFIX):]: v for k, v in sd.items()}
+    pv["blocks.6.proj.weight"] = torch.zeros(400, 2304)
+    pv["blocks.6.proj.bias"] = torch.zeros(400)
+    sf2 = SlowFastR50(pv)
+    assert sf2.state_dict().keys() == sf.state_dict().keys()
+    assert all(torch.equal(sf2.state_dict()[k], v) for k, v in sf.state_dict().items())
+    ps = list(sf.parameters())
+    assert len(ps) == n_w and not any(p.requires_grad for p in ps)
+    with pytest.raises(RuntimeError, match="no SlowFast tensors"):
+        SlowFastR50({"vision_model.x": torch.zeros(1)})
+    with pytest.raises(RuntimeError, match="GPU only"):
+        sf.features(torch.zeros(8, 3, 224, 224), 1)
+
+
+def test_model_state_dict_with_slowfast_tensors_builds_the_branch():
+    import aigv_assessor_amd as pkg
+    from aigv_assessor_amd import synth
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    from aigv_assessor_amd.slowfast import SlowFastR50
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=1)
+    m = InternVLChatModel(cfg)
+    assert m.slowfast_model is None
+    m.load_state_dict({**synth.make_state_dict(cfg, seed=1), **synth.slowfast_state_dict(seed=1)})
+    assert isinstance(m.slowfast_model, SlowFastR50)
+    with pytest.raises(ValueError, match="precision"):
+        m.set_precision("int4")
+    m.set_precision("fp8")          # no context yet: remembered and applied when the context is built
+    assert m._precision == "fp8"
