@@ -656,6 +656,7 @@ int aigv_slowfast_forward(aigv_slowfast* sf, const void* frames_nchw_bf16, int c
   if (!sf || !frames_nchw_bf16 || !feature_bf16) return sf_fail(AIGV_ERR_ARG, "aigv_slowfast_forward: null argument");
   if (!sf->finalized) return sf_fail(AIGV_ERR_STATE, "aigv_slowfast_forward: call aigv_slowfast_finalize first");
   if (clips <= 0 || clips > sf->Bcap) return sf_fail(AIGV_ERR_ARG, "aigv_slowfast_forward: %d clips, capacity %d", clips, sf->Bcap);
+  if (hipSetDevice(sf->device) != hipSuccess) return sf_fail(AIGV_ERR_HIP, "aigv_slowfast_forward: hipSetDevice(%d) failed", sf->device);
   hipStream_t s = (hipStream_t)stream;
   for (const Op& op : sf->ops) {
     hipError_t e = hipSuccess;
@@ -703,7 +704,7 @@ int aigv_op_conv3d(const void* x, int ld_in, int Cin, int B, const int* dims, co
   a.in = (const bf16_t*)x; a.ld_in = ld_in; a.Cin = Cin; a.Ti = dims[0]; a.Hi = dims[1]; a.Wi = dims[2];
   a.kt = dims[3]; a.kh = dims[4]; a.kw = dims[5]; a.st = dims[6]; a.sh = dims[7]; a.sw = dims[8]; a.pt = dims[9]; a.ph = dims[10]; a.pw = dims[11];
   if (a.kt <= 0 || a.kh <= 0 || a.kw <= 0 || a.st <= 0 || a.sh <= 0 || a.sw <= 0 || a.pt < 0 || a.ph < 0 || a.pw < 0 || B <= 0 || Cin <= 0 || Cout <= 0 ||
-      ld_in < Cin || ld_out < c_off + Cout || a.Ti + 2 * a.pt < a.kt || a.Hi + 2 * a.ph < a.kh || a.Wi + 2 * a.pw < a.kw)
+      ld_in < Cin || ld_out < c_off + Cout || (res && ld_res < Cout) || a.Ti + 2 * a.pt < a.kt || a.Hi + 2 * a.ph < a.kh || a.Wi + 2 * a.pw < a.kw)
     return sf_fail(AIGV_ERR_ARG, "aigv_op_conv3d: bad geometry");
   a.To = (a.Ti + 2 * a.pt - a.kt) / a.st + 1; a.Ho = (a.Hi + 2 * a.ph - a.kh) / a.sh + 1; a.Wo = (a.Wi + 2 * a.pw - a.kw) / a.sw + 1;
   a.w = (const bf16_t*)w_packed; a.Kp = Kp; a.bias = bias; a.Cout = Cout; a.CoutPad = (Cout + 15) / 16 * 16;
