@@ -80,7 +80,7 @@ def test_conv3d_rejects_misaligned(lib):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("B,T,S", [(2, 8, 224), (1, 16, 256)])
+@pytest.mark.parametrize("B,T,S", [(2, 8, 224), (1, 16, 256), (1, 12, 224)])   # T = 12: slow frames 0, 5, 11; 5 temporal windows in the slow pool
 def test_slowfast_branch_matches_oracle(B, T, S):
     from aigv_assessor_amd import synth
     from aigv_assessor_amd.slowfast import SlowFastR50
