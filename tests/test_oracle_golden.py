@@ -238,3 +238,18 @@ def test_fp8_oracle_linear_and_hook_scope():
         assert torch.equal(O._llm_linear(x, w, 1, "wo"), F.linear(x, w))                     # post-attention half of the last layer: bf16
         assert torch.equal(O._llm_linear(x, w, 1, "wqkv"), O8.fp8_linear(x, w))
     assert O.LLM_LINEAR_HOOK is None
+
+
+def test_slowfast_restatement_regression_fixture():
+    """tests/golden/slowfast_oracle.pt was written by the restatement itself (make_slowfast_golden.py): a guard against accidental
+    change of oracle/slowfast.py or of the synthetic-weight recipe, not a reference vector."""
+    import os
+    from aigv_assessor_amd import synth
+    from oracle import slowfast as osf
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "slowfast_oracle.pt"), weights_only=True)
+    sd = synth.slowfast_state_dict(seed=g["seed"])
+    frames = synth.synthetic_frames(g["frames"], g["size"], seed=g["seed"]).view(1, g["frames"], 3, g["size"], g["size"]).permute(0, 2, 1, 3, 4)
+    f32 = osf.slowfast_features(sd, frames.float())
+    assert torch.allclose(f32, g["feature_fp32"], rtol=1e-4, atol=1e-4)          # conv algorithms may differ between hosts: not bitwise
+    bf = osf.slowfast_features(sd, frames).float()
+    assert (bf - g["feature_bf16"].float()).abs().mean() <= 0.01 * g["feature_fp32"].abs().mean()
