@@ -7,6 +7,8 @@
 // One workgroup = 4 waves = one 16-row slab of W (two slabs for SwiGLU); the waves split K four ways, stream
 // their W fragments straight from global memory into MFMA A-operands (no LDS round trip: every weight byte
 // is used once), keep the x fragments (L2-resident) as B-operands, and combine partial sums through LDS.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -19,8 +21,11 @@ __device__ __forceinline__ unsigned int ord_f32(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-template <int RT, int EPI>
-__global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ x, int ldx, int R,
+// NWV: waves per workgroup = K slices.  8 for the decode GEMVs whose N gives at most one workgroup per CU (wo, w2: 256 slabs of 16
+// rows): twice the loads in flight per CU, which is what bounds a weight stream at this occupancy (in-box A/B, scripts/decode_gemv_bench.py:
+// wo 7.9 -> 7.5 us, w2 26.6 -> 24.8 us = 4.7 TB/s; wqkv with 384 slabs is faster with 4 waves, 12.5 vs 13.2 us).
+template <int RT, int EPI, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restrict__ x, int ldx, int R,
                                                      const bf16_t* __restrict__ W, int ldw, int N, int K,
                                                      const bf16_t* __restrict__ bias, const bf16_t* __restrict__ resid,
                                                      int ldr, bf16_t* __restrict__ out, int ldo,
@@ -29,11 +34,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
   // W slabs (16 rows each) per workgroup.  The lm-head on the answer rows (40+ x rows) is bound by re-reading the x fragments
   // from L2 once per workgroup, not by streaming W: four slabs per workgroup share them.
   constexpr int NS = (EPI == SK_SWIGLU) ? 2 : (EPI == SK_ARGMAX && RT >= 2) ? 4 : 1;
-  __shared__ float part[3][NS][RT][4][64];
+  __shared__ float part[NWV - 1][NS][RT][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int n0 = blockIdx.x * 16 * NS;
-  const int kper = K / 4, kbeg = wave * kper;      // K % 128 == 0 checked by the launcher
+  const int kper = K / NWV, kbeg = wave * kper;      // K % (32 * NWV) == 0 checked by the launcher
 
   const bf16_t* wrow[NS];
 #pragma unroll
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
 
   // DEPTH k-steps (DEPTH x 16 B per lane per operand) are loaded before their MFMAs so several loads are in flight; a decode
   // GEMV (one x row tile, few workgroups per CU when N is small) needs the deeper form to cover the HBM latency
-  constexpr int DEPTH = (RT == 1 && NS == 1) ? 8 : 4;
+  constexpr int DEPTH = (RT == 1 && NS == 1) ? 16 : 4;
   int k = 0;
   for (; k + 32 * DEPTH <= kper; k += 32 * DEPTH) {
     bf16x8 wf[DEPTH][NS], xf[DEPTH][RT];
@@ -95,7 +100,16 @@ __global__ __launch_bounds__(256) void skinny_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[s][t][e] += (part[0][s][t][e][lane] + part[1][s][t][e][lane]) + part[2][s][t][e][lane];
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (NWV == 4) {
+          acc[s][t][e] += (part[0][s][t][e][lane] + part[1][s][t][e][lane]) + part[2][s][t][e][lane];
+        } else {
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < NWV - 1; ++w) sum += part[w][s][t][e][lane];   // fixed order
+          acc[s][t][e] += sum;
+        }
+      }
 
   // lane owns x row r = 16t + fr and W rows n = n0 + 4*fq + e
 #pragma unroll
@@ -234,6 +248,13 @@ hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int l
   const int ns = (EPI == SK_SWIGLU) ? 2 : (EPI == SK_ARGMAX && rt >= 2) ? 4 : 1;   // = NS of the kernel
   const int blocks = (N + 16 * ns - 1) / (16 * ns);
 #define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, EPI>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls)
+  if constexpr (EPI == SK_STORE || EPI == SK_RESID) {
+    static const int max8 = getenv("AIGV_SKINNY8_MAX_BLOCKS") ? atoi(getenv("AIGV_SKINNY8_MAX_BLOCKS")) : 256;   // A/B knob (scripts/decode_gemv_bench.py)
+    if (rt == 1 && K % 256 == 0 && blocks <= max8) {   // a decode GEMV with about one slab per CU: 8 K slices per workgroup
+      hipLaunchKernelGGL((skinny_kernel<1, EPI, 8>), dim3(blocks), dim3(512), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
+      return hipGetLastError();
+    }
+  }
   switch (rt) {
     case 1: GO(1); break;
     case 2: GO(2); break;
