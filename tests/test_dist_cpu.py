@@ -49,22 +49,23 @@ def _clip_feature(pixel_values, clips, dim):
     return (base + torch.linspace(0, 1, dim)[None, :]).to(torch.float32)
 
 
-def _case():
+def _case(B=3):
     cfg = pkg.tiny(vit_hidden=64, vit_heads=1, vit_layers=1, vit_inter=128, llm_hidden=256, llm_heads=2, llm_kv_heads=1,
                    llm_layers=1, llm_inter=256, vocab=256, image_size=56, score_dims=(32, 1), motion_dim=128)
     sd = synth.make_state_dict(cfg, seed=5, dtype=torch.float32, rich=True)
-    B, T = 3, 2            # 6 frames over 2 ranks = 3+3 (splits clip 1), 3 clips over 2 ranks = 2+1
+    T = 2                  # B = 3: 6 frames over 2 ranks = 3+3 (splits clip 1), 3 clips over 2 ranks = 2+1;  B = 1 (latency mode):
+                           # the clip's frames are split 1+1 and rank 1 has no clip of its own
     toks = synth.canonical_tokens(cfg, B, T, seed=5)
     pv = synth.synthetic_frames(B * T, 56, seed=5, dtype=torch.float32)
     motion = synth.synthetic_motion(B, 128, seed=5, dtype=torch.float32)
     return cfg, sd, toks, pv, motion, B, T
 
 
-def _worker(rank, world, port, q, use_branch=False):
+def _worker(rank, world, port, q, use_branch=False, n_clips=3):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     dist_utils.init_dist("pytorch", backend="gloo")
-    cfg, sd, toks, pv, motion, B, T = _case()
+    cfg, sd, toks, pv, motion, B, T = _case(n_clips)
     model = OracleBackedModel(cfg, sd, toks["img_context_token_id"])
     out = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
                                     toks["labels"], None if use_branch else motion)
@@ -73,11 +74,11 @@ def _worker(rank, world, port, q, use_branch=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_branch", [False, True])
-def test_frame_dp_two_ranks_equals_single_process(use_branch):
+@pytest.mark.parametrize("use_branch,n_clips", [(False, 3), (True, 3), (True, 1)])
+def test_frame_dp_two_ranks_equals_single_process(use_branch, n_clips):
     """use_branch: motion_feature=None - every rank runs the model's own motion branch on the frames of ITS clips (the native SlowFast
     branch in the product; a frame-dependent stand-in here)."""
-    cfg, sd, toks, pv, motion, B, T = _case()
+    cfg, sd, toks, pv, motion, B, T = _case(n_clips)
     if use_branch:
         motion = _clip_feature(pv, B, cfg.motion_dim)
     ref = O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
@@ -88,7 +89,7 @@ def test_frame_dp_two_ranks_equals_single_process(use_branch):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_branch)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_branch, n_clips)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
