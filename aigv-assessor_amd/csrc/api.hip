@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -76,6 +77,9 @@ struct aigv_ctx {
   uint8_t* q8 = nullptr;       // [max_tokens, max(H, I)] e4m3 activations of the GEMM about to run
   float* q8_scale = nullptr;   // [max_tokens]
   bool trim_last_layer = true;
+  int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2
+  size_t splitk_floats = 0;
+  float* splitk_ws = nullptr;  // fp32 slabs of the split-K row bands: owned by the context (one launch stream per context at a time)
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 3 (attention out, hidden, normed) + [64, I]
   bf16_t* l_score_ws = nullptr;
   bf16_t *kc = nullptr, *vc = nullptr;   // [layer][seq][kv head][cap][D]
@@ -198,10 +202,30 @@ double t128(int rows, int N, int nk) { return rows <= 0 ? 0 : t128_blocks((long)
 // slabs read once + the bf16 result (and residual) at ~3 TB/s, plus the launch
 double t_finalize(long rows, int N, int S) { return (double)rows * N * (4.0 * S + 4.0) / 3.0e6 + 3.0; }
 
-// fp32 scratch for split-K slices (one per process, grown on demand; one launch stream per process)
-float* g_splitk_ws = nullptr;
-size_t g_splitk_floats = 0;
+// fp32 scratch for split-K slices.  A context owns its own (allocated at aigv_ctx_create on the context's device, SPLITK_MAX_FLOATS:
+// the planner never asks for more).  The context-free single-operator entry points (aigv_op_gemm: tests, benches) use one scratch
+// per DEVICE, created on first use under a lock and kept for the process lifetime - never freed or regrown, so no launch ever
+// waits on a device synchronisation, and a second device never sees memory of the first.
 constexpr size_t SPLITK_MAX_FLOATS = (size_t)64 << 20;   // 256 MB
+constexpr int MAX_DEVICES = 64;
+float* g_op_splitk_ws[MAX_DEVICES] = {};
+std::mutex g_op_splitk_lock;
+
+int splitk_scratch(aigv_ctx* c, size_t need_floats, float** out) {
+  if (need_floats > SPLITK_MAX_FLOATS) return fail(c, AIGV_ERR_ARG, "split-K scratch: %zu floats exceed the planner's cap", need_floats);
+  if (c) {
+    if (need_floats > c->splitk_floats) return fail(c, AIGV_ERR_STATE, "split-K scratch: %zu floats exceed the context's %zu", need_floats, c->splitk_floats);
+    *out = c->splitk_ws;
+    return 0;
+  }
+  int dev = 0;
+  HIPCHK(c, hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES) return fail(c, AIGV_ERR_ARG, "device %d out of range", dev);
+  std::lock_guard<std::mutex> g(g_op_splitk_lock);
+  if (!g_op_splitk_ws[dev]) HIPCHK(c, hipMalloc((void**)&g_op_splitk_ws[dev], SPLITK_MAX_FLOATS * sizeof(float)));
+  *out = g_op_splitk_ws[dev];
+  return 0;
+}
 constexpr int SPLITS[] = {2, 3, 4, 6, 8};
 
 // rows that do not fill whole rounds are latency-bound on their K loop: split K over S workgroups per tile (fp32 slabs +
@@ -257,14 +281,10 @@ int launch_one(aigv_ctx* c, const GemmArgs& a, int epi, bool use256, hipStream_t
 }
 
 int launch_splitk(aigv_ctx* c, const GemmArgs& a, int epi, int S, bool tile256, hipStream_t s) {
-  const size_t need = (size_t)S * a.M * a.N;
-  if (need > g_splitk_floats) {
-    if (g_splitk_ws) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(g_splitk_ws)); g_splitk_ws = nullptr; g_splitk_floats = 0; }
-    HIPCHK(c, hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
-    g_splitk_floats = need;
-  }
+  float* ws = nullptr;
+  TRY(splitk_scratch(c, (size_t)S * a.M * a.N, &ws));
   GEMM_PROF(c, a, s);
-  HIPCHK(c, aigv_launch_gemm_splitk(a, epi, S, g_splitk_ws, s, tile256));
+  HIPCHK(c, aigv_launch_gemm_splitk(a, epi, S, ws, s, tile256));
   return 0;
 }
 
@@ -291,14 +311,14 @@ struct GemmPlan {
   double est_us = 0;
 };
 
-GemmPlan plan_gemm(int M, int N, int K, int epi) {
+GemmPlan plan_gemm(int M, int N, int K, int epi, int mode) {
   GemmPlan pl;
   const int nk = K / 64, sk = skinny_epi(epi);
   const bool ok256 = (N % 256 == 0);
-  if (g_gemm_mode == 1 || !ok256) { pl.last_rows = M; pl.last_kind = 2; pl.est_us = t128(M, N, nk); return pl; }
+  if (mode == 1 || !ok256) { pl.last_rows = M; pl.last_kind = 2; pl.est_us = t128(M, N, nk); return pl; }
   pl.top_tiles = -1;
   pl.est_us = t256((M + 255) / 256, N, nk);
-  if (g_gemm_mode == 2) return pl;
+  if (mode == 2) return pl;
   if (epi == EPI_PATCH) {
     if (t128(M, N, nk) < pl.est_us) { pl = GemmPlan(); pl.last_rows = M; pl.last_kind = 2; pl.est_us = t128(M, N, nk); }
     return pl;
@@ -333,11 +353,11 @@ GemmPlan plan_gemm(int M, int N, int K, int epi) {
 
 // Columns are independent too: N = 256 j + 128 (InternViT-6B: 3200, 9600) would put the whole GEMM on the 128 kernel; instead the
 // first 256 j columns take the row-band plan and only the last 128 columns run on the 128 kernel.
-int split_columns(int M, int N, int K, int epi) {   // width of the right-hand 128-kernel band, 0 = no column split
-  if (g_gemm_mode != 0 || N % 256 != 128 || N < 384 || epi == EPI_PATCH || epi == EPI_SWIGLU) return 0;
+int split_columns(int M, int N, int K, int epi, int mode) {   // width of the right-hand 128-kernel band, 0 = no column split
+  if (mode != 0 || N % 256 != 128 || N < 384 || epi == EPI_PATCH || epi == EPI_SWIGLU) return 0;
   const int nk = K / 64;
   const double whole = t128(M, N, nk);
-  const double split = plan_gemm(M, N - 128, K, epi).est_us + t128(M, 128, nk) + LAUNCH_GAP;
+  const double split = plan_gemm(M, N - 128, K, epi, mode).est_us + t128(M, 128, nk) + LAUNCH_GAP;
   return split < whole ? 128 : 0;
 }
 
@@ -354,11 +374,12 @@ GemmArgs col_slice(const GemmArgs& a, int n0, int n) {
 
 int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
-  if (const int right = split_columns(a.M, a.N, a.K, epi)) {
+  const int mode = (c && c->gemm_mode >= 0) ? c->gemm_mode : g_gemm_mode;
+  if (const int right = split_columns(a.M, a.N, a.K, epi, mode)) {
     TRY(run_gemm(c, col_slice(a, 0, a.N - right), epi, s));
     return launch_one(c, col_slice(a, a.N - right, right), epi, false, s);
   }
-  const GemmPlan pl = plan_gemm(a.M, a.N, a.K, epi);
+  const GemmPlan pl = plan_gemm(a.M, a.N, a.K, epi, mode);
   if (pl.top_tiles < 0) return launch_one(c, a, epi, true, s);
   int row = 0;
   if (pl.top_tiles > 0) {
@@ -435,13 +456,9 @@ int run_gemm_fp8(aigv_ctx* c, const bf16_t* A, int lda, int K, const uint8_t* W8
       for (int cand : {8, 6, 4, 3, 2})
         if (nk % cand == 0 && nk / cand >= 4 && tail_tiles * cand <= 288 && (size_t)cand * b.M * N <= SPLITK_MAX_FLOATS) { S = cand; break; }
     if (S >= 2) {
-      const size_t need = (size_t)S * b.M * N;
-      if (need > g_splitk_floats) {
-        if (g_splitk_ws) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(g_splitk_ws)); g_splitk_ws = nullptr; g_splitk_floats = 0; }
-        HIPCHK(c, hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
-        g_splitk_floats = need;
-      }
-      e = aigv_launch_gemm_splitk_fp8(b, epi, S, g_splitk_ws, s);
+      float* ws = nullptr;
+      TRY(splitk_scratch(c, (size_t)S * b.M * N, &ws));
+      e = aigv_launch_gemm_splitk_fp8(b, epi, S, ws, s);
     } else {
       e = aigv_launch_gemm256_fp8(b, epi, s);
     }
@@ -552,6 +569,15 @@ int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out) {
     if ((rc = dalloc(c, &c->l_packed, (size_t)64))) break;
     if ((rc = dalloc(c, &c->l_trim, (size_t)64 * (3 * k.llm_hidden + k.llm_inter)))) break;
     if ((rc = dalloc(c, &c->l_neg1, (size_t)k.max_tokens))) break;
+    {   // split-K slabs: the planner's cap, or less when no GEMM of this context can reach it (8 slices x most rows x widest N)
+      const size_t widest = (size_t)std::max(std::max(std::max(2 * k.llm_inter, c->qkv_out), std::max(k.vit_inter, 3 * k.vit_hidden)), k.llm_hidden);
+      const size_t rows = std::max((size_t)k.max_tokens, (size_t)k.vit_chunk * c->S);
+      c->splitk_floats = std::min(SPLITK_MAX_FLOATS, (size_t)8 * rows * widest);
+      void* p = nullptr;
+      if (hipMalloc(&p, c->splitk_floats * sizeof(float)) != hipSuccess) { rc = fail(c, AIGV_ERR_ALLOC, "hipMalloc(split-K scratch) failed"); break; }
+      c->allocs.push_back(p);
+      c->splitk_ws = (float*)p;
+    }
     if (hipMemset(c->l_neg1, 0xFF, (size_t)k.max_tokens * sizeof(int32_t)) != hipSuccess) { rc = fail(c, AIGV_ERR_HIP, "hipMemset failed"); break; }
     {
       int maxd = k.llm_hidden;
@@ -830,6 +856,7 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
         a.n_heads = a.n_kv_heads = k.vit_heads;
         a.q_group_stride = a.kv_head_stride = c->vit_head_dim;
         a.causal = 0; a.post_div = 1.0f; a.q_prescale = 1.0f / sqrtf((float)c->vit_head_dim);
+        a.uniform_len = 1;
         if (const char* m = aigv_attn_check(a, c->vit_head_dim)) return fail(c, AIGV_ERR_ARG, "%s", m);
         ProfScope ps(c, AIGV_PROF_ATTN_VIT, 4.0 * F * (double)c->S * c->S * Hv, 2.0 * 4 * rows * (double)Hv, s);
         HIPCHK(c, aigv_launch_attention(a, c->vit_head_dim, s));
@@ -1113,8 +1140,16 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
   for (int li = 0; li < k.llm_layers; ++li) {
     const LlmLayer& L = c->llm[li];
-    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
-    TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
+    // fp8 mode: the linears aigv_llm_prefill runs in e4m3 run in e4m3 here too (all but the post-attention half of the last layer),
+    // so a continuation scores like the same tokens inside one prefill of that mode
+    const bool f8 = c->fp8_llm, f8_post = f8 && li != k.llm_layers - 1;
+    if (f8) {
+      HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.an, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
+      TRY(run_gemm_fp8(c, nullptr, H, H, c->llm8[li].wqkv, c->llm8[li].s_wqkv, c->l_qkv, c->qkv_out, T, c->qkv_out, EPI_STORE, nullptr, 0, s));
+    } else {
+      HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
+      TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
+    }
     // RoPE: K in place (one of g + 2 slots per group); the query heads are rotated by the attention kernel as it loads them
     HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, 1, g + 2, nkv, D, s, g));
     HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, T, nkv, g, D,
@@ -1134,6 +1169,14 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
       if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
       ProfScope ps(c, AIGV_PROF_ATTN_LLM, attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
       HIPCHK(c, aigv_launch_attention(a, D, s));
+    }
+    if (f8_post) {
+      const LlmLayerFp8& Q = c->llm8[li];
+      TRY(run_gemm_fp8(c, c->l_ao, H, H, Q.wo, Q.s_wo, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
+      HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.fn, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
+      TRY(run_gemm_fp8(c, nullptr, H, H, Q.w13, Q.s_w13, c->l_ffn, I, T, 2 * I, EPI_SWIGLU, nullptr, 0, s));
+      TRY(run_gemm_fp8(c, c->l_ffn, I, I, Q.w2, Q.s_w2, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
+      continue;
     }
     {
       GemmArgs a = gemm_args(c->l_ao, H, L.wo, H, c->l_h, H, T, H, H);
@@ -1231,6 +1274,13 @@ int aigv_set_precision(aigv_ctx* c, int mode) {
 int aigv_set_row_trimming(aigv_ctx* c, int on) {
   if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_row_trimming: null context");
   c->trim_last_layer = on != 0;
+  return 0;
+}
+
+int aigv_set_gemm_mode(aigv_ctx* c, int mode) {
+  if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_gemm_mode: null context");
+  if (mode < -1 || mode > 2) return fail(c, AIGV_ERR_ARG, "aigv_set_gemm_mode: mode must be -1 (process default), 0 (auto), 1 (128 tile) or 2 (256 tile)");
+  c->gemm_mode = mode;
   return 0;
 }
 
@@ -1360,7 +1410,7 @@ int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void
   a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
   a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
   a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
-  a.causal = causal; a.post_div = post_div; a.q_prescale = q_prescale;
+  a.causal = causal & 1; a.uniform_len = (causal >> 1) & 1; a.post_div = post_div; a.q_prescale = q_prescale;
   if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));
   return 0;
@@ -1374,7 +1424,7 @@ int aigv_op_attention_rope(const void* q, int ldq, const void* k, int ldk, const
   a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.v = (const bf16_t*)v; a.ldv = ldv;
   a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
   a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
-  a.causal = causal; a.post_div = post_div; a.q_prescale = q_prescale;
+  a.causal = causal & 1; a.uniform_len = (causal >> 1) & 1; a.post_div = post_div; a.q_prescale = q_prescale;
   a.rope_pos = pos; a.rope_cos = (const bf16_t*)cos; a.rope_sin = (const bf16_t*)sin;
   if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));
@@ -1423,8 +1473,8 @@ int aigv_op_frame_resize_ingest(const void* hwc_u8, int n_frames, int in_h, int 
 int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us) {
   if (!plan || M <= 0 || N <= 0 || K <= 0 || N % 128 || K % 64 || epi < 0 || epi >= EPI_COUNT)
     return fail(nullptr, AIGV_ERR_ARG, "aigv_plan_gemm: bad problem M=%d N=%d K=%d epi=%d", M, N, K, epi);
-  const int right = split_columns(M, N, K, epi);
-  const GemmPlan pl = plan_gemm(M, N - right, K, epi);
+  const int right = split_columns(M, N, K, epi, g_gemm_mode);
+  const GemmPlan pl = plan_gemm(M, N - right, K, epi, g_gemm_mode);
   plan[6] = right;
   plan[0] = pl.top_tiles; plan[1] = pl.mid_tiles; plan[2] = pl.mid_slices; plan[3] = pl.last_rows; plan[4] = pl.last_kind;
   plan[5] = pl.last_slices;
@@ -1433,7 +1483,8 @@ int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us) {
 }
 
 int aigv_tune_attention(int waves) {
-  if (waves != 0 && waves != 4 && waves != 8) return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_attention: waves must be 0, 4 or 8, got %d", waves);
+  if (waves != 0 && waves != 4 && waves != 8 && waves != 64)
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_attention: 0 (per-shape choice), 4 / 8 (32-row kernel) or 64 (64-row kernel), got %d", waves);
   g_attn_waves = waves;
   return 0;
 }

@@ -21,26 +21,13 @@
 // truth the kernel is at least as accurate as the reference's eager path (tests/test_gpu_ops.py).
 #include "common.h"
 #include "kernels.h"
+#include "attn_lay.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int KT = 64;    // keys per tile
-
-template <int D> struct Lay;
-template <> struct Lay<64> {
-  static constexpr int ROWB = 128;
-  // K tile: 32x32 row reads (ds_read_b128) are conflict-free with chunk ^= (row>>1)&7 on 128-B rows
-  __device__ static int kchunk(int row, int ch) { return ch ^ ((row >> 1) & 7); }
-  // V tile: transposed reads take 4 consecutive keys x 64 B per 32-lane half
-  __device__ static int vchunk(int row, int ch) { return ch ^ (((row >> 1) & 1) << 2); }
-};
-template <> struct Lay<128> {
-  static constexpr int ROWB = 256;
-  __device__ static int kchunk(int row, int ch) { return ch ^ (row & 15); }
-  __device__ static int vchunk(int row, int ch) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)); }
-};
 
 // NW = waves per workgroup (32 query rows each).  More waves share one K/V tile: the LDS-DMA issue cost per wave and tile
 // (the dominant overhead next to the MFMAs) halves going from 4 to 8 waves.
@@ -60,14 +47,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs, so the linear id is remapped (bijectively) to
   // give each XCD a contiguous run of (sequence, head, query block) - the query blocks of one head, and the heads of one GQA
   // group, then stream the same K/V through ONE L2 instead of eight.
-  const int nqb = (p.max_len + QB - 1) / QB;
+  // a launch restricted to the query rows >= q_begin (the tail of a row range split between the two kernels) spans only those blocks
+  const int qb0 = p.q_begin / QB;
+  const int nqb = (p.max_len + QB - 1) / QB - qb0;
   int v;
   {
     const int total = (int)gridDim.x, bid = blockIdx.x, xcd = bid & 7, q8 = total >> 3, r8 = total & 7;
     v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   }
   int qb = v % nqb, grp = v / nqb;
-  if (!CAUSAL && (p.max_len % QB) != 0 && (p.max_len % QB) <= 32 && nqb > 1 && ((int)gridDim.x % (8 * nqb)) == 0) {
+  if (qb0 == 0 && !CAUSAL && (p.max_len % QB) != 0 && (p.max_len % QB) <= 32 && nqb > 1 && ((int)gridDim.x % (8 * nqb)) == 0) {
     // Non-causal with a nearly empty last query block per head (ViT: 1025 rows): each XCD runs its full blocks first and the
     // cheap ragged ones (key-split below) at the end, so the launch drains on short workgroups instead of on full ones.
     const int chunk = (int)gridDim.x >> 3, gpc = chunk / nqb, j = blockIdx.x >> 3, x = blockIdx.x & 7;
@@ -82,7 +71,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
   const int row0 = p.cu[seq];
   const int len = p.cu[seq + 1] - row0;          // queries (= keys appended this call)
   // causal work grows with the query block index: launch the heaviest blocks first
-  const int q0 = (CAUSAL ? nqb - 1 - qb : qb) * QB;
+  const int q0 = (qb0 + (CAUSAL ? nqb - 1 - qb : qb)) * QB;
   if (q0 >= len) return;
   if (p.q_tail > 0 && q0 + QB <= len - p.q_tail) return;   // this block's rows are not consumed (last-layer row trimming)
   const int kv_off = p.kv_off ? p.kv_off[seq] : p.kv_len_offset;   // keys in front of this sequence's first query row
@@ -530,7 +519,7 @@ const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
   return nullptr;
 }
 
-int g_attn_waves = 0;   // 0 = per-shape default, 4 / 8 = forced (A/B experiments)
+int g_attn_waves = 0;   // 0 = per-shape default; forced for A/B experiments: 4 / 8 = the 32-row kernel with that many waves, 64 = the 64-row kernel
 
 // NB = 2: deeper rings (3, 4 buffers) measured 5-15 % slower on the ViT shape - they cost resident workgroups (LDS), and
 // with four workgroups per CU the wait for the next tile is already covered by the others' work
@@ -543,22 +532,46 @@ static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int nqb = (a.max_len + NW * 32 - 1) / (NW * 32);
+  const int nqb = (a.max_len + NW * 32 - 1) / (NW * 32) - a.q_begin / (NW * 32);
   hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, NW, NB>), dim3(nqb * a.n_heads * a.n_seq), dim3(NW * 64), LDS, s, a);
   return hipGetLastError();
 }
 
-hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
+static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_t s) {
   // 4 waves (128 query rows) per workgroup.  With the XCD-aware block order the K/V stream of a head is shared in L2, and
   // 8-wave workgroups (half the K/V reads, half the resident workgroups) measured equal or slower on every headline shape
   // (scripts/attn_bench.py with AB_WAVES=1); the 8-wave form stays reachable through aigv_tune_attention for such A/Bs.
-  const int nw = g_attn_waves ? g_attn_waves : 4;
+  const int nw = g_attn_waves == 8 ? 8 : 4;
   if (head_dim == 64) {
     if (a.causal) return nw == 8 ? launch_attn<64, true, 8>(a, s) : launch_attn<64, true, 4>(a, s);
     return nw == 8 ? launch_attn<64, false, 8>(a, s) : launch_attn<64, false, 4>(a, s);
   }
   if (a.causal) return nw == 8 ? launch_attn<128, true, 8>(a, s) : launch_attn<128, true, 4>(a, s);
   return nw == 8 ? launch_attn<128, false, 8>(a, s) : launch_attn<128, false, 4>(a, s);
+}
+
+// Which kernel runs which query rows (A/B on one device, scripts/attn_bench.py with AB_WAVES=1, profiles/r2_attn_ab.txt):
+//   * non-causal (InternViT): the software-pipelined kernel of attention64.hip - 860 vs 790 TFLOP/s on 32 x 1024 rows at d = 64.
+//     For uniform sequences whose last query block holds at most 32 rows (1025 = 4 x 256 + 1) that block goes to the kernel
+//     above in its key-split form, as a second launch over just those blocks (193 vs 196 us for 32 x 1025 rows);
+//   * causal (InternLM2 prefill): the one-tile-at-a-time kernel above - 808 vs 775 TFLOP/s on 4 x 2176 rows: at d = 128 a wave
+//     holds one 32-row sub-block in both kernels (two would need more than the 256 registers a lane has at two waves per SIMD),
+//     and the pipelined form's masked half tiles and three-slot K ring cost more than its schedule gains;
+//   * short sequences (the few-token continuations of aigv_llm_extend): the kernel above.
+// aigv_tune_attention forces one kernel for experiments and tests (4 / 8: above, 64: attention64.hip).
+hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
+  if (g_attn_waves == 4 || g_attn_waves == 8) return launch_attention32(a, head_dim, s);
+  if (g_attn_waves != 64 && (a.causal || a.max_len < 192)) return launch_attention32(a, head_dim, s);
+  const int rem = a.max_len % 256;
+  if (!a.causal && a.uniform_len && a.q_tail == 0 && a.max_len > 256 && rem > 0 && rem <= 32) {
+    AttnArgs body = a, tail = a;
+    body.q_end = a.max_len - rem;
+    tail.q_begin = a.max_len - rem;
+    hipError_t e = aigv_launch_attention64(body, head_dim, s);
+    if (e != hipSuccess) return e;
+    return launch_attention32(tail, head_dim, s);
+  }
+  return aigv_launch_attention64(a, head_dim, s);
 }
 
 size_t aigv_attention_decode_ws_floats(int n_seq, int n_kv, int g, int cap) {

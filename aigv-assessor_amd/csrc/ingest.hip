@@ -277,7 +277,9 @@ struct DeviceTables {
   int *bounds_h = nullptr, *kk_h = nullptr, *bounds_v = nullptr, *kk_v = nullptr;
   int ksize_h = 0, ksize_v = 0, y_first = 0, rows = 0;
 };
-std::map<std::pair<long long, long long>, DeviceTables> g_resize_tables;   // (in_h, in_w) x (out_h, out_w), process lifetime
+// keyed by (device, (in_h, in_w), (out_h, out_w)): a table lives in the memory of the device it was built on; process lifetime,
+// written once under the lock and never regrown (a cached entry is immutable, so launches on any stream may share it)
+std::map<std::pair<int, std::pair<long long, long long>>, DeviceTables> g_resize_tables;
 std::mutex g_resize_mutex;
 
 hipError_t upload(const std::vector<int>& v, int** out) {
@@ -297,7 +299,10 @@ hipError_t aigv_launch_frame_resize_ingest(const uint8_t* hwc, int n_frames, int
   DeviceTables t;
   {
     std::lock_guard<std::mutex> lock(g_resize_mutex);
-    const auto key = std::make_pair(((long long)in_h << 32) | (unsigned)in_w, ((long long)out_h << 32) | (unsigned)out_w);
+    int dev = 0;
+    hipError_t de = hipGetDevice(&dev);
+    if (de != hipSuccess) return de;
+    const auto key = std::make_pair(dev, std::make_pair(((long long)in_h << 32) | (unsigned)in_w, ((long long)out_h << 32) | (unsigned)out_w));
     auto it = g_resize_tables.find(key);
     if (it == g_resize_tables.end()) {
       const AxisTable h = precompute_axis(in_w, out_w);

@@ -42,15 +42,20 @@ from .conversation import get_conv_template
 # ------------------------------------------------------------------------------------------------------
 # host-side weight preparation (not on the hot path: runs once per weight upload)
 # ------------------------------------------------------------------------------------------------------
-def rope_tables(head_dim: int, theta: float, n_pos: int, max_pos: int = 32768, scaling: Optional[dict] = None):
+def rope_tables(head_dim: int, theta: float, n_pos: int, max_pos: int = 32768, scaling: Optional[dict] = None,
+                seq_len: Optional[int] = None):
     """cos/sin [n_pos, head_dim/2] bf16, computed as the reference does (modeling_internlm2.py:161-243):
     fp32 inv_freq and angles, cos/sin in fp32, then cast to the activation dtype.  The reference table is
-    cat(freqs, freqs) so only the first half is stored.  Dynamic-NTK rescaling engages only past
-    max_position_embeddings (:230-235)."""
+    cat(freqs, freqs) so only the first half is stored.
+
+    ``n_pos`` is only the number of table rows (a capacity: packed tokens of a batch, KV capacity).  Dynamic-NTK
+    rescaling is decided by ``seq_len``, the length of the longest SINGLE sequence of the call - the reference keys it
+    on the per-sequence ``kv_seq_len`` (:218-243, :387-391), so a batch of many short clips is never rescaled however
+    many tokens it packs.  ``seq_len=None`` means "no sequence is longer than max_pos" (no rescale)."""
     base = float(theta)
-    if scaling is not None and scaling.get("type") == "dynamic" and n_pos > max_pos:
+    if scaling is not None and scaling.get("type") == "dynamic" and seq_len is not None and seq_len > max_pos:
         f = float(scaling["factor"])
-        base = base * ((f * n_pos / max_pos) - (f - 1)) ** (head_dim / (head_dim - 2))
+        base = base * ((f * seq_len / max_pos) - (f - 1)) ** (head_dim / (head_dim - 2))
     inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2).float() / head_dim))
     t = torch.arange(n_pos).to(inv_freq.dtype)
     if scaling is not None and scaling.get("type") == "linear":
@@ -197,24 +202,57 @@ class InternVLChatModel(nn.Module):
     # ---- construction / (de)serialisation ----------------------------------------------------------
     @classmethod
     def from_pretrained(cls, path, torch_dtype=torch.bfloat16, config: Optional[InternVLChatConfig] = None, **kw):
-        """Load ``config.json`` + ``*.safetensors`` / ``pytorch_model*.bin`` shards with the reference's
-        state-dict names (stage2_eval.py:779-780); ``slowfast_model.*`` tensors build the native motion branch."""
+        """Load ``config.json`` + the MODEL shards of a checkpoint directory with the reference's state-dict names
+        (stage2_eval.py:779-780); ``slowfast_model.*`` tensors build the native motion branch.
+
+        A directory written by the reference trainer (HF Trainer) also holds ``training_args.bin``, ``optimizer.pt``,
+        ``scheduler.pt``, ``rng_state*.pth`` and possibly ``lora_weights.pth`` (stage2_train.py:223-235): only
+        ``model*.safetensors`` / ``pytorch_model*.bin`` are read (through the ``*.index.json`` weight map when there is one),
+        ``lora_weights.pth`` is folded in by ``weights.merge_lora_state_dict``, everything else is ignored."""
         if config is None:
             config = InternVLChatConfig.from_pretrained(path)
         model = cls(config, dtype=torch_dtype, **kw)
+        model.load_state_dict(cls._read_checkpoint(path))
+        return model
+
+    @staticmethod
+    def _checkpoint_files(path) -> List[str]:
+        """The weight shards of a checkpoint directory, in load order (host logic; no tensor is read)."""
+        import json
+        names = sorted(os.listdir(path))
+        for index in ("model.safetensors.index.json", "pytorch_model.bin.index.json"):
+            if index in names:
+                with open(os.path.join(path, index)) as f:
+                    shards = sorted(set(json.load(f)["weight_map"].values()))
+                missing = [x for x in shards if x not in names]
+                if missing:
+                    raise FileNotFoundError(f"{index} names shards that are not under {path}: {missing}")
+                return shards
+        st = [f for f in names if f.endswith(".safetensors") and (f.startswith("model") or f.startswith("pytorch_model"))]
+        if st:
+            return st
+        return [f for f in names if f.startswith("pytorch_model") and f.endswith(".bin")]
+
+    @classmethod
+    def _read_checkpoint(cls, path) -> Dict[str, torch.Tensor]:
+        files = cls._checkpoint_files(path)
+        if not files:
+            raise FileNotFoundError(f"no model shards (model*.safetensors / pytorch_model*.bin) found under {path}")
         sd: Dict[str, torch.Tensor] = {}
-        files = sorted(os.listdir(path))
         for f in files:
             fp = os.path.join(path, f)
             if f.endswith(".safetensors"):
                 from safetensors.torch import load_file
                 sd.update(load_file(fp))
-            elif f.endswith(".bin") or f.endswith(".pth") or f.endswith(".pt"):
+            else:
                 sd.update(torch.load(fp, map_location="cpu", weights_only=True))
-        if not sd:
-            raise FileNotFoundError(f"no weight shards found under {path}")
-        model.load_state_dict(sd)
-        return model
+        lora = os.path.join(path, "lora_weights.pth")
+        has_adapters = any(".lora_A." in k for k in sd)
+        if os.path.exists(lora) or has_adapters:
+            from .weights import merge_lora_state_dict
+            extra = torch.load(lora, map_location="cpu", weights_only=True) if os.path.exists(lora) else None
+            sd = merge_lora_state_dict(sd, extra)
+        return sd
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         sf = {k: v for k, v in state_dict.items() if k.startswith("slowfast_model.")}
@@ -256,17 +294,32 @@ class InternVLChatModel(nn.Module):
         return torch.bfloat16
 
     # ---- native context ---------------------------------------------------------------------------------
-    def _native(self, n_frames: int = 0, n_tokens: int = 0, n_clips: int = 0, out_rows: int = 0, kv_cap: int = 0):
-        """Create (or grow) the native context and upload weights if they changed."""
+    def _rope_seq_len(self, seq_len: int) -> int:
+        """The sequence length the dynamic-NTK base is computed for, 0 = plain tables.  The reference rescales the rotary
+        base when the per-sequence ``kv_seq_len`` (the padded N of the call, plus any cache) exceeds
+        ``max_position_embeddings`` (modeling_internlm2.py:218-243); the packed token count of a batch plays no part."""
+        l = self.config.llm_config
+        sc = l.rope_scaling
+        if sc and sc.get("type") == "dynamic" and seq_len > l.max_position_embeddings:
+            return int(seq_len)
+        return 0
+
+    def _native(self, n_frames: int = 0, n_tokens: int = 0, n_clips: int = 0, out_rows: int = 0, kv_cap: int = 0,
+                seq_len: int = 0):
+        """Create (or grow) the native context and upload weights if they changed.  ``seq_len`` = the longest single
+        sequence of the call about to run (0: leave the rotary tables as they are)."""
         if self.device.type != "cuda":
             raise native.NativeError("the scorer hot path runs on an MI355X only: move the model with .cuda() "
                                      "(there is no CPU fallback)")
         lib = native.load()
         cfg, v, l = self.config, self.config.vision_config, self.config.llm_config
         key = getattr(self, "_cap", None) or dict(frames=0, tokens=0, clips=0, rows=0, kv=0)
+        # capacities only grow, in coarse steps (tokens by 512, KV by 256, output rows by 64): a context is re-created - workspaces
+        # re-allocated, weights re-uploaded - when a request exceeds one, so an answer a few tokens longer must not trigger that
+        up = lambda x, m: (int(x) + m - 1) // m * m
         want = dict(frames=max(key["frames"], n_frames, self._max_frames or 0, 1),
-                    tokens=max(key["tokens"], n_tokens, self._max_tokens, 1), clips=max(key["clips"], n_clips, self._max_clips, 1),
-                    rows=max(key["rows"], out_rows, 64), kv=max(key["kv"], kv_cap))
+                    tokens=max(key["tokens"], up(max(n_tokens, self._max_tokens, 1), 512)), clips=max(key["clips"], n_clips, self._max_clips, 1),
+                    rows=max(key["rows"], up(max(out_rows, 64), 64)), kv=max(key["kv"], up(kv_cap, 256)))
         geom = (v.image_size if cfg.force_image_size is None else cfg.force_image_size, v.hidden_size, l.vocab_size,
                 self.select_layer)
         if self._ctx is None or want != key or geom != self._ctx_key:
@@ -294,9 +347,28 @@ class InternVLChatModel(nn.Module):
             native.check(lib.aigv_ctx_create(self.device.index or 0, C.byref(c), C.byref(h)))
             self._ctx, self._cap, self._ctx_key, self._dirty = h, want, geom, True
             self._n_pos = c.max_positions
+        if seq_len:
+            ntk = self._rope_seq_len(seq_len)
+            if ntk != getattr(self, "_rope_ntk", 0):
+                self._rope_ntk = ntk
+                if not self._dirty:
+                    self._upload_rope()
         if self._dirty:
             self._upload()
         return lib, self._ctx
+
+    def _upload_rope(self):
+        """(Re)build the rotary tables: rows = the context's position capacity, base = the dynamic-NTK base of the current call."""
+        lib, ctx = native.load(), self._ctx
+        l = self.config.llm_config
+        ntk = getattr(self, "_rope_ntk", 0)
+        cos, sin = rope_tables(l.head_dim, l.rope_theta, self._n_pos, l.max_position_embeddings, l.rope_scaling, seq_len=ntk or None)
+        for name, t in (("rope.cos", cos), ("rope.sin", sin)):
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            native.check(lib.aigv_load_weight(ctx, name.encode(), t.data_ptr(), shape, t.dim(), 0, 0), ctx)
+        if not self._dirty:     # tables swapped under finalized weights: re-derive the pointers, keep the precision mode
+            native.check(lib.aigv_finalize_weights(ctx), ctx)
+            native.check(lib.aigv_set_precision(ctx, 1 if getattr(self, "_precision", "bf16") == "fp8" else 0), ctx)
 
     def _upload(self):
         lib, ctx = native.load(), self._ctx
@@ -320,12 +392,13 @@ class InternVLChatModel(nn.Module):
         if self.stage == 1:  # stage-1 flavour has no score head: a 1-wide dummy keeps the ABI uniform
             put("mlpscore.fc1.weight", torch.zeros(1, l.hidden_size, dtype=torch.bfloat16))
             put("mlpscore.fc1.bias", torch.zeros(1, dtype=torch.bfloat16))
-        cos, sin = rope_tables(l.head_dim, l.rope_theta, self._n_pos, l.max_position_embeddings, l.rope_scaling)
-        put("rope.cos", cos)
-        put("rope.sin", sin)
+        self._upload_rope()
         native.check(lib.aigv_finalize_weights(ctx), ctx)
         # finalize resets the context to bf16 and drops stale e4m3 weight copies: a re-created context or reloaded weights keep the mode
         native.check(lib.aigv_set_precision(ctx, 1 if getattr(self, "_precision", "bf16") == "fp8" else 0), ctx)
+        # per-context switches survive a re-created context
+        native.check(lib.aigv_set_gemm_mode(ctx, int(getattr(self, "_gemm_mode", -1))), ctx)
+        native.check(lib.aigv_set_row_trimming(ctx, int(getattr(self, "_row_trim", True))), ctx)
         self._dirty = False
 
     def __del__(self):
@@ -501,7 +574,7 @@ class InternVLChatModel(nn.Module):
         motion_feature = self._motion_feature(pixel_values, B, motion_feature)
 
         # ---- device work: ViT -> projector -> motion projector -> LLM pass + heads ----
-        self._native(n_frames=n_frames, n_tokens=plan["cu"][-1], n_clips=B, out_rows=len(plan["logit_rows"]))   # size workspaces once
+        self._native(n_frames=n_frames, n_tokens=plan["cu"][-1], n_clips=B, out_rows=len(plan["logit_rows"]), seq_len=N)   # size workspaces once
         vit_embeds, motion = self._visual_inputs(pixel_values, visual_tokens, motion_feature, plan)
         score, amax = self._prefill(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], motion,
                                     plan["score_rows"], plan["logit_rows"])
@@ -653,7 +726,8 @@ class InternVLChatModel(nn.Module):
         P = len(plans)
         n_suffix = sum(pl["cu"][-1] for pl in plans) - P * cu_prefix[-1]
         self._native(n_frames=n_frames, n_tokens=max(cu_prefix[-1], n_suffix), n_clips=B * P,
-                     out_rows=sum(len(pl["logit_rows"]) for pl in plans), kv_cap=longest + 1)
+                     out_rows=sum(len(pl["logit_rows"]) for pl in plans), kv_cap=longest + 1,
+                     seq_len=max(ids.shape[1] for (ids, _, _) in prompts))
         vit_embeds, motion = self._visual_inputs(pixel_values, visual_tokens, motion_feature, p0)
         self._prefill(ids_prefix, slot_prefix, cu_prefix, vit_embeds, p0["n_vis"], motion, None, [], keep_kv=True, kv_cap=longest + 1)
         lib, ctx = native.load(), self._ctx
@@ -692,11 +766,16 @@ class InternVLChatModel(nn.Module):
         return outs
 
     # ---- generation (API surface; greedy) -------------------------------------------------------------------
-    def _greedy(self, ids_packed, slot, cu, vis, n_vis, max_new_tokens: int, eos_ids: List[int], pad_id: int):
+    def _greedy(self, ids_packed, slot, cu, vis, n_vis, max_new_tokens: int, eos_ids: List[int], pad_id: int, motion=None):
         b = len(cu) - 1
         longest = max(cu[i + 1] - cu[i] for i in range(b))
         last_rows = [cu[i + 1] - 1 for i in range(b)]
-        _, nxt = self._prefill(ids_packed, slot, cu, vis, n_vis, None, None, last_rows, keep_kv=True,
+        if self._rope_seq_len(longest + max_new_tokens):
+            # the reference recomputes the dynamic-NTK base at every decode step past max_position_embeddings
+            # (modeling_internlm2.py:227-235) while its cached keys keep the base they were rotated with
+            raise NotImplementedError("decoding past max_position_embeddings with dynamic-NTK rope scaling is not implemented")
+        self._native(seq_len=longest)
+        _, nxt = self._prefill(ids_packed, slot, cu, vis, n_vis, motion, None, last_rows, keep_kv=True,
                                kv_cap=longest + max_new_tokens + 1)
         lib, ctx = native.load(), self._ctx
         done = torch.zeros(b, dtype=torch.bool, device=self.device)
@@ -773,32 +852,32 @@ class InternVLChatModel(nn.Module):
         slot = torch.arange(T, dtype=torch.int32, device=dev)          # every row comes from `emb`
         return self._greedy(ids, slot, cu, emb, T, max_new, eos, pad)
 
-    def _stage2_embeds(self, pixel_values, input_ids, image_flags, motion_feature=None):
-        """Embedding assembly of chat2 (modeling_internvl_chat.py:642-707): as forward(), with the motion token."""
-        dev = self.device
-        B, N = input_ids.shape
-        input_ids = input_ids.to(dev)
-        emb = self.language_model.model.tok_embeddings.weight[input_ids].clone()
-        vit = self.extract_feature(pixel_values)
-        vit = vit[image_flags.squeeze(-1).to(dev) == 1].reshape(-1, emb.shape[-1])
-        motion = self.motion_embed(self._motion_feature(pixel_values, B, motion_feature))
-        sel = input_ids == self.img_context_token_id
-        csum = torch.cumsum(sel, dim=1)
-        last = (csum == csum.max(dim=1, keepdim=True)[0]) & sel
-        flat = emb.view(B * N, -1)
-        flat[(sel & ~last).view(-1)] = vit
-        flat[last.view(-1)] = motion
-        return flat.view(B, N, -1)
+    @torch.no_grad()
+    def generate_stage2(self, pixel_values, input_ids, attention_mask=None, image_flags=None, motion_feature=None,
+                        generation_config=None, **generate_kwargs) -> torch.LongTensor:
+        """Greedy decode behind a stage-2 prompt: the embedding assembly of the reference's ``chat2``
+        (modeling_internvl_chat.py:642-707: all <IMG_CONTEXT> slots but the last of each clip take visual tokens, the last one the
+        motion token) followed by its ``generate2``.  Ids and slot map go to the native prefill, whose embed kernel gathers
+        token / visual / motion rows - no embedding tensor is assembled on the host side."""
+        if self.img_context_token_id is None:
+            raise AssertionError("img_context_token_id must be set (stage2_eval.py:810)")
+        max_new, eos, pad = self._gen_args(generation_config, generate_kwargs)
+        pad = self.config.llm_config.pad_token_id if pad is None else pad
+        B = input_ids.shape[0]
+        plan = self._plan(input_ids, attention_mask, None, image_flags, pixel_values.shape[0], drop_dead_tail=False)
+        motion_feature = self._motion_feature(pixel_values, B, motion_feature)
+        self._native(n_frames=pixel_values.shape[0], n_tokens=plan["cu"][-1], n_clips=B)
+        vit_embeds, motion = self._visual_inputs(pixel_values, None, motion_feature, plan)
+        return self._greedy(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], max_new, eos, pad, motion=motion)
 
     def chat2(self, tokenizer, pixel_values, input_ids, generation_config, attention_mask, history=None,
               return_history=False, image_flags=None, IMG_START_TOKEN="<img>", IMG_END_TOKEN="</img>",
               IMG_CONTEXT_TOKEN="<IMG_CONTEXT>", verbose=False, motion_feature=None):
-        """modeling_internvl_chat.py:638-767."""
+        """modeling_internvl_chat.py:638-767: pre-tokenised stage-2 prompt (with the motion slot) -> decoded response."""
         self.img_context_token_id = tokenizer.convert_tokens_to_ids(IMG_CONTEXT_TOKEN)
-        emb = self._stage2_embeds(pixel_values, input_ids, image_flags, motion_feature)
         template = get_conv_template(self.template)
         generation_config["eos_token_id"] = tokenizer.convert_tokens_to_ids(template.sep)
-        out = self.generate2(input_embeds=emb, attention_mask=attention_mask, **generation_config)
+        out = self.generate_stage2(pixel_values, input_ids, attention_mask, image_flags, motion_feature, **generation_config)
         response = tokenizer.batch_decode(out, skip_special_tokens=True)[0].split(template.sep)[0].strip()
         return (response, history) if return_history else response
 
@@ -877,10 +956,18 @@ class InternVLChatModel(nn.Module):
         if self._ctx is not None and not self._dirty:
             native.check(native.load().aigv_set_precision(self._ctx, 1 if mode == "fp8" else 0), self._ctx)
 
+    def set_gemm_mode(self, mode: int = -1):
+        """GEMM tile choice of this model's context (aigv_set_gemm_mode): -1 process default, 0 cost-model dispatch, 1 every row
+        on the 128x128 kernel (batch-invariant bits), 2 the 256x256 kernel wherever it applies."""
+        self._gemm_mode = int(mode)
+        lib, ctx = self._native()
+        native.check(lib.aigv_set_gemm_mode(ctx, int(mode)), ctx)
+
     def set_row_trimming(self, on: bool = True):
         """Last-layer row trimming (default on): the last decoder layer finishes only the rows whose hidden state is
         consumed (score row + answer rows; stage2_eval.py:940-941, modeling_internvl_chat.py:469-481).  Off = every row
         through every layer, as the reference computes it; the returned values are the same."""
+        self._row_trim = bool(on)
         lib, ctx = self._native()
         native.check(lib.aigv_set_row_trimming(ctx, int(on)), ctx)
         self.drop_dead_tail = bool(on)      # the host-side half: tokens behind a clip's last consumed row are not run

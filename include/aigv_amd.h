@@ -13,9 +13,11 @@
  * computes for un-padded rows (modeling_internlm2.py:907-912) and for left/right padded batches
  * (:1141-1147).
  *
- * Threading: one process per GPU, one launch stream per process (the reference's eval loop is single-threaded too).  A context
- * is not re-entrant, and the split-K slab scratch and the frame-resize coefficient tables are per-process, grown on first use:
- * calls on different streams or from different threads must not overlap.
+ * Threading: the intended deployment is one process per GPU (the reference's eval loop is single-threaded too).  A context is
+ * not re-entrant - calls on ONE context must not overlap, whatever their streams - but it owns all the device state it uses
+ * (weights, workspaces, split-K slab scratch), so several contexts, also on different devices of one process, are independent.
+ * The context-free aigv_op_* entry points share one split-K scratch per DEVICE (created on first use, never regrown): overlap
+ * them only from one stream per device.  Frame-resize coefficient tables are cached per (device, size pair) and immutable.
  */
 #ifndef AIGV_AMD_H
 #define AIGV_AMD_H
@@ -135,6 +137,10 @@ int aigv_set_precision(aigv_ctx* ctx, int mode);
  * copy of those rows.  Rows are independent after attention, so the outputs are those of the untrimmed pass (up to the fp32
  * summation order of the kernel that runs the few rows); off = every row through every layer, as the reference does. */
 int aigv_set_row_trimming(aigv_ctx* ctx, int on);
+/* GEMM tile choice of THIS context: -1 = follow the process default set by aigv_tune_gemm (the state after aigv_ctx_create),
+ * 0 = the cost-model dispatch, 1 = every row on the 128x128 kernel (per-row arithmetic then independent of the batch: bit-identical
+ * batch-of-N vs one-by-one results), 2 = the 256x256 kernel wherever its shape rules allow.  Split-K scratch is per context too. */
+int aigv_set_gemm_mode(aigv_ctx* ctx, int mode);
 
 /* One greedy decode step for every clip of the last keep_kv prefill (generate(): modeling_internvl_chat.py:769-811,
  * modeling_internlm2.py:1126-1163).  ids[B] int64 device (the previous tokens) -> next[B] int64 device. */
@@ -173,7 +179,8 @@ int aigv_op_rmsnorm(const void* x, int ldx, const void* w, void* y, int ldy, int
                     const int32_t* row_idx, void* stream);
 int aigv_op_rope(void* qkv, int ld, const int32_t* pos, const void* cos, const void* sin, int tokens, int n_rot,
                  int slots, int n_groups, int head_dim, void* stream);
-/* q/k/v as in kernels.h AttnArgs; cu is a DEVICE int32[n_seq+1] */
+/* q/k/v as in kernels.h AttnArgs; cu is a DEVICE int32[n_seq+1].  causal: bit 0 = causal mask; bit 1 = "every sequence has
+ * exactly max_len rows" (InternViT frames), which lets the dispatcher give a short left-over query block to the key-split kernel. */
 int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
                       const int32_t* cu, int n_seq, int max_len, int n_heads, int n_kv_heads, int q_group_stride,
                       int kv_head_stride, int head_dim, int causal, float post_div, float q_prescale, void* stream);
@@ -215,7 +222,9 @@ int aigv_tune_gemm(int mode, double rate256);
  * column band that runs on the 128x128 kernel over all rows (N = 256 j + 128: plan[0..5] then describe the first 256 j columns;
  * 0 = no column split); `plan` holds 7 ints; est_us = the model's time. */
 int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us);
-/* Waves per prefill-attention workgroup: 0 = per-shape default, 4 or 8 = forced (32 query rows per wave). */
+/* Prefill-attention kernel choice (process-wide; experiments and tests): 0 = per-shape default; 4 or 8 = the one-tile-at-a-time
+ * kernel (attention.hip, 32 query rows per wave) with that many waves per workgroup; 64 = the software-pipelined kernel
+ * (attention64.hip) for every shape. */
 int aigv_tune_attention(int waves);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */

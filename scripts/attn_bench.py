@@ -5,7 +5,7 @@ from aigv_assessor_amd import native
 from aigv_assessor_amd.native import ptr
 lib = native.load()
 BF = torch.bfloat16
-def run(name, d, causal, h, hk, lens, iters=60):
+def run(name, d, causal, h, hk, lens, iters=60, uniform=True):
     T = sum(lens); g = h // hk
     ld = hk * (g + 2) * d
     qkv = torch.randn(T, ld, device='cuda').to(BF)
@@ -14,7 +14,7 @@ def run(name, d, causal, h, hk, lens, iters=60):
     base = qkv.data_ptr()
     pre = d ** -0.5 if not causal else 1.0
     post = 1.0 if not causal else math.sqrt(d)
-    call = lambda: native.check(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(cu), len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal), post, pre, None))
+    call = lambda: native.check(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(cu), len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal) | (2 if uniform else 0), post, pre, None))
     for _ in range(3): call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -24,12 +24,15 @@ def run(name, d, causal, h, hk, lens, iters=60):
     fl = sum(4.0 * (L * (L + 1) / 2 if causal else L * L) * d * h for L in lens)
     print(f"{name}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s", flush=True)
 import os
-for rep in range(3):
-  for nw in ((0,) if not os.environ.get("AB_WAVES") else (4, 8)):
+for rep in range(2):
+  for nw in ((0,) if not os.environ.get("AB_WAVES") else (4, 64, 0)):
     native.check(lib.aigv_tune_attention(nw))
-    print(f"-- waves per workgroup: {nw or 'default'}")
+    print(f"-- kernel choice: {({0: 'default', 4: 'attention.hip, 4 waves x 32 rows', 8: 'attention.hip, 8 waves', 64: 'attention64.hip (pipelined)'})[nw]}")
     run("vit  d64  32x1025 h16", 64, False, 16, 16, [1025] * 32)
     run("vit  d64  32x1024 h16", 64, False, 16, 16, [1024] * 32)
     run("llm  d128 4x2177 h32/8", 128, True, 32, 8, [2177] * 4)
     run("llm  d128 1x4281 h32/8", 128, True, 32, 8, [4281])
+    if os.environ.get("AB_WAVES"):
+        run("d128 noncausal 8x1024 h16", 128, False, 16, 16, [1024] * 8)
+        run("llm  d128 4x2176 h32/8", 128, True, 32, 8, [2176] * 4)
 native.check(lib.aigv_tune_attention(0))

@@ -3,7 +3,9 @@ import math, sys, torch
 sys.path.insert(0, '.')
 from aigv_assessor_amd import native
 from aigv_assessor_amd.native import ptr
+import os
 lib = native.load()
+native.check(lib.aigv_tune_attention(int(os.environ.get("ATTN_KERNEL", "0"))))   # 0 default, 4 = attention.hip, 64 = attention64.hip
 BF = torch.bfloat16
 def run(d, causal, h, hk, lens, iters=6):
     T = sum(lens); g = h // hk
@@ -17,5 +19,5 @@ def run(d, causal, h, hk, lens, iters=6):
     for _ in range(iters):
         native.check(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(cu), len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal), post, pre, None))
     torch.cuda.synchronize()
-run(64, False, 16, 16, [1025] * 32)
-run(128, True, 32, 8, [2177] * 4)
+run(64, False, 16, 16, [1024] * 32)
+run(128, True, 32, 8, [2176] * 4)

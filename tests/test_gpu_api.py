@@ -1,0 +1,147 @@
+"""The chat-style API surface of the reference's InternVLChatModel on the GPU path (MI355X only): ``chat`` / ``batch_chat`` /
+``chat2`` (modeling_internvl_chat.py:533-767) and ``from_pretrained`` (stage2_eval.py:779-780), with the deterministic stub
+tokenizer of tests/stub_tokenizer.py (no tokenizer.model offline).  Expected responses = the oracle's greedy loop (the reference's
+own KV-cache decode path, pinned token-for-token in tests/test_oracle_golden.py) on the ids of the prompt string that the
+reference's conversation template renders (pinned in tests/test_host.py against tests/golden/host_inputs.pt), decoded by the same
+tokenizer.
+"""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+import aigv_assessor_amd as pkg
+from aigv_assessor_amd import synth
+from aigv_assessor_amd.conversation import get_conv_template
+from oracle import oracle as O
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from stub_tokenizer import StubTokenizer  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+NEW = 6
+
+
+@pytest.fixture(scope="module")
+def rig():
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    sd = synth.make_state_dict(cfg, seed=61, rich=True)
+    model = InternVLChatModel(cfg)
+    model.load_state_dict(sd)
+    model.eval().cuda()
+    tok = StubTokenizer(cfg.llm_config.vocab_size)
+    return model, cfg, sd, tok
+
+
+def expected_response(sd, cfg, tok, query, pv, motion=None):
+    """The oracle's greedy continuation of ``query`` (every <IMG_CONTEXT> slot takes a visual token; with ``motion`` the last one
+    takes the motion token), decoded and cut the way the reference's chat() does."""
+    enc = tok(query, return_tensors="pt")
+    ids = enc["input_ids"]
+    ctx = tok.convert_tokens_to_ids("<IMG_CONTEXT>")
+    vit = O.extract_feature(sd, cfg, pv)
+    mo = O.projector(sd, "motion_mlp", motion) if motion is not None else None
+    emb = O.scatter_embeds(sd, ids, ctx, vit, mo)
+    sep = get_conv_template("internlm2-chat").sep
+    want = O.greedy_generate(sd, cfg, emb, torch.ones_like(ids), NEW, eos_token_id=tok.convert_tokens_to_ids(sep))
+    return tok.batch_decode(want, skip_special_tokens=True)[0].split(sep)[0].strip(), want
+
+
+def render(model, question, n_patches, history=()):
+    t = get_conv_template("internlm2-chat")
+    t.system_message = model.system_message
+    for q, a in history:
+        t.append_message(t.roles[0], q)
+        t.append_message(t.roles[1], a)
+    t.append_message(t.roles[0], question)
+    t.append_message(t.roles[1], None)
+    query = t.get_prompt()
+    for n in n_patches:
+        query = query.replace("<image>", "<img>" + "<IMG_CONTEXT>" * (model.num_image_token * n) + "</img>", 1)
+    return query
+
+
+def test_chat_single_turn_and_history(rig):
+    model, cfg, sd, tok = rig
+    pv = synth.synthetic_frames(4, 224, seed=61)
+    gen = dict(max_new_tokens=NEW, do_sample=False)
+    resp, hist = model.chat(tok, pv, "Rate the clip.", gen, return_history=True)
+    assert gen["eos_token_id"] == tok.convert_tokens_to_ids("<|im_end|>")          # chat() mutates the config like the reference (:612)
+    assert model.img_context_token_id == tok.convert_tokens_to_ids("<IMG_CONTEXT>")
+    want, _ = expected_response(sd, cfg, tok, render(model, "<image>\nRate the clip.", [4]), pv)
+    assert resp == want, (resp, want)
+    assert hist == [("<image>\nRate the clip.", resp)]
+    # second turn: the history is replayed in the prompt (:600-606); no new <image>
+    resp2 = model.chat(tok, pv, "And its motion?", dict(max_new_tokens=NEW, do_sample=False), history=list(hist))
+    want2, _ = expected_response(sd, cfg, tok, render(model, "And its motion?", [4], history=hist), pv)
+    assert resp2 == want2, (resp2, want2)
+    with pytest.raises(NotImplementedError):        # sampling / beams are not on this path: loud, not silently greedy
+        model.chat(tok, pv, "Rate the clip.", dict(max_new_tokens=2, do_sample=True))
+
+
+def test_batch_chat_left_padded_prompts(rig):
+    model, cfg, sd, tok = rig
+    pv = synth.synthetic_frames(4, 224, seed=62)
+    questions = ["Is it sharp?", "Describe the temporal consistency of this clip in a few words."]
+    got = model.batch_chat(tok, pv, questions, dict(max_new_tokens=NEW, do_sample=False), num_patches_list=[2, 2])
+    assert tok.padding_side == "left"                                                # :566
+    for i, q in enumerate(questions):
+        want, _ = expected_response(sd, cfg, tok, render(model, "<image>\n" + q, [2]), pv[2 * i:2 * i + 2])
+        assert got[i] == want, (i, got[i], want)
+    with pytest.raises(NotImplementedError):
+        model.batch_chat(tok, pv, questions, dict(max_new_tokens=2), num_patches_list=[2, 2], history=[("a", "b")])
+
+
+def test_chat2_runs_the_stage2_prompt_with_the_motion_token(rig):
+    """chat2 (:638-767): pre-tokenised stage-2 prompt; all <IMG_CONTEXT> slots but the last take visual tokens, the last one the
+    motion token.  The prompt comes from prompts.build_inputs' text, cut before the answer."""
+    from aigv_assessor_amd import prompts
+    model, cfg, sd, tok = rig
+    T = 2
+    pv = synth.synthetic_frames(T, 224, seed=63)
+    motion = synth.synthetic_motion(1, cfg.motion_dim, seed=63)
+    t = get_conv_template("internlm2-chat")
+    t.append_message(t.roles[0], prompts.video_prompt("How would you rate the static quality of this video?", T))
+    t.append_message(t.roles[1], None)
+    query = t.get_prompt()
+    for n in [model.num_image_token] * T + [1]:
+        query = query.replace("<image>", "<img>" + "<IMG_CONTEXT>" * n + "</img>", 1)
+    enc = tok(query, return_tensors="pt")
+    model.img_context_token_id = tok.convert_tokens_to_ids("<IMG_CONTEXT>")
+    resp = model.chat2(tok, pv, enc["input_ids"], dict(max_new_tokens=NEW, do_sample=False), enc["attention_mask"],
+                       image_flags=torch.ones(T, 1, dtype=torch.long), motion_feature=motion)
+    want, want_ids = expected_response(sd, cfg, tok, query, pv, motion=motion)
+    assert resp == want, (resp, want)
+    # the token-level surface under it
+    got_ids = model.generate_stage2(pv, enc["input_ids"], enc["attention_mask"], torch.ones(T, 1, dtype=torch.long), motion,
+                                    max_new_tokens=NEW, eos_token_id=tok.convert_tokens_to_ids("<|im_end|>"))
+    assert torch.equal(got_ids.cpu()[:, :want_ids.shape[1]], want_ids)
+
+
+def test_from_pretrained_checkpoint_scores_like_the_loaded_state_dict(rig, tmp_path):
+    """safetensors shards + index + the trainer's side files (stage2_eval.py:779-780) -> the same scores as load_state_dict."""
+    from safetensors.torch import save_file
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    model, cfg, sd, tok = rig
+    keys = sorted(sd)
+    half = len(keys) // 2
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    save_file({k: sd[k].contiguous() for k in keys[:half]}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[half:]}, str(d / "model-00002-of-00002.safetensors"))
+    wm = {k: ("model-00001-of-00002.safetensors" if i < half else "model-00002-of-00002.safetensors") for i, k in enumerate(keys)}
+    (d / "model.safetensors.index.json").write_text(json.dumps({"metadata": {}, "weight_map": wm}))
+    (d / "config.json").write_text(json.dumps(cfg.to_dict()))
+    torch.save({"lr": 1e-4}, str(d / "training_args.bin"))
+    torch.save({"state": {}}, str(d / "optimizer.pt"))
+    m2 = InternVLChatModel.from_pretrained(str(d), torch_dtype=torch.bfloat16).eval().cuda()
+    toks = synth.canonical_tokens(cfg, 2, 2, seed=64)
+    kw = dict(mos=None, pixel_values=synth.synthetic_frames(4, 224, seed=64), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+              image_flags=torch.ones(4, 1, dtype=torch.long), labels=toks["labels"], motion_feature=synth.synthetic_motion(2, cfg.motion_dim, seed=64))
+    model.img_context_token_id = m2.img_context_token_id = toks["img_context_token_id"]
+    a, b = model(**kw), m2(**kw)
+    assert torch.equal(a["score1"], b["score1"]) and torch.equal(a["logit"], b["logit"])

@@ -346,7 +346,7 @@ def attn_truth(q, k, v, causal, scale_pre, post_div, dtype):
     return (p @ vv).transpose(0, 1)
 
 
-def run_attention(lib, q, k, v, lens, causal, d, pre, post):
+def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False):
     from aigv_assessor_amd.native import ptr
     T, h, hk = q.shape[0], q.shape[1], k.shape[1]
     g = h // hk
@@ -361,18 +361,33 @@ def run_attention(lib, q, k, v, lens, causal, d, pre, post):
     out = torch.full((T, h * d), float("nan"), dtype=BF, device="cuda")
     base = dq.data_ptr()
     sync(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(dev(cu)),
-                               len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal), post, pre, None), lib)
+                               len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal) | (2 if uniform else 0), post, pre, None), lib)
     return out.cpu().view(T, h, d)
 
 
+# kernel: 0 = the dispatcher's choice (with the uniform-length hint where the lengths are equal: the 1025-row ViT shape then runs
+# its 1024 full rows on the pipelined kernel and the left-over row on the key-split kernel), 4 = the one-tile-at-a-time kernel
+# (attention.hip), 64 = the software-pipelined kernel (attention64.hip) for every row, short blocks and ragged tiles included
+@pytest.mark.parametrize("kernel", [0, 4, 64])
 @pytest.mark.parametrize("d,causal,h,hk,lens", [
     (64, False, 2, 2, [1025, 1025, 1025]),       # ViT: 448 px frames, cls tail row
     (64, False, 3, 3, [257, 257]),               # ViT: 224 px
+    (64, False, 2, 2, [512, 300, 33]),           # ragged non-causal: full, partial and one-sub-block query blocks
     (128, True, 4, 2, [200, 77]),                # LLM: GQA, ragged clips
     (128, True, 8, 2, [513, 64, 1]),             # group of 4, tile-boundary lengths, length-1 clip
     (128, True, 2, 1, [1300]),
+    (128, True, 8, 2, [2176]),                   # the canonical clip: 17 x 128 rows, 34 key tiles
+    (128, False, 2, 2, [384, 129]),              # InternViT-6B head width, non-causal
 ])
-def test_attention_matches_eager_reference(lib, d, causal, h, hk, lens):
+def test_attention_matches_eager_reference(lib, d, causal, h, hk, lens, kernel):
+    sync(lib.aigv_tune_attention(kernel), lib)
+    try:
+        _attention_case(lib, d, causal, h, hk, lens, uniform=(kernel == 0 and len(set(lens)) == 1))
+    finally:
+        sync(lib.aigv_tune_attention(0), lib)
+
+
+def _attention_case(lib, d, causal, h, hk, lens, uniform):
     g = torch.Generator().manual_seed(sum(lens) + d)
     T = sum(lens)
     q = (torch.randn(T, h, d, generator=g) * 1.5).to(BF)
@@ -382,7 +397,7 @@ def test_attention_matches_eager_reference(lib, d, causal, h, hk, lens):
     k[lens[0] // 2] *= 6.0
     pre = d ** -0.5 if not causal else 1.0
     post = 1.0 if not causal else math.sqrt(d)
-    got = run_attention(lib, q, k, v, lens, causal, d, pre, post).double()
+    got = run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform).double()
     off = 0
     for n in lens:
         sl = slice(off, off + n)

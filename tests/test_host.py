@@ -208,6 +208,17 @@ def test_host_weight_prep_matches_oracle():
     cos, sin = rope_tables(128, 1e6, 300, 32768, {"type": "dynamic", "factor": 2.0})
     oc, os_ = O.rope_tables(128, 1e6, 300, torch.bfloat16, 32768, {"type": "dynamic", "factor": 2.0})
     assert torch.equal(cos, oc[:, :64]) and torch.equal(cos, oc[:, 64:]) and torch.equal(sin, os_[:, :64])
+    # dynamic NTK is keyed on the longest SINGLE sequence (modeling_internlm2.py:218-243), never on the table's row count:
+    # a 900-row table (packed capacity of a batch) for sequences of at most 300 tokens under max_pos 512 is NOT rescaled ...
+    dyn = {"type": "dynamic", "factor": 2.0}
+    cos, sin = rope_tables(128, 1e6, 900, 512, dyn, seq_len=None)
+    oc, os_ = O.rope_tables(128, 1e6, 300, torch.bfloat16, 512, dyn)
+    assert torch.equal(cos[:300], oc[:, :64]) and torch.equal(sin[:300], os_[:, :64])
+    # ... and a 700-token sequence is, with the base of ITS length, whatever the table holds
+    cos, sin = rope_tables(128, 1e6, 900, 512, dyn, seq_len=700)
+    oc, os_ = O.rope_tables(128, 1e6, 700, torch.bfloat16, 512, dyn)
+    assert torch.equal(cos[:700], oc[:, :64]) and torch.equal(sin[:700], os_[:, :64])
+    assert not torch.equal(cos[:300], rope_tables(128, 1e6, 300, 512, dyn)[0])
     pos = torch.randn(1, 1025, 32, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16)
     assert torch.equal(resized_pos_table(pos, 32, 16), O.vit_pos_embed(pos, 32, 16, 16))
     assert torch.equal(resized_pos_table(pos, 32, 32), pos)       # identity at the native grid
@@ -316,3 +327,102 @@ def test_model_state_dict_with_slowfast_tensors_builds_the_branch():
         m.set_precision("int4")
     m.set_precision("fp8")          # no context yet: remembered and applied when the context is built
     assert m._precision == "fp8"
+
+
+def test_from_pretrained_reads_only_the_model_shards(tmp_path):
+    """A checkpoint directory as the reference trainer leaves it (HF Trainer files + stage2_train.py:223-235's
+    lora_weights.pth): only the model shards are loaded, the LoRA file is merged, the rest is ignored."""
+    import json
+    from safetensors.torch import save_file
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=1)
+    sd = synth.make_state_dict(cfg, seed=5, rich=True)
+    keys = sorted(sd)
+    half = len(keys) // 2
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    save_file({k: sd[k].contiguous() for k in keys[:half]}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[half:]}, str(d / "model-00002-of-00002.safetensors"))
+    wm = {k: ("model-00001-of-00002.safetensors" if i < half else "model-00002-of-00002.safetensors") for i, k in enumerate(keys)}
+    (d / "model.safetensors.index.json").write_text(json.dumps({"metadata": {}, "weight_map": wm}))
+    (d / "config.json").write_text(json.dumps(cfg.to_dict()))
+    # what a Trainer run leaves beside the shards: none of it may be read as weights
+    torch.save({"not": "a tensor dict", "lr": 1e-4}, str(d / "training_args.bin"))
+    torch.save({"state": {0: {"exp_avg": torch.zeros(3)}}}, str(d / "optimizer.pt"))
+    torch.save({"last_epoch": 3}, str(d / "scheduler.pt"))
+    torch.save({"cpu": torch.zeros(8, dtype=torch.uint8)}, str(d / "rng_state.pth"))
+    assert InternVLChatModel._checkpoint_files(str(d)) == ["model-00001-of-00002.safetensors", "model-00002-of-00002.safetensors"]
+    m = InternVLChatModel.from_pretrained(str(d), torch_dtype=torch.bfloat16)
+    got = m.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    # + a LoRA adapter file: folded into the named weight by W + 2 * B @ A
+    name = "language_model.model.layers.0.attention.wo"
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(8, sd[name + ".weight"].shape[1], generator=g) * 0.05
+    b = torch.randn(sd[name + ".weight"].shape[0], 8, generator=g) * 0.05
+    torch.save({"language_model.base_model.model.model.layers.0.attention.wo.lora_A.default.weight": a,
+                "language_model.base_model.model.model.layers.0.attention.wo.lora_B.default.weight": b}, str(d / "lora_weights.pth"))
+    m2 = InternVLChatModel.from_pretrained(str(d), torch_dtype=torch.bfloat16)
+    want = (sd[name + ".weight"].float() + 2.0 * (b @ a)).to(torch.bfloat16)
+    assert torch.equal(m2.state_dict()[name + ".weight"], want)
+    assert torch.equal(m2.state_dict()["mlp1.1.weight"], sd["mlp1.1.weight"])
+    # a pytorch_model.bin checkpoint, and a directory without shards
+    d2 = tmp_path / "bin"
+    d2.mkdir()
+    torch.save(sd, str(d2 / "pytorch_model.bin"))
+    torch.save({"x": 1}, str(d2 / "training_args.bin"))
+    (d2 / "config.json").write_text(json.dumps(cfg.to_dict()))
+    m3 = InternVLChatModel.from_pretrained(str(d2))
+    assert all(torch.equal(m3.state_dict()[k], sd[k]) for k in sd)
+    d3 = tmp_path / "empty"
+    d3.mkdir()
+    (d3 / "config.json").write_text(json.dumps(cfg.to_dict()))
+    torch.save({"x": 1}, str(d3 / "training_args.bin"))
+    with pytest.raises(FileNotFoundError):
+        InternVLChatModel.from_pretrained(str(d3))
+
+
+def test_build_inputs_and_get_index_match_the_reference(golden_dir):
+    """prompts.build_inputs / get_index against outputs of the reference's own preprocess_internlm (dataset.py:595-682) and
+    get_index (stage2_eval.py:429-441), recorded by tests/golden/make_host_golden.py with the stub tokenizer."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from stub_tokenizer import StubTokenizer
+    from aigv_assessor_amd import prompts
+    from aigv_assessor_amd.conversation import get_conv_template
+    g = torch.load(os.path.join(golden_dir, "host_inputs.pt"), weights_only=False)
+    tok = StubTokenizer(92553)
+    assert len(g["samples"]) >= 6
+    for s in g["samples"]:
+        got = prompts.build_inputs(tok, s["question"], s["answer"], s["n_frames"], s["num_image_token"])
+        assert torch.equal(got["input_ids"], s["input_ids"]), (s["n_frames"], s["question"])
+        assert torch.equal(got["labels"], s["labels"])
+        assert torch.equal(got["attention_mask"], s["attention_mask"])
+        n_ctx = int((got["input_ids"] == tok.special["<IMG_CONTEXT>"]).sum())
+        if s["n_frames"] * s["num_image_token"] + 1 < 4096 - 100:
+            assert n_ctx == s["n_frames"] * s["num_image_token"] + 1            # 256 per frame + ONE motion slot (stage2_eval.py:493-494)
+            lab = got["labels"][got["labels"] != -100]
+            assert tok.decode(lab) == s["answer"].strip() + "<|im_end|>"           # answer + closing <|im_end|> (dataset.py:643-666)
+        else:
+            # 16 frames do not fit max_seq_length 4096: the reference truncates and ends with every label ignored (SURVEY.md §5)
+            assert got["input_ids"].numel() == 4096 and bool((got["labels"] == -100).all())
+    assert len(g["get_index"]) >= 100
+    for c in g["get_index"]:
+        assert prompts.get_index(c["bound"], c["fps"], c["max_frame"], 0, c["num_segments"]) == c["indices"], c
+    # the chat template, as chat() renders it
+    t = get_conv_template("internlm2-chat")
+    assert t.sep == g["chat_prompts"]["sep"] and t.system_message == g["chat_prompts"]["system_message"]
+    t.append_message(t.roles[0], "<image>\nDescribe the quality.")
+    t.append_message(t.roles[1], None)
+    assert t.get_prompt() == g["chat_prompts"]["single"]
+    t = get_conv_template("internlm2-chat")
+    t.append_message(t.roles[0], "<image>\nDescribe the quality.")
+    t.append_message(t.roles[1], "It is fair.")
+    t.append_message(t.roles[0], "And the motion?")
+    t.append_message(t.roles[1], None)
+    assert t.get_prompt() == g["chat_prompts"]["history"]
+    # batching pads like the reference's collator and the plan strips it again
+    b = prompts.batch_inputs([prompts.build_inputs(tok, q, a, 4, 64) for q, a in (("Q one?", "Short."), ("A longer question?", "A longer answer."))])
+    assert b["input_ids"].shape[0] == 2 and int(b["attention_mask"][0].sum()) < b["input_ids"].shape[1] == int(b["attention_mask"][1].sum())
+    assert bool((b["labels"][0][~b["attention_mask"][0]] == -100).all()) and bool((b["input_ids"][0][~b["attention_mask"][0]] == 2).all())
