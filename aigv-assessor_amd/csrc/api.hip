@@ -1304,9 +1304,11 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
   for (int li = 0; li < k.llm_layers; ++li) {
     const LlmLayer& L = c->llm[li];
     HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, B, H, k.rms_eps, nullptr, s));
-    TRY(run_skinny(c, c->l_t, H, B, L.wqkv, H, c->qkv_out, H, nullptr, nullptr, 0, c->l_qkv, c->qkv_out, 0, s));
-    HIPCHK(c, aigv_launch_rope_kv_store(c->l_qkv, c->qkv_out, c->dec_seq, c->dec_pos, c->rope_cos, c->rope_sin, c->kc + li * kv_layer,
-                                        c->vc + li * kv_layer, B, nkv, g, D, k.kv_capacity, s));
+    {   // wqkv with RoPE + KV-cache append in its epilogue: one launch instead of GEMV + rope / store
+      ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * B * (double)c->qkv_out * H, 2.0 * (double)c->qkv_out * H, s);
+      HIPCHK(c, aigv_launch_skinny_rope_kv(c->l_t, H, B, L.wqkv, H, c->qkv_out, H, c->l_qkv, c->qkv_out, c->dec_pos, c->dec_seq, c->rope_cos,
+                                           c->rope_sin, c->kc + li * kv_layer, c->vc + li * kv_layer, g, nkv, k.kv_capacity, D, s));
+    }
     HIPCHK(c, aigv_launch_attention_decode(c->l_qkv, c->qkv_out, (g + 2) * D, c->kc + li * kv_layer, c->vc + li * kv_layer,
                                            c->dec_kvlen, k.kv_capacity, c->l_ao, H, B, nkv, g, D, sqrtf((float)D), max_vis,
                                            c->dec_ws, s));

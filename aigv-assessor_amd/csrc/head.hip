@@ -14,7 +14,18 @@
 
 namespace {
 
-enum { SK_STORE = 0, SK_RESID = 1, SK_SWIGLU = 2, SK_GELU = 3, SK_ARGMAX = 4, SK_RELU = 5, SK_LS_RESID = 6 };
+enum { SK_STORE = 0, SK_RESID = 1, SK_SWIGLU = 2, SK_GELU = 3, SK_ARGMAX = 4, SK_RELU = 5, SK_LS_RESID = 6, SK_ROPE_KV = 7 };
+
+// SK_ROPE_KV: the decode step's wqkv GEMV with RoPE and the KV-cache append in its epilogue (head_dim 128).  A workgroup takes the
+// two 16-row slabs of W that rotate_half pairs - dims 16 sub .. and 64 + 16 sub .. of one head slot - so a lane ends up holding
+// x_i and x_{i+64} of the same token: query slots are rotated and stored to the qkv row, the K slot is rotated and the V slot
+// copied straight into the caches (modeling_internlm2.py:247-261, 397-402; same three bf16 roundings as rope_kernel).
+struct RopeKvArgs {
+  const int32_t* pos; const int32_t* seq;      // position / cache sequence of every x row (device)
+  const bf16_t* cos; const bf16_t* sin;        // [max_pos, 64]
+  bf16_t* kc; bf16_t* vc;                      // [seq][kv head][cap][128]
+  int g, n_kv, cap;
+};
 
 __device__ __forceinline__ unsigned int ord_f32(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -24,25 +35,35 @@ __device__ __forceinline__ unsigned int ord_f32(float f) {
 // NWV: waves per workgroup = K slices.  8 for the decode GEMVs whose N gives at most one workgroup per CU (wo, w2: 256 slabs of 16
 // rows): twice the loads in flight per CU, which is what bounds a weight stream at this occupancy (in-box A/B, scripts/decode_gemv_bench.py:
 // wo 7.9 -> 7.5 us, w2 26.6 -> 24.8 us = 4.7 TB/s; wqkv with 384 slabs is faster with 4 waves, 12.5 vs 13.2 us).
-template <int RT, int EPI, int NWV = 4>
+// NT: the weight fragments are loaded non-temporally (each byte is used once: no point in keeping it in L2 / Infinity Cache, and a
+// once-read stream lands sooner with the nt policy - MI355X_MICROARCH.md 'nt-weights').
+template <bool NT>
+__device__ __forceinline__ bf16x8 wload(const bf16_t* p) {
+  if constexpr (NT) return __builtin_nontemporal_load((const bf16x8*)p);
+  else return *(const bf16x8*)p;
+}
+
+template <int RT, int EPI, int NWV = 4, bool NT = false>
 __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restrict__ x, int ldx, int R,
                                                      const bf16_t* __restrict__ W, int ldw, int N, int K,
                                                      const bf16_t* __restrict__ bias, const bf16_t* __restrict__ resid,
                                                      int ldr, bf16_t* __restrict__ out, int ldo,
                                                      unsigned long long* __restrict__ packed,
-                                                     const bf16_t* __restrict__ ls) {
+                                                     const bf16_t* __restrict__ ls, const RopeKvArgs rk = RopeKvArgs{}) {
   // W slabs (16 rows each) per workgroup.  The lm-head on the answer rows (40+ x rows) is bound by re-reading the x fragments
   // from L2 once per workgroup, not by streaming W: four slabs per workgroup share them.
-  constexpr int NS = (EPI == SK_SWIGLU) ? 2 : (EPI == SK_ARGMAX && RT >= 2) ? 4 : 1;
+  constexpr int NS = (EPI == SK_SWIGLU || EPI == SK_ROPE_KV) ? 2 : (EPI == SK_ARGMAX && RT >= 2) ? 4 : 1;
   __shared__ float part[NWV - 1][NS][RT][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int n0 = blockIdx.x * 16 * NS;
+  // SK_ROPE_KV: block = (head slot, 16-dim group); its two slabs are 64 rows apart
+  const int n0 = EPI == SK_ROPE_KV ? (int)(blockIdx.x >> 2) * 128 + (int)(blockIdx.x & 3) * 16 : blockIdx.x * 16 * NS;
+  constexpr int SLAB_STEP = EPI == SK_ROPE_KV ? 64 : 16;
   const int kper = K / NWV, kbeg = wave * kper;      // K % (32 * NWV) == 0 checked by the launcher
 
   const bf16_t* wrow[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) wrow[s] = W + (size_t)min(n0 + s * 16 + fr, N - 1) * ldw + kbeg + fq * 8;
+  for (int s = 0; s < NS; ++s) wrow[s] = W + (size_t)min(n0 + s * SLAB_STEP + fr, N - 1) * ldw + kbeg + fq * 8;
   const bf16_t* xrow[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) xrow[t] = x + (size_t)min(t * 16 + fr, R - 1) * ldx + kbeg + fq * 8;
@@ -62,7 +83,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) wf[u][s] = *(const bf16x8*)(wrow[s] + k + 32 * u);
+      for (int s = 0; s < NS; ++s) wf[u][s] = wload<NT>(wrow[s] + k + 32 * u);
 #pragma unroll
       for (int t = 0; t < RT; ++t) xf[u][t] = *(const bf16x8*)(xrow[t] + k + 32 * u);
     }
@@ -77,7 +98,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
   for (; k < kper; k += 32) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const bf16x8 wf = *(const bf16x8*)(wrow[s] + k);
+      const bf16x8 wf = wload<NT>(wrow[s] + k);
 #pragma unroll
       for (int t = 0; t < RT; ++t)
         acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, *(const bf16x8*)(xrow[t] + k), acc[s][t], 0, 0, 0);
@@ -130,6 +151,29 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
       unsigned long long o = __shfl_xor(best, 16, 64); best = o > best ? o : best;
       o = __shfl_xor(best, 32, 64); best = o > best ? o : best;
       if (fq == 0 && r < R) atomicMax(packed + r, best);
+    } else if constexpr (EPI == SK_ROPE_KV) {
+      if (r < R) {
+        const int hs = blockIdx.x >> 2, d = (int)(blockIdx.x & 3) * 16 + 4 * fq;   // head slot; dims d .. d+3 and d+64 .. d+67
+        const int slot = hs % (rk.g + 2), gi = hs / (rk.g + 2);
+        const int p = rk.pos[r];
+        u16x4 olo, ohi;
+        if (slot <= rk.g) {
+          const u16x4 co = *(const u16x4*)(rk.cos + (size_t)p * 64 + d), si = *(const u16x4*)(rk.sin + (size_t)p * 64 + d);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x1 = rbf(acc[0][t][e]), x2 = rbf(acc[1][t][e]), cc = bf2f(co[e]), ss = bf2f(si[e]);
+            olo[e] = f2bf(rbf(x1 * cc) + rbf(-x2 * ss));
+            ohi[e] = f2bf(rbf(x2 * cc) + rbf(x1 * ss));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { olo[e] = f2bf(acc[0][t][e]); ohi[e] = f2bf(acc[1][t][e]); }
+        }
+        bf16_t* dst = slot < rk.g ? out + (size_t)r * ldo + (size_t)hs * 128 + d
+                                  : (slot == rk.g ? rk.kc : rk.vc) + (((size_t)rk.seq[r] * rk.n_kv + gi) * rk.cap + p) * 128 + d;
+        *(u16x4*)dst = olo;
+        *(u16x4*)(dst + 64) = ohi;
+      }
     } else if constexpr (EPI == SK_SWIGLU) {
       if (r < R) {
         const int n = n0 / 2 + 4 * fq;
@@ -247,13 +291,19 @@ hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int l
   const int rt = (R + 15) / 16;
   const int ns = (EPI == SK_SWIGLU) ? 2 : (EPI == SK_ARGMAX && rt >= 2) ? 4 : 1;   // = NS of the kernel
   const int blocks = (N + 16 * ns - 1) / (16 * ns);
+  static const bool nt = getenv("AIGV_SKINNY_NT") ? atoi(getenv("AIGV_SKINNY_NT")) != 0 : true;   // A/B knob (scripts/decode_gemv_bench.py)
 #define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, EPI>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls)
   if constexpr (EPI == SK_STORE || EPI == SK_RESID) {
     static const int max8 = getenv("AIGV_SKINNY8_MAX_BLOCKS") ? atoi(getenv("AIGV_SKINNY8_MAX_BLOCKS")) : 256;   // A/B knob (scripts/decode_gemv_bench.py)
     if (rt == 1 && K % 256 == 0 && blocks <= max8) {   // a decode GEMV with about one slab per CU: 8 K slices per workgroup
-      hipLaunchKernelGGL((skinny_kernel<1, EPI, 8>), dim3(blocks), dim3(512), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
+      if (nt) hipLaunchKernelGGL((skinny_kernel<1, EPI, 8, true>), dim3(blocks), dim3(512), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
+      else hipLaunchKernelGGL((skinny_kernel<1, EPI, 8>), dim3(blocks), dim3(512), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
       return hipGetLastError();
     }
+  }
+  if (rt == 1 && nt) {   // the decode GEMVs and other one-tile weight streams
+    hipLaunchKernelGGL((skinny_kernel<1, EPI, 4, true>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
+    return hipGetLastError();
   }
   switch (rt) {
     case 1: GO(1); break;
@@ -267,6 +317,28 @@ hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int l
 }
 
 }  // namespace
+
+// the decode step's wqkv projection with RoPE + KV-cache append in the epilogue (SK_ROPE_KV above); x rows = one new token per sequence
+hipError_t aigv_launch_skinny_rope_kv(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, bf16_t* qkv, int ldo,
+                                      const int32_t* pos, const int32_t* seq, const bf16_t* cos, const bf16_t* sin, bf16_t* kc, bf16_t* vc,
+                                      int g, int n_kv, int cap, int head_dim, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  if (R > 64 || K % 128 || (ldx % 8) || (ldw % 8) || (ldo % 4) || head_dim != 128 || N != n_kv * (g + 2) * 128 || !pos || !seq || !cos ||
+      !sin || !kc || !vc)
+    return hipErrorInvalidValue;
+  RopeKvArgs rk{pos, seq, cos, sin, kc, vc, g, n_kv, cap};
+  const int rt = (R + 15) / 16, blocks = N / 32;
+#define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, SK_ROPE_KV, 4, true>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk)
+  switch (rt) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef GO
+  return hipGetLastError();
+}
 
 // epi: 0 store(+bias) | 1 residual(+bias) | 2 swiglu (16-row interleaved w1/w3, out is N/2 wide) | 3 gelu(+bias)
 //      6 layer-scale + residual (+bias)

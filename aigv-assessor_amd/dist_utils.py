@@ -142,21 +142,29 @@ def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, a
     else:
         probe = model.vit_tokens(pixel_values[:1])     # keeps shapes/dtypes uniform on idle ranks
         local = probe[:0]
-    # 3. all-gather of pre-projector tokens
-    tokens = all_gather_rows(local, [h - l for l, h in fsplit], group)
-    # 4. clip shard -> projector + LLM pass
+    # 3. all-gather of pre-projector tokens: started here, completed where its result is first needed.  RCCL runs it on its own
+    #    stream, so whatever this rank enqueues in between overlaps with it.
+    finish_tokens = all_gather_rows_begin(local, [h - l for l, h in fsplit], group)
+    # 4. clip shard -> projector + LLM pass.  When the frames of this rank's clips all lie inside its own frame shard (B a multiple
+    #    of the world size: the throughput mode of SURVEY.md 8e) the pass needs no remote token and runs while the collective is in
+    #    flight; otherwise (a clip's frames spread over ranks: latency mode, ragged splits) it waits for the gathered tokens.
     dev = local.device
     n1 = N - 1
     score_l = torch.zeros((chi - clo,), dtype=torch.float32, device=dev)
     logit_l = torch.full(((chi - clo) * n1,), -1, dtype=torch.long, device=dev)
+    own = chi > clo and lo <= clo * fpc and chi * fpc <= hi
+    tokens = None if own else finish_tokens()
     if chi > clo:
+        vis = local[clo * fpc - lo: chi * fpc - lo] if own else tokens[fl]
         out = model(mos=None if mos is None else mos[sl], pixel_values=None, input_ids=input_ids[sl],
                     attention_mask=None if attention_mask is None else attention_mask[sl],
                     image_flags=None if image_flags is None else image_flags[fl], labels=labels[sl],
-                    motion_feature=motion_l, visual_tokens=tokens[fl])
+                    motion_feature=motion_l, visual_tokens=vis)
         logit_l = out["logit"]
         if "score1" in out:
             score_l = out["score1"].float()
+    if own:
+        finish_tokens()       # every rank ends the step holding every token (the mandated collective), without having waited for it
     # 5. results everywhere
     counts = [h - l for l, h in csplit]
     score = all_gather_rows(score_l, counts, group)

@@ -187,6 +187,7 @@ class InternVLChatModel(nn.Module):
         self._ctx = None
         self._ctx_key = None
         self._dirty = True
+        self._rope_ntk = 0                  # sequence length the dynamic-NTK rotary base is currently built for (0: plain tables)
 
         dev = torch.device(device) if device is not None else torch.device("cpu")
         self.vision_model = _VisionModel(self)

@@ -10,6 +10,13 @@ in HBM before the timed region.  Workload at N = 1: BASELINE.json configs[1] (ba
 at N > 1 every rank adds its own 4 clips (weak scaling, BASELINE.json configs[2] at N = 8) with the frame-DP
 all-gather of visual tokens over RCCL.  Prints ONE JSON line on rank 0.
 
+Inputs of the timed step are bf16 NCHW frames RESIDENT in HBM: no host-to-device copy and no resize / normalise inside the step
+(the reference loop copies per clip, stage2_eval.py:919-921); `--ingest` puts both inside (pinned uint8 720p frames -> H2D ->
+aigv_op_frame_resize_ingest -> the same step) as a separately reported variant, never the headline `value`.
+`--dry-run-cpu` executes the multi-process control flow of this file (process group, barriers, all_reduce(MAX), the lock-step
+second pass, the result gather of score_clips_dp) on gloo with a trivial stand-in model: a rehearsal of the N > 1 path on a
+machine without GPUs, not a measurement.
+
 `roofline`: the bf16 MFMA GEMM kernel (95 % of the FLOPs) timed live with HIP events on the launch stream during the
 timed steps; `cpu_baseline`: the CPU oracle (torch CPU restatement of the reference path) timed on this box's host
 cores on a bounded sample (full-width layers, reduced depth, scaled by layer counts) — a reported baseline only.
@@ -101,12 +108,22 @@ def cpu_baseline(cfg, T, N, budget_s=30.0, slowfast=False):
         with torch.no_grad():
             t_sf = timed(lambda: OSF.slowfast_features(sf_sd, clip), reps=1)
     per_clip = t_vit_layer * v.num_hidden_layers + t_llm_layer * l.num_hidden_layers + t_embed + t_proj + t_logits + t_sf
+    # the same two layers in fp32 (the reference's other CPU dtype; on hosts without a bf16 matrix unit it is the FASTER of the two)
+    with torch.no_grad():
+        sd32 = {k: (t.float() if t.is_floating_point() else t) for k, t in sd.items()}
+        mask32 = O.additive_mask(torch.ones(1, N, dtype=torch.bool), N, 0, torch.float32)
+        t_vit32 = timed(lambda: O.vit_layer(sd32, small, 0, xv.float()), reps=1)
+        t_llm32 = timed(lambda: O.llm_layer(sd32, small, 0, xl.float(), mask32, pos), reps=1)
+    per_clip32 = t_vit32 * v.num_hidden_layers + t_llm32 * l.num_hidden_layers + t_embed + t_proj + t_logits + t_sf
     return {
         "value": 1.0 / per_clip, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": (f"oracle (torch CPU bf16 eager restatement of the reference path), 1 clip: 1 full-width ViT layer x{v.num_hidden_layers} "
                    f"({t_vit_layer:.2f}s each) + 1 full-width LLM layer x{l.num_hidden_layers} ({t_llm_layer:.2f}s each, N={N}) + patch-embed "
                    f"{t_embed:.2f}s + projector {t_proj:.2f}s + lm-head on all rows {t_logits:.2f}s + SlowFast-R50 branch {t_sf:.2f}s; weight gen {gen_s:.0f}s untimed"),
         "s_per_clip": per_clip,
+        "fp32": {"value": 1.0 / per_clip32, "s_per_clip": per_clip32,
+                 "sample": f"the same layers in fp32: ViT layer {t_vit32:.2f}s, LLM layer {t_llm32:.2f}s (other terms as above)"},
+        "oracle_vs_reference": "wall time of this oracle against the imported reference on one host: profiles/r2_oracle_vs_reference_walltime.txt",
     }
 
 
@@ -135,6 +152,66 @@ def device_calibration(dev):
             "note": "measured right after the timed steps (chip warm: 1.28-1.35 PFLOP/s seen); the same launch from a cold start reads 1.46-1.68 PFLOP/s depending on the box"}
 
 
+class _DryRunModel:
+    """--dry-run-cpu stand-in: the members score_clips_dp and the timed loop touch, as cheap deterministic functions of the
+    inputs (no kernels, no oracle).  Exists to execute THIS FILE's multi-process control flow on a machine without GPUs."""
+    stage = 2
+    slowfast_model = None
+
+    def __init__(self, cfg):
+        self.cfg, self.device = cfg, torch.device("cpu")
+
+    def vit_tokens(self, pv):
+        m = pv.float().mean(dim=(1, 2, 3))
+        return m.view(-1, 1, 1).expand(pv.shape[0], self.cfg.num_image_token, self.cfg.proj_in).to(torch.bfloat16).contiguous()
+
+    def motion_feature(self, pv, clips):
+        return pv.float().reshape(clips, -1).mean(1, keepdim=True).expand(clips, self.cfg.motion_dim).contiguous()
+
+    def __call__(self, mos=None, pixel_values=None, input_ids=None, attention_mask=None, image_flags=None, labels=None,
+                 motion_feature=None, visual_tokens=None):
+        B = input_ids.shape[0]
+        vt = visual_tokens if visual_tokens is not None else self.vit_tokens(pixel_values)
+        mf = motion_feature if motion_feature is not None else self.motion_feature(pixel_values, B)
+        score = (vt.float().reshape(B, -1).mean(1) + mf.float().reshape(B, -1).mean(1)).to(torch.bfloat16)
+        logit = torch.where(labels[:, 1:] != -100, (input_ids[:, 1:] + 1) % 7, torch.full_like(input_ids[:, 1:], -1)).reshape(-1)
+        return {"score1": score, "logit": logit, "label": labels[:, 1:].reshape(-1)}
+
+    def prof_enable(self, on):
+        pass
+
+
+def decode_metric(model, cfg, toks, pv, T, n_short=9, n_long=41):
+    """Greedy decode at batch 1 behind clip 0's prompt (generate(): modeling_internvl_chat.py:769-811): ms per new token from the
+    difference of two runs (same prefill, 32 more tokens), and the fraction of the 8 TB/s HBM roof the weight stream reaches -
+    a decode step reads every decoder weight and the lm-head once."""
+    l = cfg.llm_config
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    ids = toks["input_ids"][:1, :n_prompt].clone()
+    ctx_id = toks["img_context_token_id"]
+    ids[0, (ids[0] == ctx_id).nonzero()[-1]] = 7          # generate() prompts carry no motion slot: turn it into a text token
+    am = torch.ones_like(ids)
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = model.generate(pixel_values=pv[:T], input_ids=ids, attention_mask=am, max_new_tokens=n, do_sample=False, eos_token_id=None)
+        torch.cuda.synchronize()
+        assert out.shape[1] == n
+        return time.perf_counter() - t0
+    run(n_long)                                            # sizes the KV cache (re-creates the context once) and warms up
+    t_s = min(run(n_short) for _ in range(3))
+    t_l = min(run(n_long) for _ in range(3))
+    ms = 1e3 * (t_l - t_s) / (n_long - n_short)
+    d = l.head_dim
+    per_layer = (l.num_attention_heads + 2 * l.num_key_value_heads) * d * l.hidden_size + l.hidden_size * l.hidden_size + 3 * l.hidden_size * l.intermediate_size
+    weight_bytes = 2.0 * (l.num_hidden_layers * per_layer + l.vocab_size * l.hidden_size)
+    kv_bytes = 2.0 * 2 * l.num_hidden_layers * l.num_key_value_heads * d * (n_prompt + (n_short + n_long) / 2)
+    return {"decode_ms_per_token": ms, "decode_batch": 1, "decode_prompt_tokens": n_prompt,
+            "decode_bytes_per_token": weight_bytes + kv_bytes, "decode_hbm_tb_per_s": (weight_bytes + kv_bytes) / (ms * 1e-3) / 1e12,
+            "decode_hbm_frac_of_8tbps": (weight_bytes + kv_bytes) / (ms * 1e-3) / 8.0e12}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +230,9 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event roofline measurement")
     ap.add_argument("--all-rows", action="store_true", help="A/B: run every row through the last decoder layer (no row trimming)")
     ap.add_argument("--force-dp", action="store_true", help="route a 1-GPU run through the frame/clip-DP scorer too (debug)")
+    ap.add_argument("--ingest", action="store_true", help="variant: pinned uint8 720p frames -> H2D -> resize + normalise on the GPU inside every step")
+    ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on gloo / CPU with a stand-in model (no measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,54 +242,75 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1 or (args.force_dp and "RANK" in os.environ):
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dry = args.dry_run_cpu
+    if dry:
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback (--dry-run-cpu rehearses the control flow only)")
+        torch.cuda.set_device(local_rank)
+        if world > 1 or (args.force_dp and "RANK" in os.environ):
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import aigv_assessor_amd as pkg
     from aigv_assessor_amd import synth
     from aigv_assessor_amd.dist_utils import score_clips_dp
     from aigv_assessor_amd.modeling import InternVLChatModel
 
-    cfg = pkg.internvl2_8b() if args.model == "8b" else pkg.internvl2_26b() if args.model == "26b" else pkg.tiny(image_size=448)
+    if dry:
+        cfg = pkg.tiny(image_size=56)
+    else:
+        cfg = pkg.internvl2_8b() if args.model == "8b" else pkg.internvl2_26b() if args.model == "26b" else pkg.tiny(image_size=448)
     T, Bl = args.frames, args.clips_per_gpu
     B = Bl * world
     N = synth.canonical_len(cfg, T)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
 
-    model = InternVLChatModel(cfg, device=dev, max_clips=Bl, max_frames=max(Bl * T, (B * T + world - 1) // world),
-                              max_tokens=Bl * N)
-    sd = synth.make_state_dict(cfg, seed=0, device=dev, rich=True)
-    model.load_state_dict(sd)
-    del sd
     toks = synth.canonical_tokens(cfg, B, T, seed=0)
-    model.img_context_token_id = toks["img_context_token_id"]
-    model.eval()
-    if args.all_rows:
-        model.set_row_trimming(False)
-    if args.precision == "fp8":
-        model.set_precision("fp8")
+    if dry:
+        model = _DryRunModel(cfg)
+    else:
+        model = InternVLChatModel(cfg, device=dev, max_clips=Bl, max_frames=max(Bl * T, (B * T + world - 1) // world),
+                                  max_tokens=Bl * N)
+        sd = synth.make_state_dict(cfg, seed=0, device=dev, rich=True)
+        model.load_state_dict(sd)
+        del sd
+        model.img_context_token_id = toks["img_context_token_id"]
+        model.eval()
+        if args.all_rows:
+            model.set_row_trimming(False)
+        if args.precision == "fp8":
+            model.set_precision("fp8")
     # inputs resident in HBM before the timed region (token ids are host data in the reference loop; tiny either way)
     pv = synth.synthetic_frames(B * T, cfg.image_size, seed=0, device=dev)
     motion = synth.synthetic_motion(B, cfg.motion_dim, seed=0, device=dev) if args.motion == "input" else None
-    if args.motion == "slowfast":
+    if args.motion == "slowfast" and not dry:
         from aigv_assessor_amd.slowfast import SlowFastR50
         model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=0))
     flags = torch.ones(B * T, 1, dtype=torch.long)
     ids, labels, am = toks["input_ids"], toks["labels"], toks["attention_mask"]
+    frames_u8 = None
+    if args.ingest and not dry:
+        # the variant with the data path inside the step: decoded 720p frames in pinned host memory (what a video decoder hands
+        # over) -> one H2D copy -> Pillow-exact BICUBIC resize to the model size + normalise on the GPU (aigv_op_frame_resize_ingest)
+        g8 = torch.Generator().manual_seed(5)
+        frames_u8 = torch.randint(0, 256, (B * T // world if world > 1 else B * T, 720, 1280, 3), dtype=torch.uint8, generator=g8).pin_memory()
 
     def step():
+        x = pv
+        if frames_u8 is not None and world == 1:
+            x = model.ingest_frames(frames_u8.to(dev, non_blocking=True))
         if world == 1 and not args.force_dp:
-            return model(mos=None, pixel_values=pv, input_ids=ids, attention_mask=am, image_flags=flags, labels=labels,
+            return model(mos=None, pixel_values=x, input_ids=ids, attention_mask=am, image_flags=flags, labels=labels,
                          motion_feature=motion)
-        return score_clips_dp(model, pv, ids, am, flags, labels, motion)
+        return score_clips_dp(model, x, ids, am, flags, labels, motion)
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         out = step()
@@ -227,7 +328,7 @@ def main():
     # ---- roofline pass: the same K steps again with one HIP-event pair around every GEMM / attention launch on the
     # launch stream.  Kept out of the timed region above because ~900 event records per step cost ~10 % of wall time;
     # the per-launch durations themselves are unaffected (they agree with the rocprofv3 kernel trace in profiles/).
-    prof = rank == 0 and not args.no_prof
+    prof = rank == 0 and not args.no_prof and not dry
     dt_prof = None
     if prof:
         model.prof_enable(True)
@@ -246,21 +347,28 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert torch.isfinite(out["score1"].float()).all()
+    if dry:
+        # what the rehearsal can check: every rank ends with the full result, equal to the stand-in applied to all clips at once
+        whole = model(mos=None, pixel_values=pv, input_ids=ids, attention_mask=am, image_flags=flags, labels=labels, motion_feature=motion)
+        assert torch.equal(out["score1"], whole["score1"]) and torch.equal(out["logit"], whole["logit"]), "data-parallel result differs"
 
     if rank == 0:
         fl = flops_per_clip(cfg, T, N, answer_rows=10)
         clips_per_s = B * args.steps / dt
         line = {
-            "metric": f"scored clips/sec ({T}-frame {cfg.image_size}x{cfg.image_size}, InternVL2-{args.model.upper()} stage-2 score eval)", "value": clips_per_s,
+            "metric": f"scored clips/sec ({T}-frame {cfg.image_size}x{cfg.image_size}, InternVL2-{args.model.upper()} stage-2 score eval)" if not dry else
+                      "DRY RUN on CPU / gloo with a stand-in model: control-flow rehearsal, not a measurement", "value": clips_per_s,
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "fp8 (e4m3 InternLM2 prefill linears, fp32 accumulate; everything else bf16)", "data": "synthetic",
             "config": {"workload": f"InternVL2-{args.model.upper()} stage-2 score eval, {Bl} clips/GPU x {T} frames x {cfg.image_size}px, "
                                    f"N={N} tokens/clip, canonical token layout (SURVEY.md 8d); random-init weights",
                        "motion_branch": "SlowFast-R50 on the frames, inside the step" if args.motion == "slowfast" else "synthetic motion_feature input",
+                       "inputs": ("bf16 NCHW frames resident in HBM before the timed region: no H2D copy, no resize / normalise inside the step"
+                                  if frames_u8 is None else "pinned uint8 720p frames: H2D copy + BICUBIC resize + normalise INSIDE the step (--ingest variant)"),
                        "global_batch_clips": B, "frames_per_clip": T, "tokens_per_clip": N,
                        "parallelism": f"frame/clip-dp{world}" + (" + RCCL all-gather of visual tokens" if world > 1 else "")},
-            "slowfast_tflop_per_clip": (model.slowfast_model.flops_per_clip() / 1e12 if args.motion == "slowfast" else 0.0),   # not in the figures below
+            "slowfast_tflop_per_clip": (model.slowfast_model.flops_per_clip() / 1e12 if args.motion == "slowfast" and not dry else 0.0),   # not in the figures below
             "algorithmic_tflop_per_clip": fl["total"] / 1e12,
             "executed_tflop_per_clip": (fl["total"] if args.all_rows else fl["executed"]) / 1e12,
             "achieved_tflops_whole_step_per_gpu": (fl["total"] if args.all_rows else fl["executed"]) * B / dt / 1e12 / world * args.steps,
@@ -295,7 +403,11 @@ def main():
                                         "kernel": "gemm256_kernel<EPI, 7, FP8> (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales); activation quantisation passes not included"}
         if prof:
             line["device_calibration"] = device_calibration(dev)
-        if world == 1 and not args.no_cpu_baseline:
+        if dry:
+            line["dry_run"] = True
+        if world == 1 and not dry and not args.no_decode and args.model == "8b" and args.precision == "bf16":
+            line.update(decode_metric(model, cfg, toks, pv, T))
+        if world == 1 and not dry and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, T, N, slowfast=args.motion == "slowfast")
             line["gpu_over_cpu"] = clips_per_s / line["cpu_baseline"]["value"]
         print(json.dumps(line))

@@ -49,23 +49,23 @@ def _clip_feature(pixel_values, clips, dim):
     return (base + torch.linspace(0, 1, dim)[None, :]).to(torch.float32)
 
 
-def _case(B=3):
+def _case(B=3, T=2):
     cfg = pkg.tiny(vit_hidden=64, vit_heads=1, vit_layers=1, vit_inter=128, llm_hidden=256, llm_heads=2, llm_kv_heads=1,
                    llm_layers=1, llm_inter=256, vocab=256, image_size=56, score_dims=(32, 1), motion_dim=128)
     sd = synth.make_state_dict(cfg, seed=5, dtype=torch.float32, rich=True)
-    T = 2                  # B = 3: 6 frames over 2 ranks = 3+3 (splits clip 1), 3 clips over 2 ranks = 2+1;  B = 1 (latency mode):
-                           # the clip's frames are split 1+1 and rank 1 has no clip of its own
+    # T = 2, B = 3: 6 frames over 2 ranks = 3+3 (splits clip 1), 3 clips over 2 ranks = 2+1;  B = 1 (latency mode):
+    # the clip's frames are split 1+1 and rank 1 has no clip of its own
     toks = synth.canonical_tokens(cfg, B, T, seed=5)
     pv = synth.synthetic_frames(B * T, 56, seed=5, dtype=torch.float32)
     motion = synth.synthetic_motion(B, 128, seed=5, dtype=torch.float32)
     return cfg, sd, toks, pv, motion, B, T
 
 
-def _worker(rank, world, port, q, use_branch=False, n_clips=3):
+def _worker(rank, world, port, q, use_branch=False, n_clips=3, n_frames=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     dist_utils.init_dist("pytorch", backend="gloo")
-    cfg, sd, toks, pv, motion, B, T = _case(n_clips)
+    cfg, sd, toks, pv, motion, B, T = _case(n_clips, n_frames)
     model = OracleBackedModel(cfg, sd, toks["img_context_token_id"])
     out = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
                                     toks["labels"], None if use_branch else motion)
@@ -74,11 +74,15 @@ def _worker(rank, world, port, q, use_branch=False, n_clips=3):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_branch,n_clips", [(False, 3), (True, 3), (True, 1)])
-def test_frame_dp_two_ranks_equals_single_process(use_branch, n_clips):
+# world 2: ragged clip / frame splits, latency mode (one clip over two ranks);  world 4: BASELINE config 4's shape (8 clips x 16
+# frames: every rank's clips lie inside its own frame shard, so the LLM pass overlaps the token all-gather), a clip count the
+# ranks do not divide (5 clips, 10 frames -> 3+3+2+2 frames, 2+1+1+1 clips), and fewer clips than ranks (2 clips on 4 ranks)
+@pytest.mark.parametrize("world,use_branch,n_clips,n_frames", [(2, False, 3, 2), (2, True, 3, 2), (2, True, 1, 2), (2, False, 4, 2),
+                                                                (4, True, 8, 16), (4, False, 5, 2), (4, True, 2, 4)])
+def test_frame_dp_equals_single_process(world, use_branch, n_clips, n_frames):
     """use_branch: motion_feature=None - every rank runs the model's own motion branch on the frames of ITS clips (the native SlowFast
     branch in the product; a frame-dependent stand-in here)."""
-    cfg, sd, toks, pv, motion, B, T = _case(n_clips)
+    cfg, sd, toks, pv, motion, B, T = _case(n_clips, n_frames)
     if use_branch:
         motion = _clip_feature(pv, B, cfg.motion_dim)
     ref = O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
@@ -89,7 +93,7 @@ def test_frame_dp_two_ranks_equals_single_process(use_branch, n_clips):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_branch, n_clips)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, use_branch, n_clips, n_frames)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -108,3 +112,28 @@ def test_even_split_and_init_dist_errors():
     assert sum(h - l for l, h in dist_utils.even_split(7, 3)) == 7
     with pytest.raises(ValueError):
         dist_utils.init_dist("bogus")
+
+
+def test_bench_multi_process_control_flow_dry_run():
+    """bench.py's N > 1 path (process group, barriers around the timed region, all_reduce(MAX) of the rank times, the lock-step
+    second pass, score_clips_dp's collectives) executed end to end with torch.distributed.run on gloo / CPU and a stand-in model
+    (`--dry-run-cpu`): the launch line is the driver's, with 2 ranks.  A rehearsal of the control flow, not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu",
+           "--clips-per-gpu", "2", "--frames", "2"]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints ONE json line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["dry_run"] is True
+    assert out["config"]["global_batch_clips"] == 4 and out["scaling"] == "weak" and out["value"] > 0
