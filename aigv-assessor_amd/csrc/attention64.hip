@@ -33,6 +33,12 @@ typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr int KT = 64;    // keys per tile
+// Timing ablations (wrong results; scripts/attn_ablate.py builds variants with -DATTN64_ABL=<bits>): 4 no DMA in the loop, 8 no P.V
+// MFMAs, 16 no Q.K MFMAs, 32 no LDS fragment reads, 64 no softmax, 128 no row maxima, 256 one key tile per block, 512 no query
+// load, 1024 no output store.  0 in every build that ships.
+#ifndef ATTN64_ABL
+#define ATTN64_ABL 0
+#endif
 // "no key seen yet" for the running softmax reference: a large FINITE negative, so that no (-inf) - (-inf) ever arises - the file
 // is compiled with -fno-honor-nans (without it every fmaxf on an MFMA result costs an extra canonicalising v_max_f32)
 constexpr float M_NONE = -1.0e30f;
@@ -118,7 +124,7 @@ __device__ __forceinline__ void attn64_run(const AttnArgs& p, const Blk& b, cons
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
     const int qr = qs[j] + c;
-    const bool ok = qr < b.q_lim;
+    const bool ok = qr < b.q_lim && !(ATTN64_ABL & 512);
     const bf16_t* qp = p.q + (size_t)(b.row0 + (ok ? qr : 0)) * p.ldq + (size_t)(b.hq / b.g) * p.q_group_stride + (b.hq % b.g) * D;
     u16x8 raw[NKS];
 #pragma unroll
@@ -144,7 +150,7 @@ __device__ __forceinline__ void attn64_run(const AttnArgs& p, const Blk& b, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) raw[ks][e] = f2bf(bf2f(raw[ks][e]) * p.q_prescale);
       }
-      if (!ok) raw[ks] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (!ok || (ATTN64_ABL & 512)) raw[ks] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
       qf[j][ks] = __builtin_bit_cast(bf16x8, raw[ks]);
     }
   }
@@ -297,13 +303,14 @@ __device__ __forceinline__ void attn64_run(const AttnArgs& p, const Blk& b, cons
     bf16x8 pf[NQ][2];
     s16x8 vf[2][NDT];
     float mn[NQ];
-    vload(vf, kt & 1, st);        // stage 1: V^T fragments of this half tile on their way ...
-    qk(nxt, kf);                  //          matrix pipe on S(next) ...
-    softmax(cur, pf);             //          ... VALU on P(this)
+    if constexpr (!(ATTN64_ABL & 32)) vload(vf, kt & 1, st);        // stage 1: V^T fragments of this half tile on their way ...
+    if constexpr (!(ATTN64_ABL & 16)) qk(nxt, kf);                  //          matrix pipe on S(next) ...
+    if constexpr (!(ATTN64_ABL & 64)) softmax(cur, pf);             //          ... VALU on P(this)
     __builtin_amdgcn_sched_barrier(0);
-    if (load_k3) kload(kf, kslot3, st3);   // stage 2: K fragments of the half tile after next on their way ...
-    pv(pf, vf);                   //          matrix pipe on P(this).V(this) ...
-    rowmax(nxt, mn);              //          ... VALU on the row maxima of S(next)
+    if constexpr (!(ATTN64_ABL & 32)) { if (load_k3) kload(kf, kslot3, st3); }   // stage 2: K fragments of the half tile after next ...
+    if constexpr (!(ATTN64_ABL & 8)) pv(pf, vf);                   //          matrix pipe on P(this).V(this) ...
+    if constexpr (!(ATTN64_ABL & 128)) rowmax(nxt, mn);            //          ... VALU on the row maxima of S(next)
+    else { for (int j = 0; j < NQ; ++j) mn[j] = m_run[j]; }
     const int key0 = kt2 * KT + st2 * 32;
     bool any_mask = key0 + 32 > b.kv_len;
 #pragma unroll
@@ -336,8 +343,10 @@ __device__ __forceinline__ void attn64_run(const AttnArgs& p, const Blk& b, cons
     // K(kt+1) and V(kt) have landed and are visible; K(kt-1)'s and V(kt-1)'s buffers are refilled
     tile_fence();
     const int kslot1 = kslot == 2 ? 0 : kslot + 1, kslot2 = kslot1 == 2 ? 0 : kslot1 + 1;
-    if (kt + 2 < b.n_tiles) dma.k(p, b, kt + 2, kslot2);
-    dma.v(p, b, kt + 1, (kt + 1) & 1);
+    if constexpr (!(ATTN64_ABL & 4)) {
+      if (kt + 2 < b.n_tiles) dma.k(p, b, kt + 2, kslot2);
+      dma.v(p, b, kt + 1, (kt + 1) & 1);
+    }
     step(sA, sB, kf, kt, 0, kt, 1, kslot1, 0, true);        // this (kt,0), next (kt,1) [kf], then (kt+1,0) from K(kt+1)
     step(sB, sA, kf, kt, 1, kt + 1, 0, kslot1, 1, true);    // this (kt,1), next (kt+1,0) [kf], then (kt+1,1)
     kslot = kslot1;
@@ -357,7 +366,7 @@ __device__ __forceinline__ void attn64_run(const AttnArgs& p, const Blk& b, cons
   for (int j = 0; j < NQ; ++j) {
     const float l = half_sum(l_run[j]);
     const int qr = qs[j] + c;
-    if (qr < b.q_lim) {
+    if (qr < b.q_lim && !(ATTN64_ABL & 1024)) {
       const float inv = l > 0.f ? 1.0f / l : 0.f;
       bf16_t* op = p.o + (size_t)(b.row0 + qr) * p.ldo + (size_t)b.hq * D;
 #pragma unroll
@@ -408,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnArgs p) {
   b.kv_len = b.len + b.kv_off;
   b.n_tiles = (b.kv_len + KT - 1) / KT;
   if (CAUSAL) b.n_tiles = min(b.n_tiles, (min(b.q0 + QB, b.q_lim) - 1 + b.kv_off) / KT + 1);
+  if (ATTN64_ABL & 256) b.n_tiles = 1;
   const size_t kv_seq = p.kv_seq_stride ? (size_t)seq * p.kv_seq_stride : 0;
   b.kbase = p.k + (p.kv_seq_stride ? kv_seq : (size_t)b.row0 * p.ldk) + (size_t)hk * p.kv_head_stride;
   b.vbase = p.v + (p.kv_seq_stride ? kv_seq : (size_t)b.row0 * p.ldv) + (size_t)hk * p.kv_head_stride;

@@ -14,6 +14,9 @@
 
 namespace {
 
+#ifndef SKINNY_DEPTH2
+#define SKINNY_DEPTH2 8      // k-steps in flight of the two-slab one-row-tile forms (SwiGLU w1|w3, RoPE wqkv)
+#endif
 enum { SK_STORE = 0, SK_RESID = 1, SK_SWIGLU = 2, SK_GELU = 3, SK_ARGMAX = 4, SK_RELU = 5, SK_LS_RESID = 6, SK_ROPE_KV = 7 };
 
 // SK_ROPE_KV: the decode step's wqkv GEMV with RoPE and the KV-cache append in its epilogue (head_dim 128).  A workgroup takes the
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
 
   // DEPTH k-steps (DEPTH x 16 B per lane per operand) are loaded before their MFMAs so several loads are in flight; a decode
   // GEMV (one x row tile, few workgroups per CU when N is small) needs the deeper form to cover the HBM latency
-  constexpr int DEPTH = (RT == 1 && NS == 1) ? 16 : 4;
+  constexpr int DEPTH = RT == 1 ? (NS == 1 ? 16 : SKINNY_DEPTH2) : 4;
   int k = 0;
   for (; k + 32 * DEPTH <= kper; k += 32 * DEPTH) {
     bf16x8 wf[DEPTH][NS], xf[DEPTH][RT];
@@ -291,7 +294,9 @@ hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int l
   const int rt = (R + 15) / 16;
   const int ns = (EPI == SK_SWIGLU) ? 2 : (EPI == SK_ARGMAX && rt >= 2) ? 4 : 1;   // = NS of the kernel
   const int blocks = (N + 16 * ns - 1) / (16 * ns);
-  static const bool nt = getenv("AIGV_SKINNY_NT") ? atoi(getenv("AIGV_SKINNY_NT")) != 0 : true;   // A/B knob (scripts/decode_gemv_bench.py)
+  // A/B knob (scripts/decode_gemv_bench.py).  Measured on the 8B decode shapes: non-temporal weight loads are SLOWER here
+  // (wqkv 12.5 -> 14.8 us, w2 24.9 -> 29.9 us, w1|w3 47.9 -> 54.9 us), so the default stays the plain cache policy.
+  static const bool nt = getenv("AIGV_SKINNY_NT") ? atoi(getenv("AIGV_SKINNY_NT")) != 0 : false;
 #define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, EPI>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls)
   if constexpr (EPI == SK_STORE || EPI == SK_RESID) {
     static const int max8 = getenv("AIGV_SKINNY8_MAX_BLOCKS") ? atoi(getenv("AIGV_SKINNY8_MAX_BLOCKS")) : 256;   // A/B knob (scripts/decode_gemv_bench.py)
@@ -328,7 +333,7 @@ hipError_t aigv_launch_skinny_rope_kv(const bf16_t* x, int ldx, int R, const bf1
     return hipErrorInvalidValue;
   RopeKvArgs rk{pos, seq, cos, sin, kc, vc, g, n_kv, cap};
   const int rt = (R + 15) / 16, blocks = N / 32;
-#define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, SK_ROPE_KV, 4, true>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk)
+#define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, SK_ROPE_KV, 4, false>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk)
   switch (rt) {
     case 1: GO(1); break;
     case 2: GO(2); break;

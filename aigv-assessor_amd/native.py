@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libaigv_amd.so")
+LIB_PATH = os.environ.get("AIGV_AMD_LIB") or os.path.join(HERE, "libaigv_amd.so")   # (the override: kernel-ablation builds of scripts/)
 ABI_VERSION = 1
 
 
