@@ -1324,6 +1324,24 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
   return 0;
 }
 
+int aigv_out_row_logits(aigv_ctx* c, int first_row, int n_rows, void* logits_bf16, int ldo, void* stream) {
+  if (!c || !logits_bf16) return fail(c, AIGV_ERR_ARG, "aigv_out_row_logits: null argument");
+  if (!c->finalized) return fail(c, AIGV_ERR_STATE, "aigv_out_row_logits: call aigv_finalize_weights first");
+  const aigv_config& k = c->cfg;
+  const int cap = k.max_out_rows + k.max_seqs + 64;
+  if (first_row < 0 || n_rows <= 0 || first_row + n_rows > cap) return fail(c, AIGV_ERR_ARG, "aigv_out_row_logits: rows %d..%d outside 0..%d", first_row, first_row + n_rows - 1, cap - 1);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  for (int r0 = 0; r0 < n_rows; r0 += 64) {
+    const int rr = std::min(64, n_rows - r0);
+    ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * rr * (double)k.vocab * k.llm_hidden, 2.0 * (double)k.vocab * k.llm_hidden, s);
+    hipError_t e = aigv_launch_lm_head_logits(c->l_rows + (size_t)(first_row + r0) * k.llm_hidden, rr, k.llm_hidden, c->lm_head, k.vocab,
+                                              (bf16_t*)logits_bf16 + (size_t)r0 * ldo, ldo, s);
+    if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "lm-head logits (rows=%d ldo=%d): %s", rr, ldo, hipGetErrorString(e));
+  }
+  return 0;
+}
+
 // ---- single operators ----------------------------------------------------------------------------------------
 int aigv_op_gemm(const void* A, int lda, const void* W_, int ldw, void* C, int ldc, const void* bias, const void* ls,
                  const void* resid, int ldr, const void* pos, int np, int M, int N, int K, int epi, void* stream) {

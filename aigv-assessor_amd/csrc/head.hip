@@ -366,6 +366,15 @@ hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t
   return hipErrorInvalidValue;
 }
 
+// lm-head logits of R rows as the reference holds them before its .float(): the bf16 output of the matmul (modeling_internlm2.py:
+// 1095-1096).  out is [R, ldo] bf16 with ldo >= V rounded up to 4 (the store epilogue writes 4 columns per lane; columns >= V of a
+// row are padding).  Used where the whole distribution is needed - sampling in generate() - the greedy paths use the fused argmax.
+hipError_t aigv_launch_lm_head_logits(const bf16_t* h, int R, int H, const bf16_t* W, int V, bf16_t* out, int ldo, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  if (R > 64 || H % 128 || ldo < ((V + 3) / 4) * 4 || (ldo % 4)) return hipErrorInvalidValue;
+  return launch_skinny<SK_STORE>(h, H, R, W, H, V, H, nullptr, nullptr, 0, out, ldo, nullptr, s);
+}
+
 hipError_t aigv_launch_lm_head_argmax(const bf16_t* h, int R, int H, const bf16_t* W, int V,
                                       unsigned long long* packed, int64_t* out_idx, float* out_val, hipStream_t s) {
   if (R <= 0) return hipSuccess;

@@ -128,6 +128,8 @@ hipError_t aigv_launch_skinny_rope_kv(const bf16_t* x, int ldx, int R, const bf1
 // lm-head on R gathered rows + argmax over the vocabulary (first maximal index, bf16-rounded logits)
 hipError_t aigv_launch_lm_head_argmax(const bf16_t* h, int R, int H, const bf16_t* W, int V,
                                       unsigned long long* packed, int64_t* out_idx, float* out_val, hipStream_t s);
+// lm-head logits (bf16, the matmul output the reference upcasts) of R rows into out[R, ldo], ldo >= roundup(V, 4)
+hipError_t aigv_launch_lm_head_logits(const bf16_t* h, int R, int H, const bf16_t* W, int V, bf16_t* out, int ldo, hipStream_t s);
 // score head: x[B,H] -> chain of Linear+ReLU (bf16 rounding after each Linear), NaN/Inf guard on x
 struct ScoreHeadArgs {
   const bf16_t* x; int ldx; int B;

@@ -22,7 +22,8 @@ Documented deviations from the reference (all outside what its eval scripts exer
     ``slowfast_model.*`` tensors (the reference downloads them from pytorchvideo's hub at construction time,
     which cannot happen offline); otherwise pass ``motion_feature=[B, 2304]`` or set ``slowfast_model`` to a
     callable with the reference's interface.
-  * ``generate`` is greedy (the reference defers to HF ``generate``; its eval configs use do_sample=False).
+  * ``generate`` implements greedy decoding and multinomial sampling (temperature / top-k / top-p, HF's warper order); the
+    reference defers to HF ``generate`` - its eval configs use do_sample=False.  Beam search raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -767,7 +768,7 @@ class InternVLChatModel(nn.Module):
         return outs
 
     # ---- generation (API surface; greedy) -------------------------------------------------------------------
-    def _greedy(self, ids_packed, slot, cu, vis, n_vis, max_new_tokens: int, eos_ids: List[int], pad_id: int, motion=None):
+    def _greedy(self, ids_packed, slot, cu, vis, n_vis, max_new_tokens: int, eos_ids: List[int], pad_id: int, motion=None, sampler=None):
         b = len(cu) - 1
         longest = max(cu[i + 1] - cu[i] for i in range(b))
         last_rows = [cu[i + 1] - 1 for i in range(b)]
@@ -779,6 +780,8 @@ class InternVLChatModel(nn.Module):
         _, nxt = self._prefill(ids_packed, slot, cu, vis, n_vis, motion, None, last_rows, keep_kv=True,
                                kv_cap=longest + max_new_tokens + 1)
         lib, ctx = native.load(), self._ctx
+        if sampler is not None:       # the prefill's fused argmax is the greedy token; sampling draws from the same rows' logits
+            nxt = self._sample(self._row_logits(b), **sampler)
         done = torch.zeros(b, dtype=torch.bool, device=self.device)
         eos = torch.tensor(eos_ids, device=self.device, dtype=torch.long) if eos_ids else None
         outs = []
@@ -793,21 +796,60 @@ class InternVLChatModel(nn.Module):
                 break
             new = torch.empty_like(tok)
             native.check(lib.aigv_decode_step(ctx, tok.contiguous().data_ptr(), new.data_ptr(), native.stream_ptr()), ctx)
-            nxt = new
+            nxt = new if sampler is None else self._sample(self._row_logits(b), **sampler)
         return torch.stack(outs, dim=1)
 
     @staticmethod
     def _gen_args(generation_config, kw):
+        """(max_new_tokens, eos ids, pad id, sampler) from a HF-style generation config / kwargs.  ``sampler`` is None for greedy
+        decoding or the warper settings of HF's multinomial sampling (temperature -> top-k -> top-p, transformers' order and
+        defaults: top_k 50, top_p 1.0, temperature 1.0).  Beam search and the repetition / n-gram processors are not on this path."""
         cfg = dict(generation_config) if isinstance(generation_config, dict) else {}
         if generation_config is not None and not isinstance(generation_config, dict):
-            cfg = {k: getattr(generation_config, k) for k in ("max_new_tokens", "do_sample", "num_beams", "eos_token_id", "pad_token_id")
+            cfg = {k: getattr(generation_config, k) for k in ("max_new_tokens", "do_sample", "num_beams", "eos_token_id", "pad_token_id",
+                                                              "temperature", "top_k", "top_p", "repetition_penalty", "no_repeat_ngram_size")
                    if hasattr(generation_config, k)}
         cfg.update(kw)
-        if cfg.get("do_sample") or (cfg.get("num_beams") or 1) > 1:
-            raise NotImplementedError("only greedy decoding is implemented on the gfx950 path")
+        if (cfg.get("num_beams") or 1) > 1:
+            raise NotImplementedError("beam search is not implemented on the gfx950 path (greedy and multinomial sampling are)")
+        if cfg.get("repetition_penalty") not in (None, 1, 1.0) or cfg.get("no_repeat_ngram_size") not in (None, 0):
+            raise NotImplementedError("repetition_penalty / no_repeat_ngram_size are not implemented on the gfx950 path")
+        sampler = None
+        if cfg.get("do_sample"):
+            sampler = dict(temperature=float(cfg["temperature"]) if cfg.get("temperature") is not None else 1.0,
+                           top_k=int(cfg["top_k"]) if cfg.get("top_k") is not None else 50,
+                           top_p=float(cfg["top_p"]) if cfg.get("top_p") is not None else 1.0, generator=cfg.get("generator"))
+            if sampler["temperature"] <= 0 or not (0 < sampler["top_p"] <= 1.0) or sampler["top_k"] < 0:
+                raise ValueError(f"bad sampling settings {sampler}")
         eos = cfg.get("eos_token_id")
         eos = [] if eos is None else ([int(eos)] if not isinstance(eos, (list, tuple)) else [int(e) for e in eos])
-        return int(cfg.get("max_new_tokens") or 20), eos, cfg.get("pad_token_id")
+        return int(cfg.get("max_new_tokens") or 20), eos, cfg.get("pad_token_id"), sampler
+
+    def _row_logits(self, n_rows: int) -> torch.Tensor:
+        """fp32 [n_rows, vocab]: lm-head logits of the rows the last native pass consumed (aigv_out_row_logits) - the reference's
+        ``logits = output(h).float()`` (modeling_internlm2.py:1095-1096)."""
+        lib, ctx = native.load(), self._ctx
+        V = self.config.llm_config.vocab_size
+        ldo = (V + 3) // 4 * 4
+        buf = torch.empty((n_rows, ldo), dtype=torch.bfloat16, device=self.device)
+        native.check(lib.aigv_out_row_logits(ctx, 0, n_rows, buf.data_ptr(), ldo, native.stream_ptr()), ctx)
+        return buf[:, :V].float()
+
+    @staticmethod
+    def _sample(logits: torch.Tensor, temperature: float, top_k: int, top_p: float, generator=None) -> torch.Tensor:
+        """One multinomial draw per row after HF's logits warpers in HF's order (TemperatureLogitsWarper, TopKLogitsWarper,
+        TopPLogitsWarper with min_tokens_to_keep = 1; transformers/generation/logits_process.py).  Host-side glue of generate():
+        a handful of torch ops on [B, vocab], not part of the scoring hot path."""
+        x = logits / temperature if temperature != 1.0 else logits
+        if top_k > 0:
+            kth = torch.topk(x, min(top_k, x.shape[-1]))[0][..., -1, None]
+            x = x.masked_fill(x < kth, float("-inf"))
+        if top_p < 1.0:
+            srt, idx = torch.sort(x, descending=False)
+            remove = srt.softmax(-1).cumsum(-1) <= (1.0 - top_p)
+            remove[..., -1:] = False
+            x = x.masked_fill(remove.scatter(1, idx, remove), float("-inf"))
+        return torch.multinomial(x.softmax(-1), 1, generator=generator).squeeze(1)
 
     @torch.no_grad()
     def generate(self, pixel_values: Optional[torch.Tensor] = None, input_ids: Optional[torch.Tensor] = None,
@@ -816,7 +858,7 @@ class InternVLChatModel(nn.Module):
         """modeling_internvl_chat.py:769-811: every <IMG_CONTEXT> slot takes a visual token (no motion
         token), then greedy decode with a KV cache.  Returns the NEW tokens [B, <=max_new_tokens]."""
         assert self.img_context_token_id is not None
-        max_new, eos, pad = self._gen_args(generation_config, generate_kwargs)
+        max_new, eos, pad, sampler = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         dev = self.device
         input_ids = input_ids.to(dev)
@@ -832,13 +874,13 @@ class InternVLChatModel(nn.Module):
             if int(sel.sum()) != n_vis:
                 raise ValueError(f"visual token count mismatch: {int(sel.sum())} slots vs {n_vis} tokens")
             slot[sel] = torch.arange(n_vis, device=dev, dtype=torch.int32)
-        return self._greedy(ids_packed, slot, cu, vis, n_vis, max_new, eos, pad)
+        return self._greedy(ids_packed, slot, cu, vis, n_vis, max_new, eos, pad, sampler=sampler)
 
     @torch.no_grad()
     def generate2(self, input_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, visual_features=None,
                   generation_config=None, output_hidden_states=None, return_dict=None, **generate_kwargs) -> torch.Tensor:
         """modeling_internvl_chat.py:812-853: decode from precomputed input embeddings [B, N, C]."""
-        max_new, eos, pad = self._gen_args(generation_config, generate_kwargs)
+        max_new, eos, pad, sampler = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         dev = self.device
         b, n, c = input_embeds.shape
@@ -851,7 +893,7 @@ class InternVLChatModel(nn.Module):
         T = emb.shape[0]
         ids = torch.zeros(T, dtype=torch.long, device=dev)
         slot = torch.arange(T, dtype=torch.int32, device=dev)          # every row comes from `emb`
-        return self._greedy(ids, slot, cu, emb, T, max_new, eos, pad)
+        return self._greedy(ids, slot, cu, emb, T, max_new, eos, pad, sampler=sampler)
 
     @torch.no_grad()
     def generate_stage2(self, pixel_values, input_ids, attention_mask=None, image_flags=None, motion_feature=None,
@@ -862,14 +904,14 @@ class InternVLChatModel(nn.Module):
         token / visual / motion rows - no embedding tensor is assembled on the host side."""
         if self.img_context_token_id is None:
             raise AssertionError("img_context_token_id must be set (stage2_eval.py:810)")
-        max_new, eos, pad = self._gen_args(generation_config, generate_kwargs)
+        max_new, eos, pad, sampler = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         B = input_ids.shape[0]
         plan = self._plan(input_ids, attention_mask, None, image_flags, pixel_values.shape[0], drop_dead_tail=False)
         motion_feature = self._motion_feature(pixel_values, B, motion_feature)
         self._native(n_frames=pixel_values.shape[0], n_tokens=plan["cu"][-1], n_clips=B)
         vit_embeds, motion = self._visual_inputs(pixel_values, None, motion_feature, plan)
-        return self._greedy(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], max_new, eos, pad, motion=motion)
+        return self._greedy(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], max_new, eos, pad, motion=motion, sampler=sampler)
 
     def chat2(self, tokenizer, pixel_values, input_ids, generation_config, attention_mask, history=None,
               return_history=False, image_flags=None, IMG_START_TOKEN="<img>", IMG_END_TOKEN="</img>",

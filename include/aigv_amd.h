@@ -126,7 +126,8 @@ int aigv_kv_fork(aigv_ctx* ctx, int copies, void* stream);
  * dtype flow.  AIGV_PRECISION_FP8_LLM: wqkv, wo, w1|w3, w2 of every decoder layer - except wo / w1|w3 / w2 of the LAST layer, which act on
  * the few consumed rows - run on the e4m3 MFMA: weights quantised once per output channel (scale = amax / 448), activations per token row
  * on the fly (aigv_op_quant_fp8_rows), fp32 accumulation, the bf16 path's epilogues and rounding points after the scaled accumulator.
- * Attention, norms, RoPE, residual stream, lm-head and score head stay bf16, and so do aigv_llm_extend / aigv_decode_step.  The reference
+ * Attention, norms, RoPE, residual stream, lm-head and score head stay bf16, and so does aigv_decode_step; aigv_llm_extend runs the
+ * same e4m3 linears as the prefill (a continuation scores like the same tokens inside one prefill of this mode).  The reference
  * has no fp8 path: results move by the quantisation noise (oracle/fp8.py restates this mode; measured drift in DESIGN.md).  First call
  * quantises the weights (extra memory: one byte per InternLM2 linear weight).  Needs H, qkv width, 2*I multiples of 256.
  * aigv_finalize_weights (i.e. any reload of weights) drops the e4m3 copies and returns the context to bf16: set the mode again after it. */
@@ -145,6 +146,12 @@ int aigv_set_gemm_mode(aigv_ctx* ctx, int mode);
 /* One greedy decode step for every clip of the last keep_kv prefill (generate(): modeling_internvl_chat.py:769-811,
  * modeling_internlm2.py:1126-1163).  ids[B] int64 device (the previous tokens) -> next[B] int64 device. */
 int aigv_decode_step(aigv_ctx* ctx, const int64_t* ids, int64_t* next, void* stream);
+/* The full next-token distribution of the rows the last aigv_llm_prefill / aigv_llm_extend / aigv_decode_step consumed: lm-head
+ * logits of their final hidden states (kept in the context, in the order [score rows | logit rows]; a decode step keeps its
+ * n_clips rows) as the bf16 values the reference upcasts with .float() (modeling_internlm2.py:1095-1096).
+ * logits: DEVICE bf16 [n_rows, ldo], ldo >= vocab rounded up to a multiple of 4 (columns >= vocab are padding).  For
+ * generate() with do_sample (HF sampling needs the distribution; the greedy paths use the fused argmax and never call this). */
+int aigv_out_row_logits(aigv_ctx* ctx, int first_row, int n_rows, void* logits_bf16, int ldo, void* stream);
 
 /* ---- single operators (parity tests call these through the same ABI) --------------------------------- */
 /* C = epilogue(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch */
