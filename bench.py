@@ -379,11 +379,12 @@ def main():
             if gm["launches"]:
                 ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
                 traffic, tnote = None, None
-                tf = os.path.join(ROOT, "profiles", "r1_gemm_traffic.json")
-                if os.path.exists(tf):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (scripts/pmc_summary.py)
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (scripts/pmc_summary.py); newest round's file first
+                tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (2, 1)) if os.path.exists(f)), None)
+                if tf:
                     tj = json.load(open(tf))
                     traffic = tj["all_gemm"]["traffic_bytes_per_launch"]
-                    tnote = "L2<->fabric bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r1_gemm_traffic.json)"
+                    tnote = f"L2<->fabric bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/{os.path.basename(tf)})"
                 line["roofline"] = {
                     "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                     "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": gm["bytes"] / gm["launches"],
