@@ -1301,20 +1301,30 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
   for (int b = 0; b < B; ++b) max_vis = std::max(max_vis, c->h_kvlen[b] + 1);
   HIPCHK(c, aigv_launch_embed(ids, c->dec_slot, c->tok_emb, nullptr, nullptr, 0, c->l_h, B, H, s));
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
+  // Up to 4 sequences: attention_norm / ffn_norm are applied by the GEMV that consumes them (NormArgs in head.hip; same bits), 6
+  // launches per layer instead of 8.  AIGV_DECODE_FUSED=0 keeps the separate norm kernels (A/B).
+  static const bool fused_env = getenv("AIGV_DECODE_FUSED") ? atoi(getenv("AIGV_DECODE_FUSED")) != 0 : true;
+  const bool fused = fused_env && B <= 4 && aigv_skinny_norm_fusable(H);
   for (int li = 0; li < k.llm_layers; ++li) {
     const LlmLayer& L = c->llm[li];
-    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, B, H, k.rms_eps, nullptr, s));
+    if (!fused) HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, B, H, k.rms_eps, nullptr, s));
     {   // wqkv with RoPE + KV-cache append in its epilogue: one launch instead of GEMV + rope / store
       ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * B * (double)c->qkv_out * H, 2.0 * (double)c->qkv_out * H, s);
-      HIPCHK(c, aigv_launch_skinny_rope_kv(c->l_t, H, B, L.wqkv, H, c->qkv_out, H, c->l_qkv, c->qkv_out, c->dec_pos, c->dec_seq, c->rope_cos,
-                                           c->rope_sin, c->kc + li * kv_layer, c->vc + li * kv_layer, g, nkv, k.kv_capacity, D, s));
+      HIPCHK(c, aigv_launch_skinny_rope_kv(fused ? c->l_h : c->l_t, H, B, L.wqkv, H, c->qkv_out, H, c->l_qkv, c->qkv_out, c->dec_pos, c->dec_seq, c->rope_cos,
+                                           c->rope_sin, c->kc + li * kv_layer, c->vc + li * kv_layer, g, nkv, k.kv_capacity, D, s,
+                                           fused ? L.an : nullptr, k.rms_eps));
     }
     HIPCHK(c, aigv_launch_attention_decode(c->l_qkv, c->qkv_out, (g + 2) * D, c->kc + li * kv_layer, c->vc + li * kv_layer,
                                            c->dec_kvlen, k.kv_capacity, c->l_ao, H, B, nkv, g, D, sqrtf((float)D), max_vis,
                                            c->dec_ws, s));
     TRY(run_skinny(c, c->l_ao, H, B, L.wo, H, H, H, nullptr, c->l_h, H, c->l_h, H, 1, s));
-    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, B, H, k.rms_eps, nullptr, s));
-    TRY(run_skinny(c, c->l_t, H, B, L.w13, H, 2 * I, H, nullptr, nullptr, 0, c->l_ffn, I, 2, s));
+    if (fused) {
+      ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * B * 2.0 * I * H, 2.0 * 2.0 * I * H, s);
+      HIPCHK(c, aigv_launch_skinny_swiglu_normed(c->l_h, H, B, L.w13, H, 2 * I, H, c->l_ffn, I, L.fn, k.rms_eps, s));
+    } else {
+      HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, B, H, k.rms_eps, nullptr, s));
+      TRY(run_skinny(c, c->l_t, H, B, L.w13, H, 2 * I, H, nullptr, nullptr, 0, c->l_ffn, I, 2, s));
+    }
     TRY(run_skinny(c, c->l_ffn, I, B, L.w2, I, H, I, nullptr, c->l_h, H, c->l_h, H, 1, s));
   }
   HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, c->final_norm, c->l_rows, H, B, H, k.rms_eps, nullptr, s));

@@ -30,6 +30,12 @@ struct RopeKvArgs {
   int g, n_kv, cap;
 };
 
+// NORM: the GEMV applies the RMSNorm in front of it (attention_norm before wqkv, ffn_norm before w1|w3; modeling_internlm2.py:138-143)
+// to its x rows itself: x is the raw residual stream, every workgroup normalises the R <= 4 rows into LDS with rmsnorm_kernel's exact
+// arithmetic (same thread -> chunk mapping, same reduction tree) and takes its B fragments from there.  Redundant work per
+// workgroup (R x K elements), but no launch: the statistics' L2 round trip and barriers run behind the first weight loads.
+struct NormArgs { const bf16_t* w; float eps; };
+
 __device__ __forceinline__ unsigned int ord_f32(float f) {
   const unsigned int u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -46,13 +52,17 @@ __device__ __forceinline__ bf16x8 wload(const bf16_t* p) {
   else return *(const bf16x8*)p;
 }
 
-template <int RT, int EPI, int NWV = 4, bool NT = false>
+template <int RT, int EPI, int NWV = 4, bool NT = false, int NC = 0>   // NC: fused-norm form, K = NC x 2048 (0 = off)
 __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restrict__ x, int ldx, int R,
                                                      const bf16_t* __restrict__ W, int ldw, int N, int K,
                                                      const bf16_t* __restrict__ bias, const bf16_t* __restrict__ resid,
                                                      int ldr, bf16_t* __restrict__ out, int ldo,
                                                      unsigned long long* __restrict__ packed,
-                                                     const bf16_t* __restrict__ ls, const RopeKvArgs rk = RopeKvArgs{}) {
+                                                     const bf16_t* __restrict__ ls, const RopeKvArgs rk = RopeKvArgs{},
+                                                     const NormArgs na = NormArgs{}) {
+  constexpr bool NORM = NC > 0;
+  static_assert(!NORM || (RT == 1 && NWV == 4), "the fused norm is the decode form: one row tile, 256 threads (rmsnorm_kernel's reduction)");
+  extern __shared__ __attribute__((aligned(16))) bf16_t xs[];   // NORM: the normalised x rows [R][K]
   // W slabs (16 rows each) per workgroup.  The lm-head on the answer rows (40+ x rows) is bound by re-reading the x fragments
   // from L2 once per workgroup, not by streaming W: four slabs per workgroup share them.
   constexpr int NS = (EPI == SK_SWIGLU || EPI == SK_ROPE_KV) ? 2 : (EPI == SK_ARGMAX && RT >= 2) ? 4 : 1;
@@ -81,6 +91,53 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
   // GEMV (one x row tile, few workgroups per CU when N is small) needs the deeper form to cover the HBM latency
   constexpr int DEPTH = RT == 1 ? (NS == 1 ? 16 : SKINNY_DEPTH2) : 4;
   int k = 0;
+  const int xs_off = min(fr, R - 1) * K + kbeg + fq * 8;          // NORM: this lane's fragment origin in xs
+  if constexpr (NORM) {
+    // Load order matters (vmcnt retires in issue order): the x rows and the norm weight - a few L2 hits - go out FIRST, then the
+    // first DEPTH weight k-steps; the statistics then wait only for the former, with the weight stream in flight behind them.
+    // Rows past R repeat row R - 1 (never normalised); thread -> chunk mapping and sums as rmsnorm_kernel.
+    u16x8 xr[4][NC], gw[NC];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) xr[r][c] = *(const u16x8*)(x + (size_t)min(r, R - 1) * ldx + ((threadIdx.x + c * 256) << 3));
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gw[c] = *(const u16x8*)(na.w + ((threadIdx.x + c * 256) << 3));
+    bf16x8 wf[DEPTH][NS];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) wf[u][s] = wload<NT>(wrow[s] + 32 * u);
+    {
+      __shared__ float red[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r == 0 || r < R) {     // (row 0 unconditionally: hipcc otherwise sinks the norm-weight loads into the branch, behind the weight stream)
+          float sq = 0.f;
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float v = bf2f(xr[r][c][e]); sq += v * v; }
+          const float rstd = rsqrtf(block_sum_256(sq, red) / (float)K + na.eps);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            u16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(gw[c][e]) * rbf(bf2f(xr[r][c][e]) * rstd));
+            *(u16x8*)(xs + (size_t)r * K + ((threadIdx.x + c * 256) << 3)) = o;
+          }
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      const bf16x8 xf = *(const bf16x8*)(xs + xs_off + 32 * u);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][s], xf, acc[s][0], 0, 0, 0);
+    }
+    k = 32 * DEPTH;
+  }
   for (; k + 32 * DEPTH <= kper; k += 32 * DEPTH) {
     bf16x8 wf[DEPTH][NS], xf[DEPTH][RT];
 #pragma unroll
@@ -88,7 +145,10 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
 #pragma unroll
       for (int s = 0; s < NS; ++s) wf[u][s] = wload<NT>(wrow[s] + k + 32 * u);
 #pragma unroll
-      for (int t = 0; t < RT; ++t) xf[u][t] = *(const bf16x8*)(xrow[t] + k + 32 * u);
+      for (int t = 0; t < RT; ++t) {
+        if constexpr (NORM) xf[u][t] = *(const bf16x8*)(xs + xs_off + k + 32 * u);
+        else xf[u][t] = *(const bf16x8*)(xrow[t] + k + 32 * u);
+      }
     }
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u)
@@ -103,8 +163,12 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
     for (int s = 0; s < NS; ++s) {
       const bf16x8 wf = wload<NT>(wrow[s] + k);
 #pragma unroll
-      for (int t = 0; t < RT; ++t)
-        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, *(const bf16x8*)(xrow[t] + k), acc[s][t], 0, 0, 0);
+      for (int t = 0; t < RT; ++t) {
+        bf16x8 xf;
+        if constexpr (NORM) xf = *(const bf16x8*)(xs + xs_off + k);
+        else xf = *(const bf16x8*)(xrow[t] + k);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[s][t], 0, 0, 0);
+      }
     }
   }
 
@@ -323,16 +387,27 @@ hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int l
 
 }  // namespace
 
+// widths the fused-norm GEMVs are built for (K = 2 x 2048: InternLM2-7B, 3 x 2048: InternLM2-20B)
+bool aigv_skinny_norm_fusable(int K) { return K == 4096 || K == 6144; }
+
 // the decode step's wqkv projection with RoPE + KV-cache append in the epilogue (SK_ROPE_KV above); x rows = one new token per sequence
 hipError_t aigv_launch_skinny_rope_kv(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, bf16_t* qkv, int ldo,
                                       const int32_t* pos, const int32_t* seq, const bf16_t* cos, const bf16_t* sin, bf16_t* kc, bf16_t* vc,
-                                      int g, int n_kv, int cap, int head_dim, hipStream_t s) {
+                                      int g, int n_kv, int cap, int head_dim, hipStream_t s, const bf16_t* norm_w, float norm_eps) {
   if (R <= 0) return hipSuccess;
   if (R > 64 || K % 128 || (ldx % 8) || (ldw % 8) || (ldo % 4) || head_dim != 128 || N != n_kv * (g + 2) * 128 || !pos || !seq || !cos ||
       !sin || !kc || !vc)
     return hipErrorInvalidValue;
   RopeKvArgs rk{pos, seq, cos, sin, kc, vc, g, n_kv, cap};
   const int rt = (R + 15) / 16, blocks = N / 32;
+  if (norm_w) {   // x = the raw residual rows; attention_norm applied by the kernel (NormArgs above)
+    if (R > 4 || !aigv_skinny_norm_fusable(K)) return hipErrorInvalidValue;
+#define GO(NC) hipLaunchKernelGGL((skinny_kernel<1, SK_ROPE_KV, 4, false, NC>), dim3(blocks), dim3(256), (size_t)R * K * sizeof(bf16_t), s, x, ldx, R, W, ldw, N, K, \
+                                  nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk, NormArgs{norm_w, norm_eps})
+    if (K == 4096) GO(2); else GO(3);
+#undef GO
+    return hipGetLastError();
+  }
 #define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, SK_ROPE_KV, 4, false>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk)
   switch (rt) {
     case 1: GO(1); break;
@@ -341,6 +416,18 @@ hipError_t aigv_launch_skinny_rope_kv(const bf16_t* x, int ldx, int R, const bf1
     case 4: GO(4); break;
     default: return hipErrorInvalidValue;
   }
+#undef GO
+  return hipGetLastError();
+}
+
+// decode: SwiGLU(x_n W13^T) with x_n = RMSNorm(x) * norm_w computed by the kernel itself (R <= 4 rows; NormArgs above)
+hipError_t aigv_launch_skinny_swiglu_normed(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, bf16_t* out, int ldo,
+                                            const bf16_t* norm_w, float norm_eps, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  if (R > 4 || !aigv_skinny_norm_fusable(K) || (ldx % 8) || (ldw % 8) || (ldo % 4) || (N % 32) || !norm_w) return hipErrorInvalidValue;
+#define GO(NC) hipLaunchKernelGGL((skinny_kernel<1, SK_SWIGLU, 4, false, NC>), dim3(N / 32), dim3(256), (size_t)R * K * sizeof(bf16_t), s, x, ldx, R, W, ldw, N, K, \
+                                  nullptr, nullptr, 0, out, ldo, nullptr, nullptr, RopeKvArgs{}, NormArgs{norm_w, norm_eps})
+  if (K == 4096) GO(2); else GO(3);
 #undef GO
   return hipGetLastError();
 }
