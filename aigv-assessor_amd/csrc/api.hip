@@ -467,10 +467,12 @@ int run_gemm_fp8(aigv_ctx* c, const bf16_t* A, int lda, int K, const uint8_t* W8
   return 0;
 }
 
+int g_skinny_p = 0;   // aigv_tune_skinny: sub-slab form forced on the op-level entry point / the decode step (0 = default)
+
 int run_skinny(aigv_ctx* c, const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
-               const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi, hipStream_t s) {
+               const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi, hipStream_t s, int p = 1) {
   ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * R * (double)N * K, 2.0 * (double)N * K, s);
-  hipError_t e = aigv_launch_skinny_gemm(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, epi, s);
+  hipError_t e = aigv_launch_skinny_gemm(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, epi, s, nullptr, p);
   if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP,
                                    "skinny gemm (R=%d N=%d K=%d epi=%d): %s", R, N, K, epi, hipGetErrorString(e));
   return 0;
@@ -1284,6 +1286,37 @@ int aigv_set_gemm_mode(aigv_ctx* c, int mode) {
   return 0;
 }
 
+// Which form (P = 1, 2, 4: 16, 8, 4 rows of W per workgroup and slab) each decode GEMV runs in.  A GEMV's rate depends on how
+// evenly its workgroups fill the 256 CUs and on how many there are (scripts/gemv_balance_probe.py; in-box sweep of the 8B decode
+// step, profiles/r2_decode_forms.txt: wqkv 1 -> 4: -0.16 ms/token, w1|w3 1 -> 2: -0.16, 1 -> 4: -0.24, w2 1 -> 2: -0.08, 1 -> 4: -0.04,
+// wo: no change): the finest form the batch allows whose K sub-range per wave still fills one 8-deep load group; long-K GEMVs
+// (w2) stop at 8 rows.
+static int pick_form(int max_p, int K) {
+  int best = 1;
+  for (int p = 2; p <= max_p; p *= 2) {
+    if (K % (128 * p) || K / (4 * p) < 256 || (K > 8192 && p > 2)) break;
+    best = p;
+  }
+  return best;
+}
+
+static void decode_forms(aigv_ctx* c, int B, int* pq, int* po, int* p13, int* p2) {
+  const aigv_config& k = c->cfg;
+  const int max_p = B <= 4 ? 4 : B <= 8 ? 2 : 1;
+  *pq = *po = *p13 = pick_form(max_p, k.llm_hidden);
+  *p2 = pick_form(max_p, k.llm_inter);
+  if (g_skinny_p) *pq = *po = *p13 = *p2 = std::min(g_skinny_p, max_p);
+  static const char* env = getenv("AIGV_DECODE_P");
+  if (env) {
+    int v[4];
+    if (sscanf(env, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) {
+      int* out[4] = {pq, po, p13, p2};
+      for (int i = 0; i < 4; ++i)
+        if ((v[i] == 1 || v[i] == 2 || v[i] == 4) && v[i] <= max_p) *out[i] = v[i];
+    }
+  }
+}
+
 int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* stream) {
   if (!c || !ids || !next) return fail(c, AIGV_ERR_ARG, "aigv_decode_step: null argument");
   if (!c->kv_valid) return fail(c, AIGV_ERR_STATE, "aigv_decode_step: no KV state (run aigv_llm_prefill with keep_kv)");
@@ -1305,6 +1338,10 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
   // launches per layer instead of 8.  AIGV_DECODE_FUSED=0 keeps the separate norm kernels (A/B).
   static const bool fused_env = getenv("AIGV_DECODE_FUSED") ? atoi(getenv("AIGV_DECODE_FUSED")) != 0 : true;
   const bool fused = fused_env && B <= 4 && aigv_skinny_norm_fusable(H);
+  // sub-slab forms of the four GEMVs (skinny_kernel's P; head.hip): chosen so that the workgroups come to a whole number per CU.
+  // AIGV_DECODE_P="wqkv,wo,w13,w2" overrides (A/B); aigv_tune_skinny forces one value everywhere it is legal.
+  int pq, po, p13, p2;
+  decode_forms(c, B, &pq, &po, &p13, &p2);
   for (int li = 0; li < k.llm_layers; ++li) {
     const LlmLayer& L = c->llm[li];
     if (!fused) HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, B, H, k.rms_eps, nullptr, s));
@@ -1312,20 +1349,20 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
       ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * B * (double)c->qkv_out * H, 2.0 * (double)c->qkv_out * H, s);
       HIPCHK(c, aigv_launch_skinny_rope_kv(fused ? c->l_h : c->l_t, H, B, L.wqkv, H, c->qkv_out, H, c->l_qkv, c->qkv_out, c->dec_pos, c->dec_seq, c->rope_cos,
                                            c->rope_sin, c->kc + li * kv_layer, c->vc + li * kv_layer, g, nkv, k.kv_capacity, D, s,
-                                           fused ? L.an : nullptr, k.rms_eps));
+                                           fused ? L.an : nullptr, k.rms_eps, pq));
     }
     HIPCHK(c, aigv_launch_attention_decode(c->l_qkv, c->qkv_out, (g + 2) * D, c->kc + li * kv_layer, c->vc + li * kv_layer,
                                            c->dec_kvlen, k.kv_capacity, c->l_ao, H, B, nkv, g, D, sqrtf((float)D), max_vis,
                                            c->dec_ws, s));
-    TRY(run_skinny(c, c->l_ao, H, B, L.wo, H, H, H, nullptr, c->l_h, H, c->l_h, H, 1, s));
+    TRY(run_skinny(c, c->l_ao, H, B, L.wo, H, H, H, nullptr, c->l_h, H, c->l_h, H, 1, s, po));
     if (fused) {
       ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * B * 2.0 * I * H, 2.0 * 2.0 * I * H, s);
-      HIPCHK(c, aigv_launch_skinny_swiglu_normed(c->l_h, H, B, L.w13, H, 2 * I, H, c->l_ffn, I, L.fn, k.rms_eps, s));
+      HIPCHK(c, aigv_launch_skinny_swiglu_normed(c->l_h, H, B, L.w13, H, 2 * I, H, c->l_ffn, I, L.fn, k.rms_eps, s, p13));
     } else {
       HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, B, H, k.rms_eps, nullptr, s));
-      TRY(run_skinny(c, c->l_t, H, B, L.w13, H, 2 * I, H, nullptr, nullptr, 0, c->l_ffn, I, 2, s));
+      TRY(run_skinny(c, c->l_t, H, B, L.w13, H, 2 * I, H, nullptr, nullptr, 0, c->l_ffn, I, 2, s, p13));
     }
-    TRY(run_skinny(c, c->l_ffn, I, B, L.w2, I, H, I, nullptr, c->l_h, H, c->l_h, H, 1, s));
+    TRY(run_skinny(c, c->l_ffn, I, B, L.w2, I, H, I, nullptr, c->l_h, H, c->l_h, H, 1, s, p2));
   }
   HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, c->final_norm, c->l_rows, H, B, H, k.rms_eps, nullptr, s));
   HIPCHK(c, aigv_launch_lm_head_argmax(c->l_rows, B, H, c->lm_head, k.vocab, c->l_packed, next, nullptr, s));
@@ -1409,7 +1446,7 @@ int aigv_op_gemm_fp8(const void* A_e4m3, int lda, const void* W_e4m3, int ldw, v
 int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W_, int ldw, int N, int K, const void* bias,
                         const void* resid, int ldr, void* out, int ldo, int epi, void* stream) {
   return run_skinny(nullptr, (const bf16_t*)x, ldx, R, (const bf16_t*)W_, ldw, N, K, (const bf16_t*)bias,
-                    (const bf16_t*)resid, ldr, (bf16_t*)out, ldo, epi, (hipStream_t)stream);
+                    (const bf16_t*)resid, ldr, (bf16_t*)out, ldo, epi, (hipStream_t)stream, g_skinny_p ? g_skinny_p : 1);
 }
 
 int aigv_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H, float eps,
@@ -1509,6 +1546,12 @@ int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us) {
   plan[0] = pl.top_tiles; plan[1] = pl.mid_tiles; plan[2] = pl.mid_slices; plan[3] = pl.last_rows; plan[4] = pl.last_kind;
   plan[5] = pl.last_slices;
   if (est_us) *est_us = pl.est_us + (right ? t128(M, right, K / 64) + LAUNCH_GAP : 0.0);
+  return 0;
+}
+
+int aigv_tune_skinny(int p) {
+  if (p != 0 && p != 1 && p != 2 && p != 4) return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_skinny: 0 (default), 1, 2 or 4, got %d", p);
+  g_skinny_p = p;
   return 0;
 }
 

@@ -453,55 +453,67 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* 
 
 constexpr int MERGE_MAX_CHUNKS = 128;   // capacity / DC the merge kernel holds in LDS (a 16 384-token cache)
 
+// pass 2: grid (kv heads x pairs of query heads, sequences); a workgroup merges the chunk partials of two query heads (256 outputs,
+// one per thread): chunk maxima -> global maximum, chunk weights exp(m - M), denominator (chunks in order), then the weighted sum
+// of the chunk accumulators with sixteen loads in flight (the chunk loop is a chain of L2 latencies, not of FMAs).
 template <int G>
 __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __restrict__ ws, int max_chunks,
                                                                 const int32_t* __restrict__ kv_lens, bf16_t* __restrict__ o,
                                                                 int ldo) {
   constexpr int D = 128;
-  __shared__ float sM[G][MERGE_MAX_CHUNKS], sW[G][MERGE_MAX_CHUNKS];   // chunk maxima, then chunk weights exp(m - M)
-  __shared__ float sL[G];
-  const int hk = blockIdx.x, seq = blockIdx.y, n_kv = gridDim.x;
+  constexpr int HP = G >= 2 ? 2 : 1;                  // query heads per workgroup
+  constexpr int PAIRS = (G + HP - 1) / HP;
+  __shared__ float sM[HP][MERGE_MAX_CHUNKS], sW[HP][MERGE_MAX_CHUNKS];   // chunk maxima, then chunk weights exp(m - M)
+  __shared__ float sL[HP];
+  const int hk = blockIdx.x / PAIRS, j0 = (blockIdx.x % PAIRS) * HP, seq = blockIdx.y, n_kv = gridDim.x / PAIRS;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nch = (kv_lens[seq] + DC - 1) / DC;
   const float* base = ws + (((size_t)seq * n_kv + hk) * max_chunks) * G * (D + 2);
-  // all chunk statistics with independent loads (the chunk loop used to be a chain of global-load latencies)
-  for (int i = t; i < nch * G; i += 256) {
-    const int ch = i / G, j2 = i - ch * G;
-    const float* pp = base + ((size_t)ch * G + j2) * (D + 2);
-    sM[j2][ch] = pp[0];
-    sW[j2][ch] = pp[1];
+  for (int i = t; i < nch * HP; i += 256) {
+    const int ch = i / HP, jj = i - ch * HP;
+    if (j0 + jj < G) {
+      const float* pp = base + ((size_t)ch * G + j0 + jj) * (D + 2);
+      sM[jj][ch] = pp[0];
+      sW[jj][ch] = pp[1];
+    }
   }
   __syncthreads();
-  for (int j2 = wave; j2 < G; j2 += 4) {   // one wave per head: global maximum, chunk weights, denominator - chunks in order
+  if (wave < HP && j0 + wave < G) {   // one wave per head
+    const int jj = wave;
     float m = -INFINITY;
-    for (int ch = lane; ch < nch; ch += 64) m = fmaxf(m, sM[j2][ch]);
+    for (int ch = lane; ch < nch; ch += 64) m = fmaxf(m, sM[jj][ch]);
     m = wave_max(m);
     float l = 0.f;
     for (int c0 = 0; c0 < nch; c0 += 64) {
       const int ch = c0 + lane;
-      const float w = ch < nch ? __expf(sM[j2][ch] - m) : 0.f;
-      const float lw = ch < nch ? sW[j2][ch] * w : 0.f;
-      if (ch < nch) sW[j2][ch] = w;
+      const float w = ch < nch ? __expf(sM[jj][ch] - m) : 0.f;
+      const float lw = ch < nch ? sW[jj][ch] * w : 0.f;
+      if (ch < nch) sW[jj][ch] = w;
       l += wave_sum(lw);
     }
-    if (lane == 0) sL[j2] = l;
+    if (lane == 0) sL[jj] = l;
   }
   __syncthreads();
-  for (int i = t; i < G * D; i += 256) {
-    const int j2 = i / D, d = i % D;
-    float A = 0.f;
-    int ch = 0;
-    for (; ch + 8 <= nch; ch += 8) {
-      float v[8];
+  const int jj = t / D, d = t % D, j2 = j0 + jj;
+  if (jj >= HP || j2 >= G) return;
+  float A = 0.f;
+  int ch = 0;
+  for (; ch + 16 <= nch; ch += 16) {
+    float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = base[((size_t)(ch + u) * G + j2) * (D + 2) + 2 + d];
+    for (int u = 0; u < 16; ++u) v[u] = base[((size_t)(ch + u) * G + j2) * (D + 2) + 2 + d];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) A += v[u] * sW[j2][ch + u];
-    }
-    for (; ch < nch; ++ch) A += base[((size_t)ch * G + j2) * (D + 2) + 2 + d] * sW[j2][ch];
-    const float L = sL[j2];
-    o[(size_t)seq * ldo + (size_t)(hk * G + j2) * D + d] = f2bf(L > 0.f ? A / L : 0.f);
+    for (int u = 0; u < 16; ++u) A += v[u] * sW[jj][ch + u];
   }
+  {   // the last partial group with clamped (re-read, weight 0) loads instead of a one-at-a-time tail
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = ch < nch ? base[((size_t)min(ch + u, nch - 1) * G + j2) * (D + 2) + 2 + d] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) A += ch + u < nch ? v[u] * sW[jj][ch + u] : 0.f;
+  }
+  const float L = sL[jj];
+  o[(size_t)seq * ldo + (size_t)(hk * G + j2) * D + d] = f2bf(L > 0.f ? A / L : 0.f);
 }
 
 }  // namespace
@@ -584,7 +596,7 @@ hipError_t aigv_launch_attention_decode(const bf16_t* q, int ldq, int q_group_st
                                         float* ws, hipStream_t s) {
   if (head_dim != 128 || !ws || max_kv_len <= 0 || max_kv_len > cap || (cap + DC - 1) / DC > MERGE_MAX_CHUNKS) return hipErrorInvalidValue;
   const int max_chunks = (cap + DC - 1) / DC;
-  dim3 grid1((max_kv_len + DC - 1) / DC, n_kv, n_seq), grid2(n_kv, n_seq);
+  dim3 grid1((max_kv_len + DC - 1) / DC, n_kv, n_seq), grid2(n_kv * (g >= 2 ? (g + 1) / 2 : 1), n_seq);
 #define DEC(G)                                                                                                              \
   hipLaunchKernelGGL((attn_decode_partial_kernel<G>), grid1, dim3(256), 0, s, q, ldq, q_group_stride, kc, vc, kv_lens, cap, \
                      post_div, ws, max_chunks);                                                                              \

@@ -8,6 +8,7 @@
 // their W fragments straight from global memory into MFMA A-operands (no LDS round trip: every weight byte
 // is used once), keep the x fragments (L2-resident) as B-operands, and combine partial sums through LDS.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -52,7 +53,14 @@ __device__ __forceinline__ bf16x8 wload(const bf16_t* p) {
   else return *(const bf16x8*)p;
 }
 
-template <int RT, int EPI, int NWV = 4, bool NT = false, int NC = 0>   // NC: fused-norm form, K = NC x 2048 (0 = off)
+// P: sub-slab form of a decode GEMV (one x row tile, R <= 16 / P rows).  A workgroup takes RS = 16 / P rows of W per slab instead
+// of 16, and the MFMA's other rows / columns carry P - 1 further K sub-ranges of the SAME rows: A row m = W row (m mod RS) over
+// sub-range (m / RS), B column n = x row (n mod RS) over sub-range (n / RS), so D[m][n] is a partial product wherever m / RS ==
+// n / RS and the result is the sum of those P diagonal blocks (a shuffle per block).  Every lane still loads distinct weight
+// bytes; what changes is the GRID: N / RS workgroups of 1 / P the bytes - a width whose 16-row slabs come to a non-integer
+// number of workgroups per CU (w1|w3 of InternLM2-7B: 3.5; fused wqkv: 0.75) runs at the rate of the next integer
+// (scripts/gemv_balance_probe.py: 3.5 per CU 4.97 TB/s, 3 per CU 5.34, 4 per CU 5.45).
+template <int RT, int EPI, int NWV = 4, bool NT = false, int NC = 0, int P = 1>   // NC: fused-norm form, K = NC x 2048 (0 = off)
 __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restrict__ x, int ldx, int R,
                                                      const bf16_t* __restrict__ W, int ldw, int N, int K,
                                                      const bf16_t* __restrict__ bias, const bf16_t* __restrict__ resid,
@@ -66,20 +74,26 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
   // W slabs (16 rows each) per workgroup.  The lm-head on the answer rows (40+ x rows) is bound by re-reading the x fragments
   // from L2 once per workgroup, not by streaming W: four slabs per workgroup share them.
   constexpr int NS = (EPI == SK_SWIGLU || EPI == SK_ROPE_KV) ? 2 : (EPI == SK_ARGMAX && RT >= 2) ? 4 : 1;
+  static_assert(P == 1 || ((P == 2 || P == 4) && RT == 1 && EPI != SK_ARGMAX), "sub-slab forms: one row tile, 8 or 4 rows per slab");
+  constexpr int RS = 16 / P;                         // W rows per slab (= x rows the form can take)
   __shared__ float part[NWV - 1][NS][RT][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  // SK_ROPE_KV: block = (head slot, 16-dim group); its two slabs are 64 rows apart
-  const int n0 = EPI == SK_ROPE_KV ? (int)(blockIdx.x >> 2) * 128 + (int)(blockIdx.x & 3) * 16 : blockIdx.x * 16 * NS;
+  const int sr = fr % RS, sp = fr / RS;              // this lane's slab row / x row, and its K sub-range (P == 1: fr, 0)
+  // first W row of the workgroup's slab(s).  SK_ROPE_KV: block = (head slot, RS-dim group), its two slabs are 64 rows apart;
+  // SK_SWIGLU: w1 / w3 alternate in 16-row blocks, block = (32-row pair, RS-row group), the slabs 16 rows apart
+  const int n0 = EPI == SK_ROPE_KV ? (int)(blockIdx.x / (64 / RS)) * 128 + (int)(blockIdx.x % (64 / RS)) * RS
+                 : EPI == SK_SWIGLU ? (int)(blockIdx.x / P) * 32 + (int)(blockIdx.x % P) * RS
+                                    : blockIdx.x * RS * NS;
   constexpr int SLAB_STEP = EPI == SK_ROPE_KV ? 64 : 16;
-  const int kper = K / NWV, kbeg = wave * kper;      // K % (32 * NWV) == 0 checked by the launcher
+  const int kper = K / (NWV * P), kbeg = (wave * P + sp) * kper;      // K % (32 * NWV * P) == 0 checked by the launcher
 
   const bf16_t* wrow[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) wrow[s] = W + (size_t)min(n0 + s * SLAB_STEP + fr, N - 1) * ldw + kbeg + fq * 8;
+  for (int s = 0; s < NS; ++s) wrow[s] = W + (size_t)min(n0 + s * SLAB_STEP + sr, N - 1) * ldw + kbeg + fq * 8;
   const bf16_t* xrow[RT];
 #pragma unroll
-  for (int t = 0; t < RT; ++t) xrow[t] = x + (size_t)min(t * 16 + fr, R - 1) * ldx + kbeg + fq * 8;
+  for (int t = 0; t < RT; ++t) xrow[t] = x + (size_t)min(t * 16 + sr, R - 1) * ldx + kbeg + fq * 8;
 
   f32x4 acc[NS][RT];
 #pragma unroll
@@ -91,7 +105,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
   // GEMV (one x row tile, few workgroups per CU when N is small) needs the deeper form to cover the HBM latency
   constexpr int DEPTH = RT == 1 ? (NS == 1 ? 16 : SKINNY_DEPTH2) : 4;
   int k = 0;
-  const int xs_off = min(fr, R - 1) * K + kbeg + fq * 8;          // NORM: this lane's fragment origin in xs
+  const int xs_off = min(sr, R - 1) * K + kbeg + fq * 8;          // NORM: this lane's fragment origin in xs
   if constexpr (NORM) {
     // Load order matters (vmcnt retires in issue order): the x rows and the norm weight - a few L2 hits - go out FIRST, then the
     // first DEPTH weight k-steps; the statistics then wait only for the former, with the weight stream in flight behind them.
@@ -138,39 +152,35 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
     }
     k = 32 * DEPTH;
   }
-  for (; k + 32 * DEPTH <= kper; k += 32 * DEPTH) {
-    bf16x8 wf[DEPTH][NS], xf[DEPTH][RT];
+  // the rest of the K slice in groups of DEPTH, then 8 / 4 / 1 k-steps: a slice that is not a multiple of DEPTH (K = 14336 over 8
+  // waves: 56 k-steps) used to finish one load at a time
+  auto run = [&](auto dtag) {
+    constexpr int DD = decltype(dtag)::value;
+    for (; k + 32 * DD <= kper; k += 32 * DD) {
+      bf16x8 wf[DD][NS], xf[DD][RT];
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u) {
+      for (int u = 0; u < DD; ++u) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) wf[u][s] = wload<NT>(wrow[s] + k + 32 * u);
+        for (int s = 0; s < NS; ++s) wf[u][s] = wload<NT>(wrow[s] + k + 32 * u);
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        if constexpr (NORM) xf[u][t] = *(const bf16x8*)(xs + xs_off + k + 32 * u);
-        else xf[u][t] = *(const bf16x8*)(xrow[t] + k + 32 * u);
+        for (int t = 0; t < RT; ++t) {
+          if constexpr (NORM) xf[u][t] = *(const bf16x8*)(xs + xs_off + k + 32 * u);
+          else xf[u][t] = *(const bf16x8*)(xrow[t] + k + 32 * u);
+        }
       }
+#pragma unroll
+      for (int u = 0; u < DD; ++u)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int t = 0; t < RT; ++t)
+            acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][s], xf[u][t], acc[s][t], 0, 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u)
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][s], xf[u][t], acc[s][t], 0, 0, 0);
-  }
-  for (; k < kper; k += 32) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const bf16x8 wf = wload<NT>(wrow[s] + k);
-#pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        bf16x8 xf;
-        if constexpr (NORM) xf = *(const bf16x8*)(xs + xs_off + k);
-        else xf = *(const bf16x8*)(xrow[t] + k);
-        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[s][t], 0, 0, 0);
-      }
-    }
-  }
+  };
+  run(std::integral_constant<int, DEPTH>{});
+  if constexpr (DEPTH > 8) run(std::integral_constant<int, 8>{});
+  if constexpr (DEPTH > 4) run(std::integral_constant<int, 4>{});
+  run(std::integral_constant<int, 1>{});
 
   // ---- combine the four K slices: waves 1..3 publish, wave 0 sums in a fixed order -------------------------
   if (wave > 0) {
@@ -199,10 +209,27 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
         }
       }
 
+  // sub-slab forms: sum the P diagonal blocks (sub-range p lives in lanes fr = p RS + i, fq = p RS / 4 + j / 4), in order
+  if constexpr (P == 2) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[s][0][e] += __shfl(acc[s][0][e], (lane + 40) & 63, 64);
+  } else if constexpr (P == 4) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[s][0][e];
+        acc[s][0][e] = ((v + __shfl(v, (lane + 20) & 63, 64)) + __shfl(v, (lane + 40) & 63, 64)) + __shfl(v, (lane + 60) & 63, 64);
+      }
+  }
+  const bool own = P == 1 || (fr < RS && fq < RS / 4);   // lanes that hold finished sums
+
   // lane owns x row r = 16t + fr and W rows n = n0 + 4*fq + e
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
-    const int r = t * 16 + fr;
+    const int r = own ? t * 16 + fr : R;
     if constexpr (EPI == SK_ARGMAX) {
       unsigned long long best = 0ull;
 #pragma unroll
@@ -220,7 +247,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
       if (fq == 0 && r < R) atomicMax(packed + r, best);
     } else if constexpr (EPI == SK_ROPE_KV) {
       if (r < R) {
-        const int hs = blockIdx.x >> 2, d = (int)(blockIdx.x & 3) * 16 + 4 * fq;   // head slot; dims d .. d+3 and d+64 .. d+67
+        const int hs = blockIdx.x / (64 / RS), d = (int)(blockIdx.x % (64 / RS)) * RS + 4 * fq;   // head slot; dims d .. d+3 and d+64 .. d+67
         const int slot = hs % (rk.g + 2), gi = hs / (rk.g + 2);
         const int p = rk.pos[r];
         u16x4 olo, ohi;
@@ -243,7 +270,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
       }
     } else if constexpr (EPI == SK_SWIGLU) {
       if (r < R) {
-        const int n = n0 / 2 + 4 * fq;
+        const int n = (int)(blockIdx.x / P) * 16 + (int)(blockIdx.x % P) * RS + 4 * fq;
         u16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -354,8 +381,20 @@ __global__ __launch_bounds__(256) void score_tail_kernel(const ScoreHeadArgs a, 
 template <int EPI>
 hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
                          const bf16_t* resid, int ldr, bf16_t* out, int ldo, unsigned long long* packed,
-                         hipStream_t s, const bf16_t* ls = nullptr) {
+                         hipStream_t s, const bf16_t* ls = nullptr, int p = 1) {
   const int rt = (R + 15) / 16;
+  if (p != 1) {   // sub-slab forms of the decode GEMVs (skinny_kernel's P): 16 / p rows per workgroup and slab
+    const int rs = 16 / p;
+    if ((p != 2 && p != 4) || R > rs || K % (128 * p) || N % (EPI == SK_SWIGLU ? 32 : rs)) return hipErrorInvalidValue;
+    if constexpr (EPI == SK_STORE || EPI == SK_RESID || EPI == SK_SWIGLU) {
+      const int blocks = EPI == SK_SWIGLU ? N / 32 * p : N / rs;
+      if (p == 2) hipLaunchKernelGGL((skinny_kernel<1, EPI, 4, false, 0, 2>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
+      else hipLaunchKernelGGL((skinny_kernel<1, EPI, 4, false, 0, 4>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   const int ns = (EPI == SK_SWIGLU) ? 2 : (EPI == SK_ARGMAX && rt >= 2) ? 4 : 1;   // = NS of the kernel
   const int blocks = (N + 16 * ns - 1) / (16 * ns);
   // A/B knob (scripts/decode_gemv_bench.py).  Measured on the 8B decode shapes: non-temporal weight loads are SLOWER here
@@ -393,19 +432,26 @@ bool aigv_skinny_norm_fusable(int K) { return K == 4096 || K == 6144; }
 // the decode step's wqkv projection with RoPE + KV-cache append in the epilogue (SK_ROPE_KV above); x rows = one new token per sequence
 hipError_t aigv_launch_skinny_rope_kv(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, bf16_t* qkv, int ldo,
                                       const int32_t* pos, const int32_t* seq, const bf16_t* cos, const bf16_t* sin, bf16_t* kc, bf16_t* vc,
-                                      int g, int n_kv, int cap, int head_dim, hipStream_t s, const bf16_t* norm_w, float norm_eps) {
+                                      int g, int n_kv, int cap, int head_dim, hipStream_t s, const bf16_t* norm_w, float norm_eps, int p) {
   if (R <= 0) return hipSuccess;
   if (R > 64 || K % 128 || (ldx % 8) || (ldw % 8) || (ldo % 4) || head_dim != 128 || N != n_kv * (g + 2) * 128 || !pos || !seq || !cos ||
       !sin || !kc || !vc)
     return hipErrorInvalidValue;
   RopeKvArgs rk{pos, seq, cos, sin, kc, vc, g, n_kv, cap};
-  const int rt = (R + 15) / 16, blocks = N / 32;
+  const int rt = (R + 15) / 16, blocks = N / 32 * p;
+  if ((p != 1 && p != 2 && p != 4) || R > (p == 1 ? 64 : 16 / p) || K % (128 * p)) return hipErrorInvalidValue;
   if (norm_w) {   // x = the raw residual rows; attention_norm applied by the kernel (NormArgs above)
     if (R > 4 || !aigv_skinny_norm_fusable(K)) return hipErrorInvalidValue;
-#define GO(NC) hipLaunchKernelGGL((skinny_kernel<1, SK_ROPE_KV, 4, false, NC>), dim3(blocks), dim3(256), (size_t)R * K * sizeof(bf16_t), s, x, ldx, R, W, ldw, N, K, \
-                                  nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk, NormArgs{norm_w, norm_eps})
-    if (K == 4096) GO(2); else GO(3);
+#define GO(NC, PP) hipLaunchKernelGGL((skinny_kernel<1, SK_ROPE_KV, 4, false, NC, PP>), dim3(blocks), dim3(256), (size_t)R * K * sizeof(bf16_t), s, x, ldx, R, W, ldw, N, K, \
+                                      nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk, NormArgs{norm_w, norm_eps})
+    if (K == 4096) { if (p == 1) GO(2, 1); else if (p == 2) GO(2, 2); else GO(2, 4); }
+    else { if (p == 1) GO(3, 1); else if (p == 2) GO(3, 2); else GO(3, 4); }
 #undef GO
+    return hipGetLastError();
+  }
+  if (p != 1) {
+    if (p == 2) hipLaunchKernelGGL((skinny_kernel<1, SK_ROPE_KV, 4, false, 0, 2>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk);
+    else hipLaunchKernelGGL((skinny_kernel<1, SK_ROPE_KV, 4, false, 0, 4>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk);
     return hipGetLastError();
   }
 #define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, SK_ROPE_KV, 4, false>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, nullptr, nullptr, 0, qkv, ldo, nullptr, nullptr, rk)
@@ -422,12 +468,13 @@ hipError_t aigv_launch_skinny_rope_kv(const bf16_t* x, int ldx, int R, const bf1
 
 // decode: SwiGLU(x_n W13^T) with x_n = RMSNorm(x) * norm_w computed by the kernel itself (R <= 4 rows; NormArgs above)
 hipError_t aigv_launch_skinny_swiglu_normed(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, bf16_t* out, int ldo,
-                                            const bf16_t* norm_w, float norm_eps, hipStream_t s) {
+                                            const bf16_t* norm_w, float norm_eps, hipStream_t s, int p) {
   if (R <= 0) return hipSuccess;
-  if (R > 4 || !aigv_skinny_norm_fusable(K) || (ldx % 8) || (ldw % 8) || (ldo % 4) || (N % 32) || !norm_w) return hipErrorInvalidValue;
-#define GO(NC) hipLaunchKernelGGL((skinny_kernel<1, SK_SWIGLU, 4, false, NC>), dim3(N / 32), dim3(256), (size_t)R * K * sizeof(bf16_t), s, x, ldx, R, W, ldw, N, K, \
-                                  nullptr, nullptr, 0, out, ldo, nullptr, nullptr, RopeKvArgs{}, NormArgs{norm_w, norm_eps})
-  if (K == 4096) GO(2); else GO(3);
+  if (R > 4 || !aigv_skinny_norm_fusable(K) || (ldx % 8) || (ldw % 8) || (ldo % 4) || (N % 32) || !norm_w || (p != 1 && p != 2 && p != 4)) return hipErrorInvalidValue;
+#define GO(NC, PP) hipLaunchKernelGGL((skinny_kernel<1, SK_SWIGLU, 4, false, NC, PP>), dim3(N / 32 * p), dim3(256), (size_t)R * K * sizeof(bf16_t), s, x, ldx, R, W, ldw, N, K, \
+                                      nullptr, nullptr, 0, out, ldo, nullptr, nullptr, RopeKvArgs{}, NormArgs{norm_w, norm_eps})
+  if (K == 4096) { if (p == 1) GO(2, 1); else if (p == 2) GO(2, 2); else GO(2, 4); }
+  else { if (p == 1) GO(3, 1); else if (p == 2) GO(3, 2); else GO(3, 4); }
 #undef GO
   return hipGetLastError();
 }
@@ -436,15 +483,16 @@ hipError_t aigv_launch_skinny_swiglu_normed(const bf16_t* x, int ldx, int R, con
 //      6 layer-scale + residual (+bias)
 hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K,
                                    const bf16_t* bias, const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi,
-                                   hipStream_t s, const bf16_t* ls) {
+                                   hipStream_t s, const bf16_t* ls, int p) {
   if (R <= 0) return hipSuccess;
   if (R > 64 || K % 128 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return hipErrorInvalidValue;
   if (epi != SK_SWIGLU && N % 4) return hipErrorInvalidValue;
   if (epi == SK_SWIGLU && N % 32) return hipErrorInvalidValue;
+  if (p != 1 && epi != SK_STORE && epi != SK_RESID && epi != SK_SWIGLU) return hipErrorInvalidValue;
   switch (epi) {
-    case SK_STORE: return launch_skinny<SK_STORE>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
-    case SK_RESID: return launch_skinny<SK_RESID>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
-    case SK_SWIGLU: return launch_skinny<SK_SWIGLU>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
+    case SK_STORE: return launch_skinny<SK_STORE>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s, nullptr, p);
+    case SK_RESID: return launch_skinny<SK_RESID>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s, nullptr, p);
+    case SK_SWIGLU: return launch_skinny<SK_SWIGLU>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s, nullptr, p);
     case SK_GELU: return launch_skinny<SK_GELU>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s);
     case SK_LS_RESID:
       if (!ls || !resid) return hipErrorInvalidValue;

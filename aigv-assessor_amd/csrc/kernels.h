@@ -120,15 +120,17 @@ hipError_t aigv_launch_embed(const int64_t* ids, const int32_t* slot, const bf16
 // skinny (R <= 64) weight-streaming GEMM; epi: 0 store(+bias) 1 residual 2 swiglu 3 gelu(+bias) 6 layer-scale+residual
 hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K,
                                    const bf16_t* bias, const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi,
-                                   hipStream_t s, const bf16_t* ls = nullptr);
+                                   hipStream_t s, const bf16_t* ls = nullptr, int p = 1);
+// p: 1 = 16-row slabs; 2 / 4 = the sub-slab forms (8 / 4 rows per workgroup and slab, R <= 8 / 4, store / residual / swiglu only):
+// same result up to fp32 summation order, 2x / 4x the workgroups - for widths whose 16-row slabs leave CUs unevenly loaded
 bool aigv_skinny_norm_fusable(int K);   // hidden widths the fused-norm decode GEMVs exist for
 // decode: SwiGLU(RMSNorm(x) W13^T) with the norm applied by the GEMV itself (R <= 4 rows, K <= 8192); same bits as rmsnorm + skinny swiglu
 hipError_t aigv_launch_skinny_swiglu_normed(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, bf16_t* out, int ldo,
-                                            const bf16_t* norm_w, float norm_eps, hipStream_t s);
+                                            const bf16_t* norm_w, float norm_eps, hipStream_t s, int p = 1);
 // decode: wqkv projection of the new tokens with RoPE (q heads, K) and the K / V cache append in the GEMV's epilogue (head_dim 128)
 hipError_t aigv_launch_skinny_rope_kv(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, bf16_t* qkv, int ldo,
                                       const int32_t* pos, const int32_t* seq, const bf16_t* cos, const bf16_t* sin, bf16_t* kc, bf16_t* vc,
-                                      int g, int n_kv, int cap, int head_dim, hipStream_t s, const bf16_t* norm_w = nullptr, float norm_eps = 0.f);
+                                      int g, int n_kv, int cap, int head_dim, hipStream_t s, const bf16_t* norm_w = nullptr, float norm_eps = 0.f, int p = 1);
 // lm-head on R gathered rows + argmax over the vocabulary (first maximal index, bf16-rounded logits)
 hipError_t aigv_launch_lm_head_argmax(const bf16_t* h, int R, int H, const bf16_t* W, int V,
                                       unsigned long long* packed, int64_t* out_idx, float* out_val, hipStream_t s);

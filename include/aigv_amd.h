@@ -233,6 +233,10 @@ int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us);
  * kernel (attention.hip, 32 query rows per wave) with that many waves per workgroup; 64 = the software-pipelined kernel
  * (attention64.hip) for every shape. */
 int aigv_tune_attention(int waves);
+/* Form of the decode GEMVs (process-wide; experiments and tests): 0 = default (per-shape choice in aigv_decode_step, 16-row slabs
+ * in aigv_op_skinny_gemm); 1 / 2 / 4 = 16 / 8 / 4 rows of W per workgroup and slab wherever legal (R <= 16 / p, epi store /
+ * residual / swiglu).  Results agree up to fp32 summation order. */
+int aigv_tune_skinny(int p);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* When enabled every GEMM / attention launch of the hot path is bracketed by HIP events on the launch stream. */

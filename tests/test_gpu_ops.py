@@ -463,6 +463,35 @@ def test_skinny_gemm(lib, R, N, K, epi):
     ulp_check(out, want, frac=0.03, max_ulps=4 if epi in (2, 3) else 2, atol_rel=2.0 ** -7 if epi == 1 else 2e-5)
 
 
+@pytest.mark.parametrize("p", [2, 4])
+@pytest.mark.parametrize("R,N,K,epi", [(1, 512, 1024, 1), (3, 1024, 4096, 2), (4, 768, 3584, 1), (8, 640, 512, 0), (2, 96, 512, 2), (1, 4096, 14336, 1)])
+def test_skinny_gemm_sub_slab_forms(lib, p, R, N, K, epi):
+    """The 8- and 4-row forms of the decode GEMVs (K sub-ranges packed into the MFMA's spare rows / columns): the same checks as the
+    16-row form, and agreement with it up to fp32 summation order."""
+    from aigv_assessor_amd.native import ptr
+    if R > 16 // p:
+        pytest.skip("this form takes at most 16 / p rows")
+    g = torch.Generator().manual_seed(R + N + K + p)
+    x = (torch.randn(R, K, generator=g) * 0.5).to(BF)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF) if epi == 0 else None
+    nout = N // 2 if epi == 2 else N
+    resid = torch.randn(R, nout, generator=g).to(BF) if epi == 1 else None
+    want = gemm_ref(x, W, {0: 0, 1: 3, 2: 4}[epi], bias=bias, resid=resid)
+    outs = []
+    try:
+        for form in (1, p):
+            assert lib.aigv_tune_skinny(form) == 0
+            out = torch.full((R, nout), float("nan"), dtype=BF, device="cuda")
+            sync(lib.aigv_op_skinny_gemm(ptr(dev(x)), K, R, ptr(dev(W)), K, N, K, ptr(dev(bias)) if bias is not None else None,
+                                         ptr(dev(resid)) if resid is not None else None, nout, ptr(out), nout, epi, None), lib)
+            ulp_check(out, want, frac=0.03, max_ulps=4 if epi == 2 else 2, atol_rel=2.0 ** -7 if epi == 1 else 2e-5)
+            outs.append(out.float().cpu())
+    finally:
+        lib.aigv_tune_skinny(0)
+    assert (outs[0] != outs[1]).float().mean() < 0.03            # the two forms differ by summation order only
+
+
 @pytest.mark.parametrize("R,V,H", [(10, 1009, 256), (40, 92553, 512), (64, 4099, 128)])
 def test_lm_head_argmax_first_max_on_ties(lib, R, V, H):
     from aigv_assessor_amd.native import ptr
