@@ -39,12 +39,38 @@ def rel_close(got, want, mean_tol, max_tol):
     assert err.max() / scale <= max_tol, f"max rel err {(err.max() / scale).item():.4g}"
 
 
-def score_ok(got, want):
+SCORE_LOG = []   # (test id, max |d| in bf16 ulps of the expected value) - printed so that a run shows the margin under each bar
+
+
+def score_ok(got, want, ulps=1):
+    """`score1` against the oracle / the reference's recorded value.  The reference emits a bf16 number, so the bar is stated in bf16
+    ulps of the expected value, per model size as measured (profiles/parity_score_noise_r1.txt): 1 ulp for the tiny
+    configurations, 2 for the 4096-wide shallow ones; 1e-3 (BASELINE's figure) always passes.  Full depth has its own statistical bar
+    (test_full_size_8b_matches_the_reference_golden)."""
     got, want = got.float().cpu(), want.float().cpu()
     d = (got - want).abs()
     ulp = want.abs().clamp_min(2.0 ** -126).log2().floor().exp2() * 2.0 ** -7
-    print("score1 hip", got.tolist(), "oracle", want.tolist(), "max|d|", d.max().item())
-    assert bool(((d <= 1e-3) | (d <= 2.0 ** -6 * want.abs().clamp_min(1.0) * 1.001)).all()), f"score differs: {got.tolist()} vs {want.tolist()}"
+    n_ulps = (d / ulp).max().item()
+    SCORE_LOG.append(n_ulps)
+    print("score1 hip", got.tolist(), "oracle", want.tolist(), "max|d|", d.max().item(), f"= {n_ulps:.2f} bf16 ulps (bar {ulps})")
+    assert bool(((d <= 1e-3) | (d <= ulps * ulp * 1.001)).all()), f"score differs by {n_ulps:.2f} bf16 ulps (bar {ulps}): {got.tolist()} vs {want.tolist()}"
+
+
+def score_near_fp32(got, ref_bf16, cfg, sd, toks, pv, motion, flags):
+    """The 4096-wide shallow configurations: a clip's score can sit 3-4 bf16 ulps from the reference's bf16 value while being CLOSER to
+    the fp32 computation than that value is (measured on tests/golden/e2e.pt bf16_b2: fp32 0.7202, reference bf16 0.7305, HIP 0.7148;
+    the HIP value itself moves by +-2 ulps with the attention / GEMM kernel choice).  So besides the ulp bar against the bf16 value the
+    score is anchored on the fp32 oracle, per clip: |hip - fp32| <= 1.5 |reference bf16 - fp32| + 1 bf16 ulp, or within 4 bf16 ulps of the
+    fp32 value (the largest single-clip deviations seen at this width: 3.8 ulps here, 4.6 in round 1's study; over 12 seeds the MEAN
+    |hip - fp32| is 0.0021 against 0.0027 for the reference's bf16 path: profiles/parity_score_noise_r2.txt)."""
+    sd32 = {k: v.float() for k, v in sd.items()}
+    f32 = O.forward_eval(sd32, cfg, pv.float(), toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion.float(),
+                         toks["img_context_token_id"], stage=2)["score1"].float()
+    got, ref_bf16 = got.float().cpu(), ref_bf16.float().cpu()
+    ulp = f32.abs().clamp_min(2.0 ** -126).log2().floor().exp2() * 2.0 ** -7
+    print("score1 fp32 oracle", f32.tolist(), "|hip - fp32|", (got - f32).abs().tolist(), "|reference bf16 - fp32|", (ref_bf16 - f32).abs().tolist())
+    d = (got - f32).abs()
+    assert bool(((d <= 1.5 * (ref_bf16 - f32).abs() + ulp) | (d <= 4 * ulp * 1.001)).all())
 
 
 def run_case(cfg, B, T, seed, stage=2, px=None):
@@ -389,7 +415,9 @@ def test_against_reference_golden_vectors(golden_dir):
         # (the oracle re-run on THIS host's CPU may differ from the golden in non-answer rows: other BLAS kernels)
         logits = ref["logits"][..., :-1, :].reshape(-1, ref["logits"].shape[-1])[want]
         assert assert_levels(out["logit"].cpu()[want], g["logit"][want], logits) <= 2
-        score_ok(out["score1"], g["score1"])
+        score_ok(out["score1"], g["score1"], ulps=4)       # 4096-wide LLM: see score_near_fp32
+        score_near_fp32(out["score1"], g["score1"], cfg, sd, toks, synth.synthetic_frames(B * T, 448, seed=seed), synth.synthetic_motion(B, 2304, seed=seed),
+                        torch.ones(B * T, 1, dtype=torch.long))
         del model
         torch.cuda.empty_cache()
 
@@ -505,8 +533,9 @@ def test_config5_fp8_mode_at_8b_widths():
     B, T, seed = 2, 8, 15
     model, sd, toks, pv, motion, ref, out = run_case(cfg, B=B, T=T, seed=seed)             # bf16 pass + bf16 oracle
     check_levels(out, ref)
-    score_ok(out["score1"], ref["score1"])
     flags = torch.ones(B * T, 1, dtype=torch.long)
+    score_ok(out["score1"], ref["score1"], ulps=4)         # 4096-wide LLM: see score_near_fp32
+    score_near_fp32(out["score1"], ref["score1"], cfg, sd, toks, pv, motion, flags)
     with O8.fp8_llm(cfg.llm_config.num_hidden_layers):
         ref8 = O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion,
                               toks["img_context_token_id"], mos=None, stage=2, return_intermediates=True)
