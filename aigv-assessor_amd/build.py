@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "attention64.hip", "rowops.hip", "head.hip", "ingest.hip", "slowfast.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "attention64.hip", "rowops.hip", "head.hip", "head8.hip", "ingest.hip", "slowfast.hip"]
 HEADERS = ["common.h", "kernels.h", "attn_lay.h", os.path.join("..", "..", "include", "aigv_amd.h")]
 OUT = os.path.join(HERE, "libaigv_amd.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]

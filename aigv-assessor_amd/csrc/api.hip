@@ -1342,8 +1342,51 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
   // AIGV_DECODE_P="wqkv,wo,w13,w2" overrides (A/B); aigv_tune_skinny forces one value everywhere it is legal.
   int pq, po, p13, p2;
   decode_forms(c, B, &pq, &po, &p13, &p2);
+  // fp8 mode: the linears the prefill runs in e4m3 stream their e4m3 copies here too (head8.hip: half the bytes per token; the
+  // x rows are normalised and quantised by the GEMV itself) - up to 4 sequences and for the widths the kernel is built for; larger
+  // batches decode from the bf16 weights.  AIGV_DECODE_FP8=0 keeps the bf16 GEMVs (A/B).  AIGV_DECODE_P8 = forms, as AIGV_DECODE_P.
+  static const bool f8_env = getenv("AIGV_DECODE_FP8") ? atoi(getenv("AIGV_DECODE_FP8")) != 0 : true;
+  const bool f8 = f8_env && c->fp8_llm && B <= 4 && aigv_skinny_fp8_supported(H, true) && aigv_skinny_fp8_supported(I, false) && D == 128;
+  int q8[4] = {4, 2, 4, 2};
+  {
+    static const char* env8 = getenv("AIGV_DECODE_P8");
+    int v[4];
+    if (env8 && sscanf(env8, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
+      for (int i = 0; i < 4; ++i)
+        if (v[i] == 1 || v[i] == 2 || v[i] == 4) q8[i] = v[i];
+    if (I / (4 * q8[3]) < 256 || I % (512 * q8[3])) q8[3] = 1;
+  }
   for (int li = 0; li < k.llm_layers; ++li) {
     const LlmLayer& L = c->llm[li];
+    if (f8) {
+      const LlmLayerFp8& Q = c->llm8[li];
+      const bool post8 = li != k.llm_layers - 1;   // the post-attention half of the last layer stays bf16, as in the prefill
+      const AigvRopeKv rk{c->dec_pos, c->dec_seq, c->rope_cos, c->rope_sin, c->kc + li * kv_layer, c->vc + li * kv_layer, g, nkv, k.kv_capacity};
+      {
+        ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * B * (double)c->qkv_out * H, (double)c->qkv_out * H, s);
+        HIPCHK(c, aigv_launch_skinny_fp8(c->l_h, H, B, Q.wqkv, H, Q.s_wqkv, c->qkv_out, H, nullptr, 0, c->l_qkv, c->qkv_out, 7, &rk, L.an, k.rms_eps, q8[0], s));
+      }
+      HIPCHK(c, aigv_launch_attention_decode(c->l_qkv, c->qkv_out, (g + 2) * D, c->kc + li * kv_layer, c->vc + li * kv_layer,
+                                             c->dec_kvlen, k.kv_capacity, c->l_ao, H, B, nkv, g, D, sqrtf((float)D), max_vis,
+                                             c->dec_ws, s));
+      if (post8) {
+        ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * B * ((double)H * H + 3.0 * H * I), (double)H * H + 3.0 * H * I, s);
+        HIPCHK(c, aigv_launch_skinny_fp8(c->l_ao, H, B, Q.wo, H, Q.s_wo, H, H, c->l_h, H, c->l_h, H, 1, nullptr, nullptr, 0.f, q8[1], s));
+        HIPCHK(c, aigv_launch_skinny_fp8(c->l_h, H, B, Q.w13, H, Q.s_w13, 2 * I, H, nullptr, 0, c->l_ffn, I, 2, nullptr, L.fn, k.rms_eps, q8[2], s));
+        HIPCHK(c, aigv_launch_skinny_fp8(c->l_ffn, I, B, Q.w2, I, Q.s_w2, H, I, c->l_h, H, c->l_h, H, 1, nullptr, nullptr, 0.f, q8[3], s));
+      } else {
+        TRY(run_skinny(c, c->l_ao, H, B, L.wo, H, H, H, nullptr, c->l_h, H, c->l_h, H, 1, s, po));
+        if (fused) {
+          ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * B * 2.0 * I * H, 2.0 * 2.0 * I * H, s);
+          HIPCHK(c, aigv_launch_skinny_swiglu_normed(c->l_h, H, B, L.w13, H, 2 * I, H, c->l_ffn, I, L.fn, k.rms_eps, s, p13));
+        } else {
+          HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, B, H, k.rms_eps, nullptr, s));
+          TRY(run_skinny(c, c->l_t, H, B, L.w13, H, 2 * I, H, nullptr, nullptr, 0, c->l_ffn, I, 2, s, p13));
+        }
+        TRY(run_skinny(c, c->l_ffn, I, B, L.w2, I, H, I, nullptr, c->l_h, H, c->l_h, H, 1, s, p2));
+      }
+      continue;
+    }
     if (!fused) HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, B, H, k.rms_eps, nullptr, s));
     {   // wqkv with RoPE + KV-cache append in its epilogue: one launch instead of GEMV + rope / store
       ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * B * (double)c->qkv_out * H, 2.0 * (double)c->qkv_out * H, s);
@@ -1447,6 +1490,16 @@ int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W_, int ldw, 
                         const void* resid, int ldr, void* out, int ldo, int epi, void* stream) {
   return run_skinny(nullptr, (const bf16_t*)x, ldx, R, (const bf16_t*)W_, ldw, N, K, (const bf16_t*)bias,
                     (const bf16_t*)resid, ldr, (bf16_t*)out, ldo, epi, (hipStream_t)stream, g_skinny_p ? g_skinny_p : 1);
+}
+
+int aigv_op_skinny_gemm_fp8(const void* x, int ldx, int R, const void* W_e4m3, int ldw, const float* w_scale, int N, int K, const void* resid,
+                            int ldr, void* out, int ldo, int epi, const void* norm_w, float eps, int p, void* stream) {
+  if (epi != 1 && epi != 2) return fail(nullptr, AIGV_ERR_ARG, "aigv_op_skinny_gemm_fp8: epi must be 1 (residual) or 2 (swiglu)");
+  hipError_t e = aigv_launch_skinny_fp8((const bf16_t*)x, ldx, R, (const uint8_t*)W_e4m3, ldw, w_scale, N, K, (const bf16_t*)resid, ldr, (bf16_t*)out, ldo,
+                                        epi, nullptr, (const bf16_t*)norm_w, eps, p, (hipStream_t)stream);
+  if (e != hipSuccess)
+    return fail(nullptr, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "fp8 skinny gemm (R=%d N=%d K=%d epi=%d p=%d): %s", R, N, K, epi, p, hipGetErrorString(e));
+  return 0;
 }
 
 int aigv_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H, float eps,

@@ -123,6 +123,17 @@ hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t
                                    hipStream_t s, const bf16_t* ls = nullptr, int p = 1);
 // p: 1 = 16-row slabs; 2 / 4 = the sub-slab forms (8 / 4 rows per workgroup and slab, R <= 8 / 4, store / residual / swiglu only):
 // same result up to fp32 summation order, 2x / 4x the workgroups - for widths whose 16-row slabs leave CUs unevenly loaded
+// e4m3 form of the decode GEMVs (head8.hip; fp8 mode of the InternLM2 linears).  epi: 1 residual, 2 swiglu, 7 wqkv with RoPE + KV append
+// (rk); norm_w != null: the RMSNorm in front of the linear is applied by the kernel.  R <= 4 rows; W8 [N][ldw bytes] e4m3, w_scale [N]
+struct AigvRopeKv {
+  const int32_t* pos; const int32_t* seq;      // position / cache sequence of every x row (device)
+  const bf16_t* cos; const bf16_t* sin;        // [max_pos, 64]
+  bf16_t* kc; bf16_t* vc;                      // [seq][kv head][cap][128]
+  int g, n_kv, cap;
+};
+bool aigv_skinny_fp8_supported(int K, bool with_norm);
+hipError_t aigv_launch_skinny_fp8(const bf16_t* x, int ldx, int R, const uint8_t* W8, int ldw, const float* w_scale, int N, int K, const bf16_t* resid,
+                                  int ldr, bf16_t* out, int ldo, int epi, const AigvRopeKv* rk, const bf16_t* norm_w, float eps, int p, hipStream_t s);
 bool aigv_skinny_norm_fusable(int K);   // hidden widths the fused-norm decode GEMVs exist for
 // decode: SwiGLU(RMSNorm(x) W13^T) with the norm applied by the GEMV itself (R <= 4 rows, K <= 8192); same bits as rmsnorm + skinny swiglu
 hipError_t aigv_launch_skinny_swiglu_normed(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, bf16_t* out, int ldo,

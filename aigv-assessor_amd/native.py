@@ -72,6 +72,7 @@ PROTOTYPES = {
     "aigv_op_quant_fp8_rows": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "aigv_op_gemm_fp8": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "aigv_op_skinny_gemm": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
+    "aigv_op_skinny_gemm_fp8": (_I, [_P, _I, _I, _P, _I, C.POINTER(C.c_float), _I, _I, _P, _I, _P, _I, _I, _P, _F, _I, _P]),
     "aigv_op_layernorm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
     "aigv_op_rmsnorm": (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P, _P]),
     "aigv_op_rope": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

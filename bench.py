@@ -181,7 +181,7 @@ class _DryRunModel:
         pass
 
 
-def decode_metric(model, cfg, toks, pv, T, n_short=9, n_long=41):
+def decode_metric(model, cfg, toks, pv, T, n_short=9, n_long=41, fp8=False):
     """Greedy decode at batch 1 behind clip 0's prompt (generate(): modeling_internvl_chat.py:769-811): ms per new token from the
     difference of two runs (same prefill, 32 more tokens), and the fraction of the 8 TB/s HBM roof the weight stream reaches -
     a decode step reads every decoder weight and the lm-head once."""
@@ -206,6 +206,9 @@ def decode_metric(model, cfg, toks, pv, T, n_short=9, n_long=41):
     d = l.head_dim
     per_layer = (l.num_attention_heads + 2 * l.num_key_value_heads) * d * l.hidden_size + l.hidden_size * l.hidden_size + 3 * l.hidden_size * l.intermediate_size
     weight_bytes = 2.0 * (l.num_hidden_layers * per_layer + l.vocab_size * l.hidden_size)
+    if fp8:   # fp8 mode: one byte per weight except the post-attention half of the last layer and the lm-head (they stay bf16)
+        post = l.hidden_size * l.hidden_size + 3 * l.hidden_size * l.intermediate_size
+        weight_bytes = 1.0 * (l.num_hidden_layers * per_layer - post) + 2.0 * (post + l.vocab_size * l.hidden_size)
     kv_bytes = 2.0 * 2 * l.num_hidden_layers * l.num_key_value_heads * d * (n_prompt + (n_short + n_long) / 2)
     return {"decode_ms_per_token": ms, "decode_batch": 1, "decode_prompt_tokens": n_prompt,
             "decode_bytes_per_token": weight_bytes + kv_bytes, "decode_hbm_tb_per_s": (weight_bytes + kv_bytes) / (ms * 1e-3) / 1e12,
@@ -406,8 +409,8 @@ def main():
             line["device_calibration"] = device_calibration(dev)
         if dry:
             line["dry_run"] = True
-        if world == 1 and not dry and not args.no_decode and args.model == "8b" and args.precision == "bf16":
-            line.update(decode_metric(model, cfg, toks, pv, T))
+        if world == 1 and not dry and not args.no_decode and args.model == "8b":
+            line.update(decode_metric(model, cfg, toks, pv, T, fp8=args.precision == "fp8"))
         if world == 1 and not dry and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, T, N, slowfast=args.motion == "slowfast")
             line["gpu_over_cpu"] = clips_per_s / line["cpu_baseline"]["value"]

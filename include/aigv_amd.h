@@ -180,6 +180,13 @@ int aigv_op_gemm_fp8(const void* A_e4m3, int lda, const void* W_e4m3, int ldw, v
                      int k_slices, void* ws_f32, void* stream);   /* k_slices > 1: split-K, ws_f32 = k_slices * M * N floats, K/128 % k_slices == 0 */
 int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W, int ldw, int N, int K, const void* bias,
                         const void* resid, int ldr, void* out, int ldo, int epi, void* stream);
+/* The e4m3 form of a decode GEMV (fp8 mode; what aigv_decode_step runs per linear after aigv_set_precision(fp8)): R <= 4 bf16 rows x
+ * [R, K] are (optionally RMS-normalised with norm_w / eps, then) quantised per row inside the kernel, W_e4m3 [N, ldw bytes] with one
+ * fp32 scale per output channel, out = epilogue(bf16((acc * row scale) * channel scale)).  epi: 1 residual, 2 swiglu (w1|w3 in 16-row
+ * blocks; needs norm_w).  K = 2048 j, j in {2, 3} with a norm, {2, 3, 7, 8} without; p = 1 / 2 / 4: 16 / 8 / 4 rows of W per workgroup
+ * (R <= 16 / p). */
+int aigv_op_skinny_gemm_fp8(const void* x, int ldx, int R, const void* W_e4m3, int ldw, const float* w_scale, int N, int K, const void* resid,
+                            int ldr, void* out, int ldo, int epi, const void* norm_w, float eps, int p, void* stream);
 int aigv_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H,
                       float eps, void* stream);
 int aigv_op_rmsnorm(const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps,

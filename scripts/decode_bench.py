@@ -10,6 +10,8 @@ cfg = pkg.internvl2_8b()
 dev = torch.device('cuda', 0)
 model = InternVLChatModel(cfg, device=dev, max_clips=B)
 model.load_state_dict(synth.make_state_dict(cfg, seed=0, device=dev, rich=True))
+if os.environ.get("PREC") == "fp8":            # fp8 mode of the InternLM2 linears: the decode GEMVs stream the e4m3 copies
+    model.set_precision("fp8")
 toks = synth.canonical_tokens(cfg, B, 8, seed=0)
 model.img_context_token_id = toks["img_context_token_id"]
 n_prompt = int((toks["labels"][0] == -100).sum())

@@ -570,6 +570,53 @@ def test_config5_fp8_mode_at_8b_widths():
     assert drift <= 0.08
 
 
+def test_fp8_mode_decode_streams_e4m3_weights_at_8b_widths():
+    """generate() in fp8 mode at the 8B widths: the decode GEMVs read the e4m3 copies of the weights (csrc/head8.hip) and quantise
+    the token rows themselves.  Checked against oracle/fp8.py's arithmetic run through the oracle's KV-cache path, teacher-forced on
+    the HIP tokens: every generated token is the oracle's argmax at that step, or a near-tie of the oracle's own logits (random
+    weights give near-uniform vocabulary logits and an e4m3 code can flip on a one-ulp activation difference)."""
+    from oracle import fp8 as O8
+    cfg = pkg.internvl2_8b()
+    cfg.vision_config.num_hidden_layers = 1
+    cfg.llm_config.num_hidden_layers = 3
+    cfg.llm_config.vocab_size = 4096
+    B, T, seed, n_new = 1, 8, 16, 6
+    sd = synth.make_state_dict(cfg, seed=seed, rich=True)
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    ids = toks["input_ids"][:, :n_prompt].clone()
+    ctx = toks["img_context_token_id"]
+    ids[0, (ids[0] == ctx).nonzero()[-1]] = 7          # generate() prompts carry no motion slot
+    pv = synth.synthetic_frames(B * T, 448, seed=seed)
+    model = make_model(cfg, sd)
+    model.img_context_token_id = ctx
+    mask = torch.ones_like(ids)
+    got_bf16 = model.generate(pixel_values=pv, input_ids=ids, attention_mask=mask, max_new_tokens=n_new, do_sample=False).cpu()
+    model.set_precision("fp8")
+    try:
+        got = model.generate(pixel_values=pv, input_ids=ids, attention_mask=mask, max_new_tokens=n_new, do_sample=False).cpu()
+    finally:
+        model.set_precision("bf16")
+    assert got.shape == (B, n_new)
+    emb = O.scatter_embeds(sd, ids, ctx, O.extract_feature(sd, cfg, pv), None)
+    pos = (mask.cumsum(-1) - 1)
+    gaps, exact = [], 0
+    with O8.fp8_llm(cfg.llm_config.num_hidden_layers):
+        hidden, past, _ = O.llm_forward(sd, cfg, emb, mask.bool(), pos)
+        m = mask.clone()
+        for t in range(n_new):
+            logits = O.lm_logits(sd, hidden[:, -1:, :])[0, -1].float()
+            top, tok = int(logits.argmax()), int(got[0, t])
+            exact += top == tok
+            gaps.append(round(abs(logits[top].item() - logits[tok].item()) / _bf16_ulp(logits[top].item()), 1))
+            m = torch.cat([m, torch.ones((B, 1), dtype=m.dtype)], dim=1)
+            emb_t = torch.nn.functional.embedding(got[:, t:t + 1], sd["language_model.model.tok_embeddings.weight"])
+            hidden, past, _ = O.llm_forward(sd, cfg, emb_t, m.bool(), (m.cumsum(-1) - 1)[:, -1:], past)
+    print(f"fp8 decode at 8B widths: tokens {got.tolist()} (bf16 mode: {got_bf16.tolist()}); oracle gap of each HIP token in bf16 ulps {gaps}; exact {exact}/{n_new}")
+    assert all(x <= 8 for x in gaps), gaps
+    assert exact >= n_new // 2
+
+
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE.json's headline configuration at FULL size (InternViT-300M x 24 layers + InternLM2.5-7B x 32 layers, 8 frames x
 # 448 px, N = 2177), against outputs of the imported REFERENCE recorded by tests/golden/make_golden_8b.py.

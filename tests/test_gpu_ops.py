@@ -705,6 +705,40 @@ def test_fp8_gemm_epilogues(lib, M, N, K, epi):
     ulp_check(C2, want, frac=0.03 if epi in (1, 4) else 0.02, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
+@pytest.mark.parametrize("p", [1, 2, 4])
+@pytest.mark.parametrize("R,N,K,epi,norm", [(1, 512, 4096, 1, False), (3, 256, 14336, 1, False), (4, 1024, 4096, 2, True), (2, 384, 6144, 2, True),
+                                            (1, 128, 16384, 1, False)])
+def test_fp8_decode_gemv(lib, p, R, N, K, epi, norm):
+    """The e4m3 form of the decode GEMVs (csrc/head8.hip): the kernel normalises (optionally) and quantises the x rows itself; the
+    result is the fp8 mode's definition (oracle/fp8.py: per-row / per-channel scales, exact products, fp32 sums) with the bf16
+    form's epilogue rounding points."""
+    from aigv_assessor_amd.native import ptr
+    if R > 16 // p:
+        pytest.skip("this form takes at most 16 / p rows")
+    g = torch.Generator().manual_seed(R + N + K + p)
+    x = (torch.randn(R, K, generator=g) * 0.7).to(BF)
+    x[:, 5] *= 6.0                                                 # an outlier per row: the amax is not a typical element
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF)
+    gw = (torch.rand(K, generator=g) + 0.5).to(BF) if norm else None
+    eps = 1e-5
+    nout = N // 2 if epi == 2 else N
+    resid = torch.randn(R, nout, generator=g).to(BF) if epi == 1 else None
+    xin = x
+    if norm:                                                       # InternLM2RMSNorm: fp32 normalise -> bf16 -> * weight -> bf16
+        xf = x.float()
+        xin = (gw.float() * rb(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps))).to(BF)
+    qa, sa = _quant_ref(xin)
+    qw, sw = _quant_ref(w)
+    acc = ((qa.float().double() @ qw.float().double().t()).float() * sa[:, None]) * sw[None, :]
+    want = _epilogue_ref(acc, 4 if epi == 2 else 3, None, None, resid)
+    out = torch.full((R, nout), float("nan"), dtype=BF, device="cuda")
+    dsw = dev(sw)
+    import ctypes as C
+    sync(lib.aigv_op_skinny_gemm_fp8(ptr(dev(x)), K, R, ptr(dev(qw.view(torch.uint8))), K, C.cast(dsw.data_ptr(), C.POINTER(C.c_float)), N, K,
+                                     ptr(dev(resid)) if resid is not None else None, nout, ptr(out), nout, epi, ptr(dev(gw)) if norm else None, eps, p, None), lib)
+    ulp_check(out, want, frac=0.03, max_ulps=4 if epi == 2 else 2, atol_rel=2.0 ** -7 if epi == 1 else 2e-5)
+
+
 def test_fp8_gemm_rejects_bad_shapes(lib):
     t = torch.zeros(256 * 256, dtype=torch.uint8, device="cuda")
     f = torch.ones(256, dtype=torch.float32, device="cuda")
