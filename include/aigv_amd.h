@@ -122,12 +122,14 @@ int aigv_llm_extend(aigv_ctx* ctx, const int64_t* ids, const int32_t* cu, int n_
  * which streams the decoder weights once for all of them. */
 int aigv_kv_fork(aigv_ctx* ctx, int copies, void* stream);
 
-/* Arithmetic of the InternLM2 PREFILL linears (aigv_llm_prefill; BASELINE config 5).  AIGV_PRECISION_BF16 (default) is the reference's
+/* Arithmetic of the InternLM2 linears (aigv_llm_prefill, aigv_llm_extend, aigv_decode_step; BASELINE config 5).  AIGV_PRECISION_BF16 (default) is the reference's
  * dtype flow.  AIGV_PRECISION_FP8_LLM: wqkv, wo, w1|w3, w2 of every decoder layer - except wo / w1|w3 / w2 of the LAST layer, which act on
  * the few consumed rows - run on the e4m3 MFMA: weights quantised once per output channel (scale = amax / 448), activations per token row
  * on the fly (aigv_op_quant_fp8_rows), fp32 accumulation, the bf16 path's epilogues and rounding points after the scaled accumulator.
- * Attention, norms, RoPE, residual stream, lm-head and score head stay bf16, and so does aigv_decode_step; aigv_llm_extend runs the
- * same e4m3 linears as the prefill (a continuation scores like the same tokens inside one prefill of this mode).  The reference
+ * Attention, norms, RoPE, residual stream, lm-head and score head stay bf16.  aigv_llm_extend runs the same e4m3 linears as the
+ * prefill (a continuation scores like the same tokens inside one prefill of this mode); aigv_decode_step streams the e4m3 copies too
+ * (same rule: all but the post-attention half of the last layer; the token rows are normalised and quantised inside the GEMVs) for up
+ * to 4 sequences and hidden / intermediate widths of 2048 j (j = 2, 3 / 2, 3, 7, 8), else it decodes from the bf16 weights.  The reference
  * has no fp8 path: results move by the quantisation noise (oracle/fp8.py restates this mode; measured drift in DESIGN.md).  First call
  * quantises the weights (extra memory: one byte per InternLM2 linear weight).  Needs H, qkv width, 2*I multiples of 256.
  * aigv_finalize_weights (i.e. any reload of weights) drops the e4m3 copies and returns the context to bf16: set the mode again after it. */
