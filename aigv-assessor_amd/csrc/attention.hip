@@ -562,18 +562,16 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
   return nw == 8 ? launch_attn<128, false, 8>(a, s) : launch_attn<128, false, 4>(a, s);
 }
 
-// Which kernel runs which query rows (A/B on one device, scripts/attn_bench.py with AB_WAVES=1, profiles/r2_attn_ab.txt):
-//   * non-causal (InternViT): the software-pipelined kernel of attention64.hip - 860 vs 790 TFLOP/s on 32 x 1024 rows at d = 64.
-//     For uniform sequences whose last query block holds at most 32 rows (1025 = 4 x 256 + 1) that block goes to the kernel
-//     above in its key-split form, as a second launch over just those blocks (193 vs 196 us for 32 x 1025 rows);
-//   * causal (InternLM2 prefill): the one-tile-at-a-time kernel above - 808 vs 775 TFLOP/s on 4 x 2176 rows: at d = 128 a wave
-//     holds one 32-row sub-block in both kernels (two would need more than the 256 registers a lane has at two waves per SIMD),
-//     and the pipelined form's masked half tiles and three-slot K ring cost more than its schedule gains;
-//   * short sequences (the few-token continuations of aigv_llm_extend): the kernel above.
-// aigv_tune_attention forces one kernel for experiments and tests (4 / 8: above, 64: attention64.hip).
+// Which kernel runs.  Default: the one-tile-at-a-time kernel above, for every shape.  The software-pipelined kernel of attention64.hip
+// wins the ISOLATED A/B on the non-causal shapes (scripts/attn_bench.py with AB_WAVES=1, profiles/r2_attn_ab.txt: 824-844 vs 753-784
+// TFLOP/s on 32 x 1024 rows at d = 64, the same launch repeated on inputs that then sit in the Infinity Cache) but loses it INSIDE the
+// scorer's step (bench.py --attn-kernel 0 / 4 / 64 on one box, profiles/r2_attn_inmodel_ab.txt: InternViT attention 5.03 vs 4.75 ms per
+// step, body 204 us per layer against 165 us isolated): with two workgroups of four waves per CU it hides less of the latency of
+// q / k / v rows that the qkv GEMM has only just written.  Causal shapes: 766 vs 802 TFLOP/s isolated.  It stays reachable through
+// aigv_tune_attention(64) (tests, A/B); uniform sequences whose last 256-row block holds at most 32 rows (1025 = 4 x 256 + 1) then
+// run that block on the kernel above in its key-split form over a compact grid.  4 / 8 force the kernel above with that many waves.
 hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
-  if (g_attn_waves == 4 || g_attn_waves == 8) return launch_attention32(a, head_dim, s);
-  if (g_attn_waves != 64 && (a.causal || a.max_len < 192)) return launch_attention32(a, head_dim, s);
+  if (g_attn_waves != 64) return launch_attention32(a, head_dim, s);
   const int rem = a.max_len % 256;
   if (!a.causal && a.uniform_len && a.q_tail == 0 && a.max_len > 256 && rem > 0 && rem <= 32) {
     AttnArgs body = a, tail = a;

@@ -234,6 +234,8 @@ def main():
     ap.add_argument("--all-rows", action="store_true", help="A/B: run every row through the last decoder layer (no row trimming)")
     ap.add_argument("--force-dp", action="store_true", help="route a 1-GPU run through the frame/clip-DP scorer too (debug)")
     ap.add_argument("--ingest", action="store_true", help="variant: pinned uint8 720p frames -> H2D -> resize + normalise on the GPU inside every step")
+    ap.add_argument("--attn-kernel", type=int, default=0, choices=[0, 4, 8, 64],
+                    help="A/B: force one prefill-attention kernel (aigv_tune_attention): 4 / 8 = attention.hip, 64 = attention64.hip; 0 = per-shape default")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on gloo / CPU with a stand-in model (no measurement)")
     args = ap.parse_args()
@@ -285,6 +287,9 @@ def main():
             model.set_row_trimming(False)
         if args.precision == "fp8":
             model.set_precision("fp8")
+        if args.attn_kernel:
+            from aigv_assessor_amd import native
+            native.check(native.load().aigv_tune_attention(args.attn_kernel))
     # inputs resident in HBM before the timed region (token ids are host data in the reference loop; tiny either way)
     pv = synth.synthetic_frames(B * T, cfg.image_size, seed=0, device=dev)
     motion = synth.synthetic_motion(B, cfg.motion_dim, seed=0, device=dev) if args.motion == "input" else None
