@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--ingest", action="store_true", help="variant: pinned uint8 720p frames -> H2D -> resize + normalise on the GPU inside every step")
     ap.add_argument("--attn-kernel", type=int, default=0, choices=[0, 4, 8, 64],
                     help="A/B: force one prefill-attention kernel (aigv_tune_attention): 4 / 8 = attention.hip, 64 = attention64.hip; 0 = per-shape default")
+    ap.add_argument("--tune-gemm", type=int, default=0, help="A/B: aigv_tune_gemm mode word (kernel choice + 16 * (1 + 256-kernel schedule variant))")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on gloo / CPU with a stand-in model (no measurement)")
     args = ap.parse_args()
@@ -290,6 +291,9 @@ def main():
         if args.attn_kernel:
             from aigv_assessor_amd import native
             native.check(native.load().aigv_tune_attention(args.attn_kernel))
+        if args.tune_gemm:
+            from aigv_assessor_amd import native
+            native.check(native.load().aigv_tune_gemm(args.tune_gemm, 0.0))
     # inputs resident in HBM before the timed region (token ids are host data in the reference loop; tiny either way)
     pv = synth.synthetic_frames(B * T, cfg.image_size, seed=0, device=dev)
     motion = synth.synthetic_motion(B, cfg.motion_dim, seed=0, device=dev) if args.motion == "input" else None
