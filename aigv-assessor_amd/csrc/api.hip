@@ -51,7 +51,9 @@ struct aigv_ctx {
   int device = 0;
   std::string err;
   std::unordered_map<std::string, DevBuf> w;
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;      // weight-side device memory: derived weights, e4m3 copies
+  std::vector<void*> ws_allocs;   // capacity-sized workspaces (aigv_ctx_create / aigv_ctx_resize)
+  bool ws_phase = false;          // dalloc books into ws_allocs while the workspaces are being allocated
   bool finalized = false;
   // derived sizes
   int np = 0, S = 0, Kp = 0, grid = 0, ntok = 0, proj_in = 0, qkv_out = 0, head_dim = 0, vit_head_dim = 0, g = 0;
@@ -127,7 +129,7 @@ int dalloc(aigv_ctx* c, T** out, size_t count) {
   if (e != hipSuccess) return fail(c, AIGV_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
   e = hipMemset(p, 0, bytes);
   if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
-  c->allocs.push_back(p);
+  (c->ws_phase ? c->ws_allocs : c->allocs).push_back(p);
   *out = (T*)p;
   return 0;
 }
@@ -502,6 +504,76 @@ int aigv_sizeof_config(void) { return (int)sizeof(aigv_config); }
 
 const char* aigv_last_error(const aigv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
+// Everything whose size depends on the capacities of aigv_config (frames, tokens, sequences, output rows, KV): activations, index
+// arrays, split-K scratch, KV caches.  Booked in ws_allocs so that aigv_ctx_resize can replace them without touching the weights.
+static int alloc_workspaces(aigv_ctx* c) {
+  const aigv_config& k = c->cfg;
+  hipError_t e = hipSuccess;
+  int rc = 0;
+  c->ws_phase = true;
+  c->kc = c->vc = nullptr;   // (no KV capacity: no caches)
+  c->dec_ws = nullptr; c->dec_pos = c->dec_seq = c->dec_kvlen = c->dec_slot = nullptr;
+  const size_t vr = (size_t)k.vit_chunk * c->S;
+  const size_t pr = (size_t)k.vit_chunk * c->ntok;
+  const size_t T = (size_t)k.max_tokens;
+  do {
+    if ((rc = dalloc(c, &c->v_col, (size_t)k.vit_chunk * c->np * c->Kp))) break;
+    if ((rc = dalloc(c, &c->v_x, vr * k.vit_hidden))) break;
+    if ((rc = dalloc(c, &c->v_t, vr * k.vit_hidden))) break;
+    if ((rc = dalloc(c, &c->v_qkv, vr * 3 * k.vit_hidden))) break;
+    if ((rc = dalloc(c, &c->v_ao, vr * k.vit_hidden))) break;
+    if ((rc = dalloc(c, &c->v_h, vr * k.vit_inter))) break;
+    if ((rc = dalloc(c, &c->v_cu, (size_t)k.vit_chunk + 1))) break;
+    if ((rc = dalloc(c, &c->p_t, pr * c->proj_in))) break;
+    if ((rc = dalloc(c, &c->p_mid, pr * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_h, T * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_t, T * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_qkv, T * c->qkv_out))) break;
+    if ((rc = dalloc(c, &c->l_ao, T * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_ffn, T * k.llm_inter))) break;
+    if ((rc = dalloc(c, &c->l_rows, (size_t)(k.max_out_rows + k.max_seqs + 64) * k.llm_hidden))) break;
+    if ((rc = dalloc(c, &c->l_pos, T))) break;
+    if ((rc = dalloc(c, &c->l_seq, T))) break;
+    if ((rc = dalloc(c, &c->l_cu, (size_t)k.max_seqs + 1))) break;
+    if ((rc = dalloc(c, &c->l_rowidx, (size_t)k.max_out_rows + k.max_seqs + 64))) break;
+    if ((rc = dalloc(c, &c->l_kvlen, (size_t)k.max_seqs))) break;
+    if ((rc = dalloc(c, &c->l_packed, (size_t)64))) break;
+    if ((rc = dalloc(c, &c->l_trim, (size_t)64 * (3 * k.llm_hidden + k.llm_inter)))) break;
+    if ((rc = dalloc(c, &c->l_neg1, (size_t)k.max_tokens))) break;
+    {   // split-K slabs: the planner's cap, or less when no GEMM of this context can reach it (8 slices x most rows x widest N)
+      const size_t widest = (size_t)std::max(std::max(std::max(2 * k.llm_inter, c->qkv_out), std::max(k.vit_inter, 3 * k.vit_hidden)), k.llm_hidden);
+      const size_t rows = std::max((size_t)k.max_tokens, (size_t)k.vit_chunk * c->S);
+      c->splitk_floats = std::min(SPLITK_MAX_FLOATS, (size_t)8 * rows * widest);
+      void* p = nullptr;
+      if (hipMalloc(&p, c->splitk_floats * sizeof(float)) != hipSuccess) { rc = fail(c, AIGV_ERR_ALLOC, "hipMalloc(split-K scratch) failed"); break; }
+      c->ws_allocs.push_back(p);
+      c->splitk_ws = (float*)p;
+    }
+    if (hipMemset(c->l_neg1, 0xFF, (size_t)k.max_tokens * sizeof(int32_t)) != hipSuccess) { rc = fail(c, AIGV_ERR_HIP, "hipMemset failed"); break; }
+    {
+      int maxd = k.llm_hidden;
+      for (int i = 0; i < k.n_score_layers; ++i) maxd = std::max(maxd, (int)k.score_dims[i]);
+      if ((rc = dalloc(c, &c->l_score_ws, (size_t)3 * 64 * maxd))) break;
+    }
+    if (k.kv_capacity > 0) {
+      const size_t per = (size_t)k.llm_layers * k.max_seqs * k.llm_kv_heads * k.kv_capacity * c->head_dim;
+      if ((rc = dalloc(c, &c->kc, per))) break;
+      if ((rc = dalloc(c, &c->vc, per))) break;
+      if ((rc = dalloc(c, &c->dec_ws, aigv_attention_decode_ws_floats(k.max_seqs, k.llm_kv_heads, c->g, k.kv_capacity)))) break;
+      if ((rc = dalloc(c, &c->dec_pos, (size_t)k.max_seqs))) break;
+      if ((rc = dalloc(c, &c->dec_seq, (size_t)k.max_seqs))) break;
+      if ((rc = dalloc(c, &c->dec_kvlen, (size_t)k.max_seqs))) break;
+      if ((rc = dalloc(c, &c->dec_slot, (size_t)k.max_seqs))) break;
+    }
+    std::vector<int32_t> cu(k.vit_chunk + 1);
+    for (int i = 0; i <= k.vit_chunk; ++i) cu[i] = i * c->S;
+    e = hipMemcpy(c->v_cu, cu.data(), cu.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(c, AIGV_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+  } while (0);
+  c->ws_phase = false;
+  return rc;
+}
+
 int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out) {
   if (!cfg || !out) return fail(nullptr, AIGV_ERR_ARG, "aigv_ctx_create: null argument");
   *out = nullptr;
@@ -543,64 +615,7 @@ int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out) {
   c->g = k.llm_heads / k.llm_kv_heads;
   c->qkv_out = (k.llm_heads + 2 * k.llm_kv_heads) * c->head_dim;
 
-  int rc = 0;
-  const size_t vr = (size_t)k.vit_chunk * c->S;
-  const size_t pr = (size_t)k.vit_chunk * c->ntok;
-  const size_t T = (size_t)k.max_tokens;
-  do {
-    if ((rc = dalloc(c, &c->v_col, (size_t)k.vit_chunk * c->np * c->Kp))) break;
-    if ((rc = dalloc(c, &c->v_x, vr * k.vit_hidden))) break;
-    if ((rc = dalloc(c, &c->v_t, vr * k.vit_hidden))) break;
-    if ((rc = dalloc(c, &c->v_qkv, vr * 3 * k.vit_hidden))) break;
-    if ((rc = dalloc(c, &c->v_ao, vr * k.vit_hidden))) break;
-    if ((rc = dalloc(c, &c->v_h, vr * k.vit_inter))) break;
-    if ((rc = dalloc(c, &c->v_cu, (size_t)k.vit_chunk + 1))) break;
-    if ((rc = dalloc(c, &c->p_t, pr * c->proj_in))) break;
-    if ((rc = dalloc(c, &c->p_mid, pr * k.llm_hidden))) break;
-    if ((rc = dalloc(c, &c->l_h, T * k.llm_hidden))) break;
-    if ((rc = dalloc(c, &c->l_t, T * k.llm_hidden))) break;
-    if ((rc = dalloc(c, &c->l_qkv, T * c->qkv_out))) break;
-    if ((rc = dalloc(c, &c->l_ao, T * k.llm_hidden))) break;
-    if ((rc = dalloc(c, &c->l_ffn, T * k.llm_inter))) break;
-    if ((rc = dalloc(c, &c->l_rows, (size_t)(k.max_out_rows + k.max_seqs + 64) * k.llm_hidden))) break;
-    if ((rc = dalloc(c, &c->l_pos, T))) break;
-    if ((rc = dalloc(c, &c->l_seq, T))) break;
-    if ((rc = dalloc(c, &c->l_cu, (size_t)k.max_seqs + 1))) break;
-    if ((rc = dalloc(c, &c->l_rowidx, (size_t)k.max_out_rows + k.max_seqs + 64))) break;
-    if ((rc = dalloc(c, &c->l_kvlen, (size_t)k.max_seqs))) break;
-    if ((rc = dalloc(c, &c->l_packed, (size_t)64))) break;
-    if ((rc = dalloc(c, &c->l_trim, (size_t)64 * (3 * k.llm_hidden + k.llm_inter)))) break;
-    if ((rc = dalloc(c, &c->l_neg1, (size_t)k.max_tokens))) break;
-    {   // split-K slabs: the planner's cap, or less when no GEMM of this context can reach it (8 slices x most rows x widest N)
-      const size_t widest = (size_t)std::max(std::max(std::max(2 * k.llm_inter, c->qkv_out), std::max(k.vit_inter, 3 * k.vit_hidden)), k.llm_hidden);
-      const size_t rows = std::max((size_t)k.max_tokens, (size_t)k.vit_chunk * c->S);
-      c->splitk_floats = std::min(SPLITK_MAX_FLOATS, (size_t)8 * rows * widest);
-      void* p = nullptr;
-      if (hipMalloc(&p, c->splitk_floats * sizeof(float)) != hipSuccess) { rc = fail(c, AIGV_ERR_ALLOC, "hipMalloc(split-K scratch) failed"); break; }
-      c->allocs.push_back(p);
-      c->splitk_ws = (float*)p;
-    }
-    if (hipMemset(c->l_neg1, 0xFF, (size_t)k.max_tokens * sizeof(int32_t)) != hipSuccess) { rc = fail(c, AIGV_ERR_HIP, "hipMemset failed"); break; }
-    {
-      int maxd = k.llm_hidden;
-      for (int i = 0; i < k.n_score_layers; ++i) maxd = std::max(maxd, (int)k.score_dims[i]);
-      if ((rc = dalloc(c, &c->l_score_ws, (size_t)3 * 64 * maxd))) break;
-    }
-    if (k.kv_capacity > 0) {
-      const size_t per = (size_t)k.llm_layers * k.max_seqs * k.llm_kv_heads * k.kv_capacity * c->head_dim;
-      if ((rc = dalloc(c, &c->kc, per))) break;
-      if ((rc = dalloc(c, &c->vc, per))) break;
-      if ((rc = dalloc(c, &c->dec_ws, aigv_attention_decode_ws_floats(k.max_seqs, k.llm_kv_heads, c->g, k.kv_capacity)))) break;
-      if ((rc = dalloc(c, &c->dec_pos, (size_t)k.max_seqs))) break;
-      if ((rc = dalloc(c, &c->dec_seq, (size_t)k.max_seqs))) break;
-      if ((rc = dalloc(c, &c->dec_kvlen, (size_t)k.max_seqs))) break;
-      if ((rc = dalloc(c, &c->dec_slot, (size_t)k.max_seqs))) break;
-    }
-    std::vector<int32_t> cu(k.vit_chunk + 1);
-    for (int i = 0; i <= k.vit_chunk; ++i) cu[i] = i * c->S;
-    e = hipMemcpy(c->v_cu, cu.data(), cu.size() * 4, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = fail(c, AIGV_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
-  } while (0);
+  int rc = alloc_workspaces(c);
   if (rc) {
     g_err = c->err;
     aigv_ctx_destroy(c);
@@ -615,10 +630,45 @@ void aigv_ctx_destroy(aigv_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
+  for (void* p : c->ws_allocs) hipFree(p);
   for (auto& kv : c->w) hipFree(kv.second.p);
   for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (auto e : c->ev_pool) hipEventDestroy(e);
   delete c;
+}
+
+int aigv_ctx_resize(aigv_ctx* c, const aigv_config* cfg) {
+  if (!c || !cfg) return fail(c, AIGV_ERR_ARG, "aigv_ctx_resize: null argument");
+  aigv_config a = c->cfg, b = *cfg;   // the model must be the same: compare with the capacity fields levelled
+  a.max_frames = b.max_frames; a.vit_chunk = b.vit_chunk; a.max_tokens = b.max_tokens; a.max_seqs = b.max_seqs; a.max_out_rows = b.max_out_rows;
+  a.kv_capacity = b.kv_capacity; a.max_positions = b.max_positions;
+  if (memcmp(&a, &b, sizeof(aigv_config)) != 0) return fail(c, AIGV_ERR_ARG, "aigv_ctx_resize: only the capacities may change (create a new context for another model)");
+  if (b.max_frames <= 0 || b.vit_chunk <= 0 || b.max_tokens <= 0 || b.max_seqs <= 0 || b.max_out_rows <= 0)
+    return fail(c, AIGV_ERR_ARG, "capacities must be positive");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  for (void* p : c->ws_allocs) hipFree(p);
+  c->ws_allocs.clear();
+  const bool had_q8 = c->q8 != nullptr;
+  if (had_q8) {   // the e4m3 activation rows are sized by max_tokens too (they live on the weight side: aigv_set_precision made them)
+    for (void* p : {(void*)c->q8, (void*)c->q8_scale}) {
+      auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
+      if (it != c->allocs.end()) c->allocs.erase(it);
+      hipFree(p);
+    }
+    c->q8 = nullptr; c->q8_scale = nullptr;
+  }
+  const int old_pos = c->cfg.max_positions;
+  c->cfg = b;
+  c->kv_valid = false;
+  int rc = alloc_workspaces(c);
+  if (!rc && had_q8) {
+    rc = dalloc(c, &c->q8, (size_t)b.max_tokens * (size_t)std::max(b.llm_hidden, b.llm_inter));
+    if (!rc) rc = dalloc(c, &c->q8_scale, (size_t)b.max_tokens);
+  }
+  if (rc) return rc;   // the context is unusable after a failed resize: destroy it
+  if (b.max_positions != old_pos) c->finalized = false;   // the rotary tables must be loaded again at the new length, then aigv_finalize_weights
+  return 0;
 }
 
 int aigv_load_weight(aigv_ctx* c, const char* name, const void* data, const int64_t* shape, int ndim, int dtype,

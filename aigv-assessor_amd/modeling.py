@@ -316,8 +316,8 @@ class InternVLChatModel(nn.Module):
         lib = native.load()
         cfg, v, l = self.config, self.config.vision_config, self.config.llm_config
         key = getattr(self, "_cap", None) or dict(frames=0, tokens=0, clips=0, rows=0, kv=0)
-        # capacities only grow, in coarse steps (tokens by 512, KV by 256, output rows by 64): a context is re-created - workspaces
-        # re-allocated, weights re-uploaded - when a request exceeds one, so an answer a few tokens longer must not trigger that
+        # capacities only grow, in coarse steps (tokens by 512, KV by 256, output rows by 64).  A request above one re-allocates the
+        # workspaces of the context (aigv_ctx_resize: a device sync and a few hipMallocs); the weights are uploaded once per load
         up = lambda x, m: (int(x) + m - 1) // m * m
         want = dict(frames=max(key["frames"], n_frames, self._max_frames or 0, 1),
                     tokens=max(key["tokens"], up(max(n_tokens, self._max_tokens, 1), 512)), clips=max(key["clips"], n_clips, self._max_clips, 1),
@@ -325,7 +325,9 @@ class InternVLChatModel(nn.Module):
         geom = (v.image_size if cfg.force_image_size is None else cfg.force_image_size, v.hidden_size, l.vocab_size,
                 self.select_layer)
         if self._ctx is None or want != key or geom != self._ctx_key:
-            if self._ctx is not None:
+            # same model, larger capacities: only the workspaces are re-allocated (aigv_ctx_resize), the weights stay on the device
+            grow = self._ctx is not None and geom == self._ctx_key and not self._dirty
+            if self._ctx is not None and not grow:
                 lib.aigv_ctx_destroy(self._ctx)
                 self._ctx = None
             c = native.AigvConfig()
@@ -345,10 +347,22 @@ class InternVLChatModel(nn.Module):
             c.max_frames = want["frames"]
             c.vit_chunk = min(want["frames"], 64)
             c.max_tokens, c.max_seqs, c.max_out_rows, c.kv_capacity = want["tokens"], want["clips"], want["rows"], want["kv"]
-            h = C.c_void_p()
-            native.check(lib.aigv_ctx_create(self.device.index or 0, C.byref(c), C.byref(h)))
-            self._ctx, self._cap, self._ctx_key, self._dirty = h, want, geom, True
-            self._n_pos = c.max_positions
+            if grow:
+                rc = lib.aigv_ctx_resize(self._ctx, C.byref(c))
+                if rc != 0:                      # e.g. out of memory: the context is unusable now
+                    msg = lib.aigv_last_error(self._ctx)
+                    lib.aigv_ctx_destroy(self._ctx)
+                    self._ctx, self._dirty = None, True
+                    raise native.NativeError(f"libaigv_amd error {rc}: {msg.decode() if msg else '?'}")
+                self._cap = want
+                if c.max_positions != self._n_pos:   # longer rotary tables: reload them (finalize + precision mode inside)
+                    self._n_pos = c.max_positions
+                    self._upload_rope()
+            else:
+                h = C.c_void_p()
+                native.check(lib.aigv_ctx_create(self.device.index or 0, C.byref(c), C.byref(h)))
+                self._ctx, self._cap, self._ctx_key, self._dirty = h, want, geom, True
+                self._n_pos = c.max_positions
         if seq_len:
             ntk = self._rope_seq_len(seq_len)
             if ntk != getattr(self, "_rope_ntk", 0):

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "aigv_sizeof_config": (_I, []),
     "aigv_ctx_create": (_I, [_I, C.POINTER(AigvConfig), C.POINTER(_P)]),
     "aigv_ctx_destroy": (None, [_P]),
+    "aigv_ctx_resize": (_I, [_P, C.POINTER(AigvConfig)]),
     "aigv_last_error": (C.c_char_p, [_P]),
     "aigv_load_weight": (_I, [_P, C.c_char_p, _P, _I64P, _I, _I, _I]),
     "aigv_finalize_weights": (_I, [_P]),

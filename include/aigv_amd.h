@@ -76,6 +76,12 @@ int aigv_abi_version(void);
 int aigv_sizeof_config(void);                        /* sizeof(aigv_config): binding self-check */
 int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out);
 void aigv_ctx_destroy(aigv_ctx* ctx);
+/* Change the CAPACITIES of a context (max_frames, vit_chunk, max_tokens, max_seqs, max_out_rows, kv_capacity, max_positions; every
+ * other field of `cfg` must equal the context's): the workspaces are re-allocated, the loaded weights - and in fp8 mode their e4m3
+ * copies - stay where they are.  Kept KV state is dropped.  When max_positions changed the rotary tables ("rope.cos" / "rope.sin")
+ * must be loaded again at the new length and aigv_finalize_weights called before the next pass.  Synchronises the device.  A
+ * failed resize (out of memory) leaves the context unusable: destroy it. */
+int aigv_ctx_resize(aigv_ctx* ctx, const aigv_config* cfg);
 const char* aigv_last_error(const aigv_ctx* ctx);     /* ctx may be NULL (creation errors) */
 
 /* Weight upload.  `name` is the reference state-dict key, e.g.

@@ -213,3 +213,48 @@ def test_sampling_generate_follows_the_hf_warpers(rig):
         assert int(InternVLChatModel._sample(x, 1.0, 0, 0.7)) in (0, 1)          # nucleus {0.5, 0.3}: smallest set reaching 0.7
         assert int(InternVLChatModel._sample(x, 1.0, 2, 1.0)) in (0, 1)
         assert int(InternVLChatModel._sample(x, 1.0, 0, 0.4)) == 0
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_context_grows_without_reloading_the_weights(precision):
+    """A request above the context's capacities (more clips, more tokens, a first generate() that needs a KV cache) re-allocates
+    the WORKSPACES only (aigv_ctx_resize): the weights are uploaded once, and the results are those of a context sized for the
+    larger request from the start (context re-creation on capacity growth)."""
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    sd = synth.make_state_dict(cfg, seed=63, rich=True)
+
+    def make():
+        m = InternVLChatModel(cfg)
+        m.load_state_dict(sd)
+        m.eval().cuda()
+        m.set_precision(precision)
+        return m
+
+    def run(m, B, T, seed):
+        toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+        m.img_context_token_id = toks["img_context_token_id"]
+        out = m(mos=None, pixel_values=synth.synthetic_frames(B * T, 224, seed=seed), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+                image_flags=torch.ones(B * T, 1, dtype=torch.long), labels=toks["labels"], motion_feature=synth.synthetic_motion(B, cfg.motion_dim, seed=seed))
+        return out["score1"].float().cpu(), out["logit"].cpu()
+
+    grown = make()
+    uploads = []
+    real_upload = grown._upload
+    grown._upload = lambda: (uploads.append(1), real_upload())[1]
+    run(grown, 1, 2, seed=1)                       # small context
+    small_cap = dict(grown._cap)
+    s_grown, l_grown = run(grown, 3, 4, seed=2)    # more clips, frames, tokens
+    assert grown._cap != small_cap and len(uploads) == 1, (small_cap, grown._cap, uploads)
+    fresh = make()
+    s_fresh, l_fresh = run(fresh, 3, 4, seed=2)
+    assert torch.equal(s_grown, s_fresh) and torch.equal(l_grown, l_fresh)
+    # a first generate() adds the KV cache to the same context
+    toks = synth.canonical_tokens(cfg, 1, 2, seed=3)
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    ids = toks["input_ids"][:, :n_prompt].clone()
+    ids[0, (ids[0] == toks["img_context_token_id"]).nonzero()[-1]] = 7
+    pv = synth.synthetic_frames(2, 224, seed=3)
+    g1 = grown.generate(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=4, do_sample=False).cpu()
+    g2 = fresh.generate(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=4, do_sample=False).cpu()
+    assert len(uploads) == 1 and torch.equal(g1, g2)
