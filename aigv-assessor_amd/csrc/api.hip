@@ -474,6 +474,7 @@ int g_skinny_p = 0;   // aigv_tune_skinny: sub-slab form forced on the op-level 
 int run_skinny(aigv_ctx* c, const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
                const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi, hipStream_t s, int p = 1) {
   ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * R * (double)N * K, 2.0 * (double)N * K, s);
+  if (c && c->gemm_mode == 1 && p == 1) p = 0;   // one fixed plan per shape: the K split of a skinny GEMM must not depend on the row count either
   hipError_t e = aigv_launch_skinny_gemm(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, epi, s, nullptr, p);
   if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP,
                                    "skinny gemm (R=%d N=%d K=%d epi=%d): %s", R, N, K, epi, hipGetErrorString(e));

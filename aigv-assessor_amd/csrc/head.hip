@@ -383,7 +383,7 @@ hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int l
                          const bf16_t* resid, int ldr, bf16_t* out, int ldo, unsigned long long* packed,
                          hipStream_t s, const bf16_t* ls = nullptr, int p = 1) {
   const int rt = (R + 15) / 16;
-  if (p != 1) {   // sub-slab forms of the decode GEMVs (skinny_kernel's P): 16 / p rows per workgroup and slab
+  if (p > 1) {   // sub-slab forms of the decode GEMVs (skinny_kernel's P): 16 / p rows per workgroup and slab
     const int rs = 16 / p;
     if ((p != 2 && p != 4) || R > rs || K % (128 * p) || N % (EPI == SK_SWIGLU ? 32 : rs)) return hipErrorInvalidValue;
     if constexpr (EPI == SK_STORE || EPI == SK_RESID || EPI == SK_SWIGLU) {
@@ -403,7 +403,7 @@ hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int l
 #define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, EPI>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls)
   if constexpr (EPI == SK_STORE || EPI == SK_RESID) {
     static const int max8 = getenv("AIGV_SKINNY8_MAX_BLOCKS") ? atoi(getenv("AIGV_SKINNY8_MAX_BLOCKS")) : 256;   // A/B knob (scripts/decode_gemv_bench.py)
-    if (rt == 1 && K % 256 == 0 && blocks <= max8) {   // a decode GEMV with about one slab per CU: 8 K slices per workgroup
+    if (rt == 1 && K % 256 == 0 && blocks <= max8 && p != 0) {   // a decode GEMV with about one slab per CU: 8 K slices per workgroup (p == 0: the caller wants ONE form for every row count)
       if (nt) hipLaunchKernelGGL((skinny_kernel<1, EPI, 8, true>), dim3(blocks), dim3(512), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
       else hipLaunchKernelGGL((skinny_kernel<1, EPI, 8>), dim3(blocks), dim3(512), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
       return hipGetLastError();
@@ -488,7 +488,7 @@ hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t
   if (R > 64 || K % 128 || (ldx % 8) || (ldw % 8) || (ldo % 4)) return hipErrorInvalidValue;
   if (epi != SK_SWIGLU && N % 4) return hipErrorInvalidValue;
   if (epi == SK_SWIGLU && N % 32) return hipErrorInvalidValue;
-  if (p != 1 && epi != SK_STORE && epi != SK_RESID && epi != SK_SWIGLU) return hipErrorInvalidValue;
+  if (p > 1 && epi != SK_STORE && epi != SK_RESID && epi != SK_SWIGLU) return hipErrorInvalidValue;
   switch (epi) {
     case SK_STORE: return launch_skinny<SK_STORE>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s, nullptr, p);
     case SK_RESID: return launch_skinny<SK_RESID>(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, nullptr, s, nullptr, p);

@@ -121,7 +121,8 @@ hipError_t aigv_launch_embed(const int64_t* ids, const int32_t* slot, const bf16
 hipError_t aigv_launch_skinny_gemm(const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K,
                                    const bf16_t* bias, const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi,
                                    hipStream_t s, const bf16_t* ls = nullptr, int p = 1);
-// p: 1 = 16-row slabs; 2 / 4 = the sub-slab forms (8 / 4 rows per workgroup and slab, R <= 8 / 4, store / residual / swiglu only):
+// p: 0 = 16-row slabs with FOUR K slices for every row count (the form does not depend on R: batch-invariant bits; aigv_set_gemm_mode 1);
+// 1 = 16-row slabs, eight K slices for a one-tile GEMV with at most one slab per CU; 2 / 4 = the sub-slab forms (8 / 4 rows per workgroup and slab, R <= 8 / 4, store / residual / swiglu only):
 // same result up to fp32 summation order, 2x / 4x the workgroups - for widths whose 16-row slabs leave CUs unevenly loaded
 // e4m3 form of the decode GEMVs (head8.hip; fp8 mode of the InternLM2 linears).  epi: 1 residual, 2 swiglu, 7 wqkv with RoPE + KV append
 // (rk); norm_w != null: the RMSNorm in front of the linear is applied by the kernel.  R <= 4 rows; W8 [N][ldw bytes] e4m3, w_scale [N]
