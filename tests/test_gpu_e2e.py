@@ -570,11 +570,31 @@ def test_config5_fp8_mode_at_8b_widths():
     assert drift <= 0.08
 
 
-def test_fp8_mode_decode_streams_e4m3_weights_at_8b_widths():
-    """generate() in fp8 mode at the 8B widths: the decode GEMVs read the e4m3 copies of the weights (csrc/head8.hip) and quantise
-    the token rows themselves.  Checked against oracle/fp8.py's arithmetic run through the oracle's KV-cache path, teacher-forced on
-    the HIP tokens: every generated token is the oracle's argmax at that step, or a near-tie of the oracle's own logits (random
-    weights give near-uniform vocabulary logits and an e4m3 code can flip on a one-ulp activation difference)."""
+def _teacher_forced_gaps(sd, cfg, emb, mask, tokens):
+    """The oracle's KV-cache path fed the GIVEN tokens: per step, (is the token the oracle's argmax, the oracle's logit gap between its
+    argmax and the token in bf16 ulps)."""
+    B = tokens.shape[0]
+    hidden, past, _ = O.llm_forward(sd, cfg, emb, mask.bool(), (mask.cumsum(-1) - 1))
+    m = mask.clone()
+    gaps, exact = [], 0
+    for t in range(tokens.shape[1]):
+        logits = O.lm_logits(sd, hidden[:, -1:, :])[0, -1].float()
+        top, tok = int(logits.argmax()), int(tokens[0, t])
+        exact += top == tok
+        gaps.append(round(abs(logits[top].item() - logits[tok].item()) / _bf16_ulp(logits[top].item()), 1))
+        m = torch.cat([m, torch.ones((B, 1), dtype=m.dtype)], dim=1)
+        emb_t = torch.nn.functional.embedding(tokens[:, t:t + 1], sd["language_model.model.tok_embeddings.weight"])
+        hidden, past, _ = O.llm_forward(sd, cfg, emb_t, m.bool(), (m.cumsum(-1) - 1)[:, -1:], past)
+    return exact, gaps
+
+
+def test_decode_at_8b_widths_bf16_and_fp8_modes():
+    """generate() at the 8B WIDTHS (hidden 4096, intermediate 14336; three decoder layers), where the decode step runs its
+    width-specific forms - the GEMVs that apply the RMSNorm themselves, the sub-slab forms (csrc/head.hip), and in fp8 mode the
+    e4m3 GEMVs that also quantise the token rows (csrc/head8.hip); the tiny configurations of the other decode tests take the generic
+    forms.  Checked against the oracle's KV-cache path teacher-forced on the HIP tokens - oracle.py for bf16, oracle/fp8.py's
+    arithmetic for fp8: every generated token is the oracle's argmax at that step or a near-tie of the oracle's own logits
+    (random weights give near-uniform vocabulary logits; in fp8 an e4m3 code can flip on a one-ulp activation difference)."""
     from oracle import fp8 as O8
     cfg = pkg.internvl2_8b()
     cfg.vision_config.num_hidden_layers = 1
@@ -594,27 +614,18 @@ def test_fp8_mode_decode_streams_e4m3_weights_at_8b_widths():
     got_bf16 = model.generate(pixel_values=pv, input_ids=ids, attention_mask=mask, max_new_tokens=n_new, do_sample=False).cpu()
     model.set_precision("fp8")
     try:
-        got = model.generate(pixel_values=pv, input_ids=ids, attention_mask=mask, max_new_tokens=n_new, do_sample=False).cpu()
+        got_fp8 = model.generate(pixel_values=pv, input_ids=ids, attention_mask=mask, max_new_tokens=n_new, do_sample=False).cpu()
     finally:
         model.set_precision("bf16")
-    assert got.shape == (B, n_new)
+    assert got_bf16.shape == (B, n_new) and got_fp8.shape == (B, n_new)
     emb = O.scatter_embeds(sd, ids, ctx, O.extract_feature(sd, cfg, pv), None)
-    pos = (mask.cumsum(-1) - 1)
-    gaps, exact = [], 0
+    exact16, gaps16 = _teacher_forced_gaps(sd, cfg, emb, mask, got_bf16)
     with O8.fp8_llm(cfg.llm_config.num_hidden_layers):
-        hidden, past, _ = O.llm_forward(sd, cfg, emb, mask.bool(), pos)
-        m = mask.clone()
-        for t in range(n_new):
-            logits = O.lm_logits(sd, hidden[:, -1:, :])[0, -1].float()
-            top, tok = int(logits.argmax()), int(got[0, t])
-            exact += top == tok
-            gaps.append(round(abs(logits[top].item() - logits[tok].item()) / _bf16_ulp(logits[top].item()), 1))
-            m = torch.cat([m, torch.ones((B, 1), dtype=m.dtype)], dim=1)
-            emb_t = torch.nn.functional.embedding(got[:, t:t + 1], sd["language_model.model.tok_embeddings.weight"])
-            hidden, past, _ = O.llm_forward(sd, cfg, emb_t, m.bool(), (m.cumsum(-1) - 1)[:, -1:], past)
-    print(f"fp8 decode at 8B widths: tokens {got.tolist()} (bf16 mode: {got_bf16.tolist()}); oracle gap of each HIP token in bf16 ulps {gaps}; exact {exact}/{n_new}")
-    assert all(x <= 8 for x in gaps), gaps
-    assert exact >= n_new // 2
+        exact8, gaps8 = _teacher_forced_gaps(sd, cfg, emb, mask, got_fp8)
+    print(f"decode at 8B widths: bf16 tokens {got_bf16.tolist()} oracle gaps (bf16 ulps) {gaps16} exact {exact16}/{n_new}; "
+          f"fp8 tokens {got_fp8.tolist()} gaps {gaps8} exact {exact8}/{n_new}")
+    assert all(x <= 2 for x in gaps16) and exact16 >= n_new - 2, gaps16
+    assert all(x <= 8 for x in gaps8) and exact8 >= n_new // 2, gaps8
 
 
 # ---------------------------------------------------------------------------------------------------------
