@@ -578,17 +578,19 @@ def _teacher_forced_gaps(sd, cfg, emb, mask, tokens):
     m = mask.clone()
     gaps, exact = [], 0
     for t in range(tokens.shape[1]):
-        logits = O.lm_logits(sd, hidden[:, -1:, :])[0, -1].float()
-        top, tok = int(logits.argmax()), int(tokens[0, t])
-        exact += top == tok
-        gaps.append(round(abs(logits[top].item() - logits[tok].item()) / _bf16_ulp(logits[top].item()), 1))
+        for b in range(B):
+            logits = O.lm_logits(sd, hidden[b:b + 1, -1:, :])[0, -1].float()
+            top, tok = int(logits.argmax()), int(tokens[b, t])
+            exact += top == tok
+            gaps.append(round(abs(logits[top].item() - logits[tok].item()) / _bf16_ulp(logits[top].item()), 1))
         m = torch.cat([m, torch.ones((B, 1), dtype=m.dtype)], dim=1)
         emb_t = torch.nn.functional.embedding(tokens[:, t:t + 1], sd["language_model.model.tok_embeddings.weight"])
         hidden, past, _ = O.llm_forward(sd, cfg, emb_t, m.bool(), (m.cumsum(-1) - 1)[:, -1:], past)
     return exact, gaps
 
 
-def test_decode_at_8b_widths_bf16_and_fp8_modes():
+@pytest.mark.parametrize("B", [1, 3])
+def test_decode_at_8b_widths_bf16_and_fp8_modes(B):
     """generate() at the 8B WIDTHS (hidden 4096, intermediate 14336; three decoder layers), where the decode step runs its
     width-specific forms - the GEMVs that apply the RMSNorm themselves, the sub-slab forms (csrc/head.hip), and in fp8 mode the
     e4m3 GEMVs that also quantise the token rows (csrc/head8.hip); the tiny configurations of the other decode tests take the generic
@@ -600,13 +602,14 @@ def test_decode_at_8b_widths_bf16_and_fp8_modes():
     cfg.vision_config.num_hidden_layers = 1
     cfg.llm_config.num_hidden_layers = 3
     cfg.llm_config.vocab_size = 4096
-    B, T, seed, n_new = 1, 8, 16, 6
+    T, seed, n_new = 8, 16, 6 if B == 1 else 4
     sd = synth.make_state_dict(cfg, seed=seed, rich=True)
     toks = synth.canonical_tokens(cfg, B, T, seed=seed)
     n_prompt = int((toks["labels"][0] == -100).sum())
     ids = toks["input_ids"][:, :n_prompt].clone()
     ctx = toks["img_context_token_id"]
-    ids[0, (ids[0] == ctx).nonzero()[-1]] = 7          # generate() prompts carry no motion slot
+    for b in range(B):
+        ids[b, (ids[b] == ctx).nonzero()[-1]] = 7      # generate() prompts carry no motion slot
     pv = synth.synthetic_frames(B * T, 448, seed=seed)
     model = make_model(cfg, sd)
     model.img_context_token_id = ctx
@@ -622,10 +625,10 @@ def test_decode_at_8b_widths_bf16_and_fp8_modes():
     exact16, gaps16 = _teacher_forced_gaps(sd, cfg, emb, mask, got_bf16)
     with O8.fp8_llm(cfg.llm_config.num_hidden_layers):
         exact8, gaps8 = _teacher_forced_gaps(sd, cfg, emb, mask, got_fp8)
-    print(f"decode at 8B widths: bf16 tokens {got_bf16.tolist()} oracle gaps (bf16 ulps) {gaps16} exact {exact16}/{n_new}; "
-          f"fp8 tokens {got_fp8.tolist()} gaps {gaps8} exact {exact8}/{n_new}")
-    assert all(x <= 2 for x in gaps16) and exact16 >= n_new - 2, gaps16
-    assert all(x <= 8 for x in gaps8) and exact8 >= n_new // 2, gaps8
+    print(f"decode at 8B widths: bf16 tokens {got_bf16.tolist()} oracle gaps (bf16 ulps) {gaps16} exact {exact16}/{B * n_new}; "
+          f"fp8 tokens {got_fp8.tolist()} gaps {gaps8} exact {exact8}/{B * n_new}")
+    assert all(x <= 2 for x in gaps16) and exact16 >= B * n_new - 2 * B, gaps16
+    assert all(x <= 8 for x in gaps8) and exact8 >= B * n_new // 2, gaps8
 
 
 # ---------------------------------------------------------------------------------------------------------
