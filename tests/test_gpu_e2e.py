@@ -391,6 +391,32 @@ def test_greedy_generate_matches_oracle_cache_path():
     assert torch.equal(got2.cpu(), want)
 
 
+@pytest.mark.parametrize("B,T", [(6, 1), (20, 1)])
+def test_greedy_generate_with_many_sequences(B, T):
+    """Decode steps with more sequences than the small-batch forms take (<= 4: fused-norm / 4-row forms, <= 8: 8-row forms, <= 16: one
+    row tile, above: several row tiles per GEMV) - positions, KV slots and the split-KV attention per sequence - against the oracle."""
+    cfg = pkg.tiny(image_size=224)
+    seed = 12
+    sd = synth.make_state_dict(cfg, seed=seed, rich=True)
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    ids = toks["input_ids"][:, :n_prompt].clone()
+    ctx = toks["img_context_token_id"]
+    for b in range(B):
+        ids[b, (ids[b] == ctx).nonzero()[-1]] = 7
+    pv = synth.synthetic_frames(B * T, 224, seed=seed)
+    emb = O.scatter_embeds(sd, ids, ctx, O.extract_feature(sd, cfg, pv), None)
+    want = O.greedy_generate(sd, cfg, emb, torch.ones_like(ids), max_new_tokens=5)
+    model = make_model(cfg, sd)
+    model.img_context_token_id = ctx
+    got = model.generate(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=5, do_sample=False).cpu()
+    same = (got == want).all(dim=1)
+    print(f"B={B}: {int(same.sum())}/{B} sequences token-identical to the oracle")
+    # a sequence may leave the oracle's path at a near-tie of the logits (bf16 noise of different summation orders); most must not
+    assert int(same.sum()) >= B - max(1, B // 5), (got.tolist(), want.tolist())
+    assert torch.equal(got[:, 0], want[:, 0]) or int((got[:, 0] != want[:, 0]).sum()) <= 1
+
+
 def test_against_reference_golden_vectors(golden_dir):
     """The fixtures were produced by the imported REFERENCE (tests/golden/make_golden.py), not by the oracle."""
     e2e = torch.load(os.path.join(golden_dir, "e2e.pt"), weights_only=False)
