@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const bf16_t* __restri
 
   // DEPTH k-steps (DEPTH x 16 B per lane per operand) are loaded before their MFMAs so several loads are in flight; a decode
   // GEMV (one x row tile, few workgroups per CU when N is small) needs the deeper form to cover the HBM latency
-  constexpr int DEPTH = RT == 1 ? (NS == 1 ? 16 : SKINNY_DEPTH2) : 4;
+  constexpr int DEPTH = RT == 1 ? (NS == 1 ? 16 : SKINNY_DEPTH2) : (RT == 2 && NS == 1) ? 8 : 4;   // (two row tiles: InternViT's 32 leftover rows per pass)
   int k = 0;
   const int xs_off = min(sr, R - 1) * K + kbeg + fq * 8;          // NORM: this lane's fragment origin in xs
   if constexpr (NORM) {
