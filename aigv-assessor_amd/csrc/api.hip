@@ -493,6 +493,7 @@ int need(aigv_ctx* c, const std::string& name, size_t elems, const bf16_t** out)
 }  // namespace
 
 extern int g_gemm256_variant;
+extern int g_gemm256_order;
 extern int g_attn_waves;
 
 void aigv_set_error(const char* msg) { g_err = msg ? msg : ""; }
@@ -1669,6 +1670,12 @@ int aigv_tune_attention(int waves) {
 int aigv_tune_gemm(int mode, double rate256) {
   // mode = kernel choice (0 auto, 1 128-tile, 2 256-tile) + 16 * (256-kernel schedule variant 0..3, experiments)
   // mode bits 4..6: 0 = keep the default schedule, 1 + v = select 256-kernel schedule variant v (0..3)
+  // bits 10..13: tile order of the 256 kernel for every shape (default 0: by weight size, gemm256.hip): 1 = row groups, 1 + g = groups of g column tiles
+  {
+    const int f = (mode >> 10) & 15;
+    g_gemm256_order = f == 0 ? -1 : f - 1;
+  }
+  mode &= 1023;
   const int vsel = mode >> 4;
   mode &= 15;
   if (mode < 0 || mode > 2 || vsel < 0 || vsel > 4)

@@ -28,6 +28,7 @@
 //   WAR  unit X of tile t is last read in LOAD(4t+{0,0,1,2}) for {V0,V2,V3,V1}; its refill for tile t+2 is issued in
 //        LOAD(4t+{2,3,4,5}) - at least 3 intervals after the last reader's interval, whose ds_reads completed
 //        (lgkmcnt(0)) right after the barrier that ended it.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -42,6 +43,9 @@ constexpr int STAGE_ROWP = 144;            // residual epilogue: 16 staged rows 
 constexpr int STAGE_BYTES = 16 * STAGE_ROWP;
 constexpr int LDS_BYTES = 2 * BUF + 8 * STAGE_BYTES;   // 128 KB ring + 18 KB
 constexpr int GROUP_M256 = 4;
+}
+int g_gemm256_order = -1;   // tile order of the plain launches (GemmArgs::order): -1 = by weight size; 0 = row groups, g > 0 = groups of g column tiles (aigv_tune_gemm bits 10..13)
+namespace {
 
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
@@ -77,11 +81,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int per_group = GROUP_M256 * nbn;
-  const int grp = wg / per_group, first_m = grp * GROUP_M256;
-  const int gsz = min(nbm - first_m, GROUP_M256);
-  const int in_g = wg - grp * per_group;
-  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  int tm, tn;
+  if (p.order == 0) {
+    const int per_group = GROUP_M256 * nbn;
+    const int grp = wg / per_group, first_m = grp * GROUP_M256;
+    const int gsz = min(nbm - first_m, GROUP_M256);
+    const int in_g = wg - grp * per_group;
+    tm = first_m + in_g % gsz; tn = in_g / gsz;
+  } else {
+    const int gn = p.order;                     // column tiles per group
+    const int per_group = gn * nbm;
+    const int grp = wg / per_group, first_n = grp * gn;
+    const int gsz = min(nbn - first_n, gn);
+    const int in_g = wg - grp * per_group;
+    tn = first_n + in_g % gsz; tm = in_g / gsz;
+  }
   const int m0 = tm * TM, n0 = tn * TN;
 
   // ---- LDS-DMA source pointers: this wave fills unit rows 16*wave .. 16*wave+15 (two 8-row wave-instructions) ----
@@ -571,7 +585,15 @@ hipError_t launch256(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
-  hipLaunchKernelGGL((gemm256_kernel<EPI, VAR>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, a);
+  GemmArgs b = a;
+  // Tile order.  The XCD-aware remap hands each XCD a contiguous run of tiles; WHICH operand an XCD then owns decides what is fetched
+  // eight times over.  Row groups (order 0): an XCD owns 4 row tiles and sweeps all of W - right when W is small (InternViT: 2-8 MB).
+  // Column groups (order g): an XCD owns a slice of W and sweeps the rows - each weight byte is wanted by one XCD only, a few times in
+  // quick succession, and the operand all XCDs share is A, which the Infinity Cache holds; for the large InternLM2 matrices (w1|w3
+  // 235 MB, w2 117 MB): w2 718 -> 694 us, w1|w3 1398 -> 1380 us isolated, 101.5-101.9 -> 100.4 ms of GEMM time per step
+  // (profiles/r2_gemm_tile_order.txt; the L2<->fabric byte count is the same either way - what changes is how much of it reaches HBM).
+  b.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)a.N * (size_t)a.K >= ((size_t)32 << 20) ? 4 : 0);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, VAR>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, b);
   return hipGetLastError();
 }
 
@@ -606,7 +628,9 @@ hipError_t launch256_fp8(const GemmArgs& b, hipStream_t s) {
     attr_set = true;
   }
   const int nbm = (b.M + TM - 1) / TM, nbn = b.N / TN;
-  hipLaunchKernelGGL((gemm256_kernel<EPI, 7, true>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, b);
+  GemmArgs c = b;   // same tile-order rule as the bf16 launches (b.K counts byte pairs here: N x K x 2 = the weight bytes)
+  c.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)b.N * (size_t)b.K * 2 >= ((size_t)64 << 20) ? 4 : 0);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, 7, true>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, c);
   return hipGetLastError();
 }
 

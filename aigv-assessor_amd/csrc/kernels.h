@@ -33,6 +33,7 @@ struct GemmArgs {
   // same 128-byte K-tiles), C = bf16(acc * row_scale[m] * col_scale[n] + bias)
   const float* row_scale;
   const float* col_scale;
+  int order;                    // gemm256 tile order: 0 = groups of 4 ROW tiles sweep the column tiles (an XCD owns rows), g > 0 = groups of g COLUMN tiles sweep the rows (an XCD owns a slice of W)
 };
 
 const char* aigv_gemm_check(const GemmArgs& a, int epi);   // nullptr if the shapes fit the kernel
