@@ -387,6 +387,7 @@ def main():
         }
         if prof:
             p = model.prof_read()
+            model.prof_enable(False)     # the decode measurement below must not carry the per-launch events
             gm = p["gemm"]
             if gm["launches"]:
                 ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
