@@ -592,7 +592,8 @@ hipError_t launch256(const GemmArgs& a, hipStream_t s) {
   // quick succession, and the operand all XCDs share is A, which the Infinity Cache holds; for the large InternLM2 matrices (w1|w3
   // 235 MB, w2 117 MB): w2 718 -> 694 us, w1|w3 1398 -> 1380 us isolated, 101.5-101.9 -> 100.4 ms of GEMM time per step
   // (profiles/r2_gemm_tile_order.txt; the L2<->fabric byte count is the same either way - what changes is how much of it reaches HBM).
-  b.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)a.N * (size_t)a.K >= ((size_t)32 << 20) ? 4 : 0);
+  // (measured at M = 8704; with M = 4281 - one 16-frame clip at the 26B widths - the row order was 0.3 % ahead, so short problems keep it)
+  b.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)a.N * (size_t)a.K >= ((size_t)32 << 20) && a.M >= 8192 ? 4 : 0);
   hipLaunchKernelGGL((gemm256_kernel<EPI, VAR>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, b);
   return hipGetLastError();
 }
@@ -629,7 +630,7 @@ hipError_t launch256_fp8(const GemmArgs& b, hipStream_t s) {
   }
   const int nbm = (b.M + TM - 1) / TM, nbn = b.N / TN;
   GemmArgs c = b;   // same tile-order rule as the bf16 launches (b.K counts byte pairs here: N x K x 2 = the weight bytes)
-  c.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)b.N * (size_t)b.K * 2 >= ((size_t)64 << 20) ? 4 : 0);
+  c.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)b.N * (size_t)b.K * 2 >= ((size_t)64 << 20) && b.M >= 8192 ? 4 : 0);
   hipLaunchKernelGGL((gemm256_kernel<EPI, 7, true>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, c);
   return hipGetLastError();
 }
