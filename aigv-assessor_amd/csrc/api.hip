@@ -75,6 +75,7 @@ struct aigv_ctx {
   int32_t* l_neg1 = nullptr;   // max_tokens x int32 -1: the "plain text token" slot map of aigv_llm_extend
   // fp8 mode of the InternLM2 prefill GEMMs (aigv_set_precision): weights quantised once, activations per row on the fly
   bool fp8_llm = false;
+  bool llm_lin_dirty = false;  // an InternLM2 linear (wqkv / wo / w1 / w3 / w2) was (re)loaded since the e4m3 copies were made
   std::vector<LlmLayerFp8> llm8;
   uint8_t* q8 = nullptr;       // [max_tokens, max(H, I)] e4m3 activations of the GEMM about to run
   float* q8_scale = nullptr;   // [max_tokens]
@@ -93,6 +94,7 @@ struct aigv_ctx {
   bool kv_valid = false;
   // profiling
   bool prof = false;
+  int gemm_cls = AIGV_PROF_GEMM;   // class the GEMM launches are booked under: AIGV_PROF_GEMM_VIT inside aigv_vit_forward / aigv_project
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> ev_pool;
 };
@@ -178,6 +180,13 @@ struct ProfScope {
     hipEventRecord(r.b, s);
     c->recs.push_back(r);
   }
+};
+
+struct GemmClassScope {   // GEMM launches inside the scope are booked under `cls` (per-class roofline entries of bench.py)
+  aigv_ctx* c;
+  int keep;
+  GemmClassScope(aigv_ctx* c_, int cls) : c(c_), keep(c_->gemm_cls) { c->gemm_cls = cls; }
+  ~GemmClassScope() { c->gemm_cls = keep; }
 };
 
 // ---- GEMM dispatch: split the rows over the tile kernels by a wave-quantisation cost model -----------------------
@@ -273,7 +282,7 @@ double t_skinny(int rows, int N, int K) {
   return (double)N * K * 2.0 / 4.5e6 + 4.0;
 }
 
-#define GEMM_PROF(c, a, s) ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * (a).M * (double)(a).N * (a).K, \
+#define GEMM_PROF(c, a, s) ProfScope ps(c, (c) ? (c)->gemm_cls : AIGV_PROF_GEMM, 2.0 * (a).M * (double)(a).N * (a).K, \
                                        2.0 * ((double)(a).M * (a).K + (double)(a).N * (a).K + (double)(a).M * (a).N), s)
 
 int launch_one(aigv_ctx* c, const GemmArgs& a, int epi, bool use256, hipStream_t s) {
@@ -374,9 +383,12 @@ GemmArgs col_slice(const GemmArgs& a, int n0, int n) {
   return b;
 }
 
+// GEMM tile choice in force for a call: the context's own setting (aigv_set_gemm_mode), else the process default (aigv_tune_gemm)
+int resolved_gemm_mode(const aigv_ctx* c) { return (c && c->gemm_mode >= 0) ? c->gemm_mode : g_gemm_mode; }
+
 int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
-  const int mode = (c && c->gemm_mode >= 0) ? c->gemm_mode : g_gemm_mode;
+  const int mode = resolved_gemm_mode(c);
   if (const int right = split_columns(a.M, a.N, a.K, epi, mode)) {
     TRY(run_gemm(c, col_slice(a, 0, a.N - right), epi, s));
     return launch_one(c, col_slice(a, a.N - right, right), epi, false, s);
@@ -396,7 +408,7 @@ int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
     const GemmArgs bot = row_slice(a, row, a.M - row);
     if (pl.last_kind == 1) {
       const int sk = skinny_epi(epi);
-      ProfScope ps(c, AIGV_PROF_GEMM, 2.0 * bot.M * (double)a.N * a.K, 2.0 * (double)a.N * a.K, s);
+      ProfScope ps(c, c ? c->gemm_cls : AIGV_PROF_GEMM, 2.0 * bot.M * (double)a.N * a.K, 2.0 * (double)a.N * a.K, s);
       hipError_t e = aigv_launch_skinny_gemm(bot.A, bot.lda, bot.M, bot.W, bot.ldw, bot.N, bot.K, bot.bias, bot.resid, bot.ldr,
                                             bot.C, bot.ldc, sk, s, bot.ls);
       if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "skinny remainder (M=%d N=%d K=%d): %s", bot.M, bot.N, bot.K, hipGetErrorString(e));
@@ -474,7 +486,9 @@ int g_skinny_p = 0;   // aigv_tune_skinny: sub-slab form forced on the op-level 
 int run_skinny(aigv_ctx* c, const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
                const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi, hipStream_t s, int p = 1) {
   ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * R * (double)N * K, 2.0 * (double)N * K, s);
-  if (c && c->gemm_mode == 1 && p == 1) p = 0;   // one fixed plan per shape: the K split of a skinny GEMM must not depend on the row count either
+  // mode 1 (batch-invariant bits): one fixed plan per shape - the K split of a skinny GEMM must not depend on the row count either.
+  // The mode is resolved exactly as run_gemm resolves it (context setting, else the process default of aigv_tune_gemm).
+  if (resolved_gemm_mode(c) == 1 && p == 1) p = 0;
   hipError_t e = aigv_launch_skinny_gemm(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, epi, s, nullptr, p);
   if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP,
                                    "skinny gemm (R=%d N=%d K=%d epi=%d): %s", R, N, K, epi, hipGetErrorString(e));
@@ -735,6 +749,7 @@ int aigv_load_weight(aigv_ctx* c, const char* name, const void* data, const int6
     HIPCHK(c, hipMemcpy2D(dst, 2 * blk, src, blk, blk, k.llm_inter / 16, src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     c->w[key + "#seen"] = DevBuf{};  // marker (no storage)
     c->finalized = false;
+    c->llm_lin_dirty = true;
     return 0;
   }
 
@@ -753,13 +768,20 @@ int aigv_load_weight(aigv_ctx* c, const char* name, const void* data, const int6
   }
   HIPCHK(c, hipMemcpy(it->second.p, src, n * 2, src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   c->finalized = false;
+  if (key.find("language_model.model.layers.") == 0 &&
+      (key.find(".attention.wqkv.weight") != std::string::npos || key.find(".attention.wo.weight") != std::string::npos ||
+       key.find(".feed_forward.w2.weight") != std::string::npos))
+    c->llm_lin_dirty = true;
   return 0;
 }
 
 int aigv_finalize_weights(aigv_ctx* c) {
   if (!c) return fail(c, AIGV_ERR_ARG, "null ctx");
   HIPCHK(c, hipSetDevice(c->device));
-  if (!c->llm8.empty()) {   // weights were (re)loaded: the e4m3 copies are stale - drop them; aigv_set_precision quantises again
+  // The e4m3 copies follow the bf16 InternLM2 linears: they are dropped (and the context returns to bf16) only when one of those was
+  // reloaded since they were made.  Any other reload - rotary tables after a capacity change, a new score head - keeps them and the mode.
+  const bool keep_fp8 = !c->llm8.empty() && !c->llm_lin_dirty && c->q8 != nullptr;
+  if (!c->llm8.empty() && !keep_fp8) {   // weights were (re)loaded: the e4m3 copies are stale - drop them; aigv_set_precision quantises again
     HIPCHK(c, hipDeviceSynchronize());
     auto drop = [&](void* p) {
       if (!p) return;
@@ -772,7 +794,8 @@ int aigv_finalize_weights(aigv_ctx* c) {
     c->q8 = nullptr; c->q8_scale = nullptr;
     c->llm8.clear();
   }
-  c->fp8_llm = false;
+  if (!keep_fp8) c->fp8_llm = false;
+  c->llm_lin_dirty = false;
   const aigv_config& k = c->cfg;
   const size_t Hv = k.vit_hidden, Iv = k.vit_inter, H = k.llm_hidden, I = k.llm_inter;
   const std::string e = "vision_model.embeddings.";
@@ -872,6 +895,7 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
   if (n_frames <= 0 || n_frames > k.max_frames) return fail(c, AIGV_ERR_ARG, "n_frames %d outside 1..%d", n_frames, k.max_frames);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
+  GemmClassScope gcls(c, AIGV_PROF_GEMM_VIT);
   const int Hv = k.vit_hidden, Iv = k.vit_inter;
   int n_layers = k.vit_layers;
   if (k.select_layer != -1) n_layers = k.select_layer < 0 ? k.vit_layers + 1 + k.select_layer : k.select_layer;
@@ -945,6 +969,7 @@ int aigv_project(aigv_ctx* c, const void* tokens, int rows, void* out, void* str
   hipStream_t s = (hipStream_t)stream;
   const aigv_config& k = c->cfg;
   const int H = k.llm_hidden, Pin = c->proj_in;
+  GemmClassScope gcls(c, AIGV_PROF_GEMM_VIT);
   const int chunk = k.vit_chunk * c->ntok;
   for (int r0 = 0; r0 < rows; r0 += chunk) {
     const int R = std::min(chunk, rows - r0);
@@ -1355,6 +1380,10 @@ static int pick_form(int max_p, int K) {
 static void decode_forms(aigv_ctx* c, int B, int* pq, int* po, int* p13, int* p2) {
   const aigv_config& k = c->cfg;
   const int max_p = B <= 4 ? 4 : B <= 8 ? 2 : 1;
+  if (resolved_gemm_mode(c) == 1) {   // batch-invariant bits: ONE form whatever the batch (p = 1 here; run_skinny then pins the K split too)
+    *pq = *po = *p13 = *p2 = 1;
+    return;
+  }
   *pq = *po = *p13 = pick_form(max_p, k.llm_hidden);
   *p2 = pick_form(max_p, k.llm_inter);
   if (g_skinny_p) *pq = *po = *p13 = *p2 = std::min(g_skinny_p, max_p);
@@ -1481,6 +1510,29 @@ int aigv_out_row_logits(aigv_ctx* c, int first_row, int n_rows, void* logits_bf1
                                               (bf16_t*)logits_bf16 + (size_t)r0 * ldo, ldo, s);
     if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "lm-head logits (rows=%d ldo=%d): %s", rr, ldo, hipGetErrorString(e));
   }
+  return 0;
+}
+
+int aigv_out_row_hidden(aigv_ctx* c, int first_row, int n_rows, void* hidden_bf16, int ldo, void* stream) {
+  if (!c || !hidden_bf16) return fail(c, AIGV_ERR_ARG, "aigv_out_row_hidden: null argument");
+  if (!c->finalized) return fail(c, AIGV_ERR_STATE, "aigv_out_row_hidden: call aigv_finalize_weights first");
+  const aigv_config& k = c->cfg;
+  const int cap = k.max_out_rows + k.max_seqs + 64;
+  if (first_row < 0 || n_rows <= 0 || first_row + n_rows > cap || ldo < k.llm_hidden)
+    return fail(c, AIGV_ERR_ARG, "aigv_out_row_hidden: rows %d..%d outside 0..%d or ldo %d < %d", first_row, first_row + n_rows - 1, cap - 1, ldo, k.llm_hidden);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy2DAsync(hidden_bf16, (size_t)ldo * sizeof(bf16_t), c->l_rows + (size_t)first_row * k.llm_hidden, (size_t)k.llm_hidden * sizeof(bf16_t),
+                             (size_t)k.llm_hidden * sizeof(bf16_t), n_rows, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int aigv_decode_eos(aigv_ctx* c, int64_t* tokens, int32_t* state, const int64_t* eos_ids, int n_eos, int64_t pad_id, void* stream) {
+  if (!c || !tokens || !state) return fail(c, AIGV_ERR_ARG, "aigv_decode_eos: null argument");
+  if (!c->kv_valid) return fail(c, AIGV_ERR_STATE, "aigv_decode_eos: no KV state (run aigv_llm_prefill with keep_kv)");
+  if (n_eos < 0 || n_eos > 8 || (n_eos > 0 && !eos_ids)) return fail(c, AIGV_ERR_ARG, "aigv_decode_eos: 0..8 end-of-sequence ids");
+  if (c->kv_seqs > 64) return fail(c, AIGV_ERR_ARG, "aigv_decode_eos: at most 64 sequences");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, aigv_launch_decode_eos(tokens, state, c->kv_seqs, eos_ids, n_eos, pad_id, (hipStream_t)stream));
   return 0;
 }
 

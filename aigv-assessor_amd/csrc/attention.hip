@@ -538,12 +538,8 @@ int g_attn_waves = 0;   // 0 = per-shape default; forced for A/B experiments: 4 
 template <int D, bool CAUSAL, int NW, int NB = 2>
 static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
   constexpr int LDS = NB * 2 * KT * (D * 2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<D, CAUSAL, NW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsAttrOnce lds_attr;
+  if (hipError_t e = lds_attr.ensure((const void*)attn_fwd_kernel<D, CAUSAL, NW, NB>, LDS); e != hipSuccess) return e;
   const int nqb = (a.max_len + NW * 32 - 1) / (NW * 32) - a.q_begin / (NW * 32);
   hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, NW, NB>), dim3(nqb * a.n_heads * a.n_seq), dim3(NW * 64), LDS, s, a);
   return hipGetLastError();

@@ -451,12 +451,8 @@ template <int D, bool CAUSAL>
 hipError_t launch64(const AttnArgs& a, hipStream_t s) {
   constexpr int NQW = D == 64 ? 2 : 1, QB = 128 * NQW;
   constexpr int LDS = 5 * KT * (D * 2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd64_kernel<D, CAUSAL, NQW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsAttrOnce lds_attr;
+  if (hipError_t e = lds_attr.ensure((const void*)attn_fwd64_kernel<D, CAUSAL, NQW>, LDS); e != hipSuccess) return e;
   const int rows = a.q_end > 0 ? (a.max_len < a.q_end ? a.max_len : a.q_end) : a.max_len;
   const int nqb = (rows + QB - 1) / QB;
   hipLaunchKernelGGL((attn_fwd64_kernel<D, CAUSAL, NQW>), dim3(nqb * a.n_heads * a.n_seq), dim3(256), LDS, s, a);

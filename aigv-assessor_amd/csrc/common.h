@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef uint16_t bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4;     // 16x16 MFMA accumulator
@@ -138,3 +140,19 @@ __device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, u
       : "memory");
 }
 
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, DEVICE): a process that drives several devices must set it on
+// each of them.  One instance per kernel instantiation (a function-local static); bit d of `done` = set on device d.  Devices >= 64
+// set it on every launch.  Thread-safe: a concurrent first launch sets the attribute twice, which is harmless.
+struct LdsAttrOnce {
+  std::atomic<unsigned long long> done{0};
+  hipError_t ensure(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    return e;
+  }
+};

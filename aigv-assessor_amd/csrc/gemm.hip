@@ -188,13 +188,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
 
 template <int EPI>
 hipError_t launch(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsAttrOnce lds_attr;
+  if (hipError_t e = lds_attr.ensure((const void*)gemm_bf16_kernel<EPI>, 2 * STAGE_BYTES); e != hipSuccess) return e;
   const int nbm = (a.M + BM - 1) / BM, nbn = a.N / BN;
   hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nbm * nbn), dim3(256), 2 * STAGE_BYTES, s, a);
   return hipGetLastError();
@@ -319,13 +314,8 @@ hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, flo
     }
     return hipGetLastError();
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * STAGE_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsAttrOnce lds_attr;
+  if (hipError_t e = lds_attr.ensure((const void*)gemm_bf16_kernel<EPI_PARTIAL>, 2 * STAGE_BYTES); e != hipSuccess) return e;
   GemmArgs b = a;
   b.part = ws;
   b.k_slices = k_slices;

@@ -578,12 +578,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 
 template <int EPI, int VAR>
 hipError_t launch256(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsAttrOnce lds_attr;
+  if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI, VAR>, LDS_BYTES); e != hipSuccess) return e;
   const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
   GemmArgs b = a;
   // Tile order.  The XCD-aware remap hands each XCD a contiguous run of tiles; WHICH operand an XCD then owns decides what is fetched
@@ -622,12 +618,8 @@ bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % T
 // fp8: a.K / a.lda / a.ldw arrive in e4m3 ELEMENTS; the kernel addresses the same bytes as pairs (its bf16_t unit)
 template <int EPI>
 hipError_t launch256_fp8(const GemmArgs& b, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsAttrOnce lds_attr;
+  if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI, 7, true>, LDS_BYTES); e != hipSuccess) return e;
   const int nbm = (b.M + TM - 1) / TM, nbn = b.N / TN;
   GemmArgs c = b;   // same tile-order rule as the bf16 launches (b.K counts byte pairs here: N x K x 2 = the weight bytes)
   c.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)b.N * (size_t)b.K * 2 >= ((size_t)64 << 20) && b.M >= 8192 ? 4 : 0);
@@ -658,12 +650,8 @@ hipError_t aigv_launch_gemm256_fp8_partial(const GemmArgs& a, hipStream_t s) {
   if (a.M < 1 || a.N % TN || a.K % 128 || (a.lda % 16) || (a.ldw % 16) || !a.row_scale || !a.col_scale || !a.A || !a.W || !a.part || a.k_slices < 1 ||
       (a.K / 128) % a.k_slices)
     return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_PARTIAL, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsAttrOnce lds_attr;
+  if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI_PARTIAL, 7, true>, LDS_BYTES); e != hipSuccess) return e;
   GemmArgs b = a;
   b.K = a.K / 2; b.lda = a.lda / 2; b.ldw = a.ldw / 2;
   const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
@@ -673,12 +661,8 @@ hipError_t aigv_launch_gemm256_fp8_partial(const GemmArgs& a, hipStream_t s) {
 
 hipError_t aigv_launch_gemm256_partial(const GemmArgs& a, hipStream_t s) {
   if (!aigv_gemm256_supported(a) || a.k_slices < 1 || (a.K / TK) % a.k_slices || !a.part) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI_PARTIAL, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsAttrOnce lds_attr;
+  if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI_PARTIAL, 7>, LDS_BYTES); e != hipSuccess) return e;
   const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
   hipLaunchKernelGGL((gemm256_kernel<EPI_PARTIAL, 7>), dim3(nbm * nbn, a.k_slices), dim3(512), LDS_BYTES, s, a);
   return hipGetLastError();

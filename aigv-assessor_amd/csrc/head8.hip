@@ -237,12 +237,8 @@ hipError_t launch8p(int p, int blocks, size_t lds, hipStream_t s, const bf16_t* 
   // the quantised rows of a long-K GEMV (4 x 16384 bytes) exceed the default dynamic-LDS limit
 #define GO(PP)                                                                                                                                        \
   do {                                                                                                                                                \
-    static bool attr_set = false;                                                                                                                     \
-    if (!attr_set) {                                                                                                                                  \
-      hipError_t e = hipFuncSetAttribute((const void*)skinny8_kernel<EPI, NORM, NCH, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);     \
-      if (e != hipSuccess) return e;                                                                                                                  \
-      attr_set = true;                                                                                                                                \
-    }                                                                                                                                                 \
+    static LdsAttrOnce lds_attr;                                                                                                                     \
+    if (hipError_t e = lds_attr.ensure((const void*)skinny8_kernel<EPI, NORM, NCH, PP>, 4 * 16384); e != hipSuccess) return e; \
     hipLaunchKernelGGL((skinny8_kernel<EPI, NORM, NCH, PP>), dim3(blocks), dim3(256), lds, s, x, ldx, R, W8, ldw, w_scale, N, K, resid, ldr, out, ldo, \
                        rk, norm_w, eps);                                                                                                              \
   } while (0)

@@ -178,6 +178,7 @@ hipError_t aigv_launch_frame_resize_ingest(const uint8_t* hwc, int n_frames, int
 void aigv_set_error(const char* msg);
 // a[i] += 1, b[i] += 1 for i < n (decode bookkeeping kept on the device: positions and visible KV lengths)
 hipError_t aigv_launch_advance(int32_t* a, int32_t* b, int n, hipStream_t s);
+hipError_t aigv_launch_decode_eos(int64_t* tok, int32_t* state, int n, const int64_t* eos_host, int n_eos, int64_t pad, hipStream_t s);
 // small host int arrays passed by value as kernel arguments (no memcpy, no implicit host/stream sync)
 #define AIGV_SMALL_INTS 256
 struct SmallInts { int32_t v[AIGV_SMALL_INTS]; };

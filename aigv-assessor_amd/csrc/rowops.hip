@@ -376,6 +376,27 @@ __global__ void advance_kernel(int32_t* a, int32_t* b, int n) {
   if (i < n) { a[i] += 1; b[i] += 1; }
 }
 
+// End-of-sequence bookkeeping of a greedy / sampling loop, on the device (HF's loop: next = next * unfinished + pad * (1 - unfinished);
+// unfinished &= next not in eos; stop when no sequence is unfinished): tok[b] in: the step's raw token, out: the token the loop
+// emits; state[b] = 1 once sequence b has emitted an end token; state[n] counts the emitted columns that still held a live sequence
+// (= the length HF's loop returns).  One wave (n <= 64).
+struct EosIds { long long v[8]; int n; };
+__global__ __launch_bounds__(64) void decode_eos_kernel(long long* __restrict__ tok, int32_t* __restrict__ state, int n, const EosIds eos,
+                                                        long long pad) {
+  const int i = threadIdx.x;
+  const bool in = i < n;
+  const int was_done = in ? state[i] : 1;
+  const bool live = __any(in && !was_done);
+  if (in) {
+    const long long t = was_done ? pad : tok[i];
+    bool hit = false;
+    for (int k = 0; k < eos.n; ++k) hit |= (t == eos.v[k]);
+    tok[i] = t;
+    state[i] = was_done | (int)hit;
+  }
+  if (i == 0 && live) state[n] += 1;
+}
+
 }  // namespace
 
 hipError_t aigv_launch_seqpos(const int32_t* cu_host, int n_seq, int32_t* pos, int32_t* seq, int32_t* cu_dev, int tokens,
@@ -397,6 +418,15 @@ hipError_t aigv_launch_write_ints(const int32_t* host, int n, int32_t* dst, hipS
     for (int i = 0; i < m; ++i) a.v[i] = host[off + i];
     hipLaunchKernelGGL(write_ints_kernel, dim3(1), dim3(AIGV_SMALL_INTS), 0, s, a, m, dst + off);
   }
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_decode_eos(int64_t* tok, int32_t* state, int n, const int64_t* eos_host, int n_eos, int64_t pad, hipStream_t s) {
+  if (n <= 0 || n > 64 || n_eos < 0 || n_eos > 8 || !tok || !state || (n_eos > 0 && !eos_host)) return hipErrorInvalidValue;
+  EosIds e{};
+  e.n = n_eos;
+  for (int k = 0; k < n_eos; ++k) e.v[k] = (long long)eos_host[k];
+  hipLaunchKernelGGL(decode_eos_kernel, dim3(1), dim3(64), 0, s, (long long*)tok, state, n, e, (long long)pad);
   return hipGetLastError();
 }
 

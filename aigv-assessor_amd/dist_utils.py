@@ -26,6 +26,9 @@ import torch
 import torch.distributed as dist
 
 timeout = timedelta(minutes=60)
+# A one-rank group needs no collective.  Set to True to run them anyway (a one-rank RCCL all-gather is a device copy through RCCL's own
+# stream and work handle): how the collective path is exercised on a single MI355X (tests/test_gpu_dist.py, bench.py --force-dp).
+force_single_rank_collectives = False
 
 
 def init_dist(launcher: str, backend: str = "nccl", **kwargs):
@@ -82,7 +85,7 @@ def all_gather_rows_begin(local: torch.Tensor, counts: List[int], group=None):
     function that completes it.  Between the two calls the collective runs on RCCL's own stream: work enqueued on the compute
     stream in the meantime overlaps with it (the completion only makes the compute stream wait, the host does not block)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_single_rank_collectives and dist.is_initialized()):
         return lambda: local
     tail = tuple(local.shape[1:])
     if len(set(counts)) == 1:

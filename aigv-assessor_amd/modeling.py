@@ -22,8 +22,9 @@ Documented deviations from the reference (all outside what its eval scripts exer
     ``slowfast_model.*`` tensors (the reference downloads them from pytorchvideo's hub at construction time,
     which cannot happen offline); otherwise pass ``motion_feature=[B, 2304]`` or set ``slowfast_model`` to a
     callable with the reference's interface.
-  * ``generate`` implements greedy decoding and multinomial sampling (temperature / top-k / top-p, HF's warper order); the
-    reference defers to HF ``generate`` - its eval configs use do_sample=False.  Beam search raises NotImplementedError.
+  * ``generate`` implements greedy decoding and multinomial sampling (temperature / top-k / top-p, HF's warper order) with HF's
+    repetition_penalty / no_repeat_ngram_size processors; the reference defers to HF ``generate`` - its eval configs use
+    do_sample=False.  Beam search raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -382,9 +383,8 @@ class InternVLChatModel(nn.Module):
         for name, t in (("rope.cos", cos), ("rope.sin", sin)):
             shape = (C.c_int64 * t.dim())(*t.shape)
             native.check(lib.aigv_load_weight(ctx, name.encode(), t.data_ptr(), shape, t.dim(), 0, 0), ctx)
-        if not self._dirty:     # tables swapped under finalized weights: re-derive the pointers, keep the precision mode
-            native.check(lib.aigv_finalize_weights(ctx), ctx)
-            native.check(lib.aigv_set_precision(ctx, 1 if getattr(self, "_precision", "bf16") == "fp8" else 0), ctx)
+        if not self._dirty:     # tables swapped under finalized weights: re-derive the pointers.  The library keeps the precision mode
+            native.check(lib.aigv_finalize_weights(ctx), ctx)     # and the e4m3 copies: no InternLM2 linear was reloaded (aigv_amd.h)
 
     def _upload(self):
         lib, ctx = native.load(), self._ctx
@@ -782,7 +782,14 @@ class InternVLChatModel(nn.Module):
         return outs
 
     # ---- generation (API surface; greedy) -------------------------------------------------------------------
-    def _greedy(self, ids_packed, slot, cu, vis, n_vis, max_new_tokens: int, eos_ids: List[int], pad_id: int, motion=None, sampler=None):
+    EOS_CHECK_EVERY = 8     # tokens between two host reads of the device-side "finished" flags
+
+    def _greedy(self, ids_packed, slot, cu, vis, n_vis, max_new_tokens: int, eos_ids: List[int], pad_id: int, motion=None, sampler=None,
+                processors=None):
+        """The token loop of generate(): HF's greedy search / multinomial sampling loop (the reference calls ``language_model.generate``,
+        modeling_internvl_chat.py:798-809).  The end-of-sequence bookkeeping runs on the device (aigv_decode_eos): a finished sequence
+        emits ``pad_id``, the loop stops once every sequence has emitted an end token - checked by the host only every EOS_CHECK_EVERY
+        tokens, so no per-token host synchronisation; the columns past HF's stopping point are cut off afterwards."""
         b = len(cu) - 1
         longest = max(cu[i + 1] - cu[i] for i in range(b))
         last_rows = [cu[i + 1] - 1 for i in range(b)]
@@ -790,34 +797,50 @@ class InternVLChatModel(nn.Module):
             # the reference recomputes the dynamic-NTK base at every decode step past max_position_embeddings
             # (modeling_internlm2.py:227-235) while its cached keys keep the base they were rotated with
             raise NotImplementedError("decoding past max_position_embeddings with dynamic-NTK rope scaling is not implemented")
+        if len(eos_ids) > 8:
+            raise ValueError("at most 8 eos_token_id values")
         self._native(seq_len=longest)
         _, nxt = self._prefill(ids_packed, slot, cu, vis, n_vis, motion, None, last_rows, keep_kv=True,
                                kv_cap=longest + max_new_tokens + 1)
         lib, ctx = native.load(), self._ctx
-        if sampler is not None:       # the prefill's fused argmax is the greedy token; sampling draws from the same rows' logits
-            nxt = self._sample(self._row_logits(b), **sampler)
-        done = torch.zeros(b, dtype=torch.bool, device=self.device)
-        eos = torch.tensor(eos_ids, device=self.device, dtype=torch.long) if eos_ids else None
-        outs = []
+        eos_a = (C.c_int64 * max(len(eos_ids), 1))(*[int(e) for e in eos_ids]) if eos_ids else None
+        state = torch.zeros(b + 1, dtype=torch.int32, device=self.device)     # finished flags + live-column count (aigv_amd.h)
+        outs: List[torch.Tensor] = []
+
+        def pick(greedy_tok):
+            """The step's raw token: the fused argmax, or - with logits processors / sampling - a choice over the rows' lm-head logits."""
+            if sampler is None and not processors:
+                return greedy_tok
+            logits = self._row_logits(b)
+            if processors:
+                hist = torch.stack(outs, dim=1) if outs else torch.zeros((b, 0), dtype=torch.long, device=self.device)
+                for proc in processors:
+                    logits = proc(hist, logits)
+            return self._sample(logits, **sampler) if sampler is not None else logits.argmax(-1)
+
+        tok = pick(nxt).contiguous()
         for step in range(max_new_tokens):
-            tok = torch.where(done, torch.full_like(nxt, pad_id), nxt)
+            if eos_ids:       # tok: raw -> emitted (pad for finished sequences); flags / live-column count advance on the device
+                native.check(lib.aigv_decode_eos(ctx, tok.data_ptr(), state.data_ptr(), eos_a, len(eos_ids), int(pad_id), native.stream_ptr()), ctx)
             outs.append(tok)
-            if eos is not None:
-                done = done | (tok[:, None] == eos[None, :]).any(1)
-                if bool(done.all()):
-                    break
             if step + 1 == max_new_tokens:
                 break
+            if eos_ids and (step + 1) % self.EOS_CHECK_EVERY == 0 and bool(state[:b].all()):
+                break
             new = torch.empty_like(tok)
-            native.check(lib.aigv_decode_step(ctx, tok.contiguous().data_ptr(), new.data_ptr(), native.stream_ptr()), ctx)
-            nxt = new if sampler is None else self._sample(self._row_logits(b), **sampler)
-        return torch.stack(outs, dim=1)
+            native.check(lib.aigv_decode_step(ctx, tok.data_ptr(), new.data_ptr(), native.stream_ptr()), ctx)
+            tok = pick(new).contiguous()
+        out = torch.stack(outs, dim=1)
+        if eos_ids:
+            out = out[:, : max(1, int(state[b].item()))]     # HF stops after the column in which the last live sequence ended
+        return out
 
     @staticmethod
     def _gen_args(generation_config, kw):
         """(max_new_tokens, eos ids, pad id, sampler) from a HF-style generation config / kwargs.  ``sampler`` is None for greedy
         decoding or the warper settings of HF's multinomial sampling (temperature -> top-k -> top-p, transformers' order and
-        defaults: top_k 50, top_p 1.0, temperature 1.0).  Beam search and the repetition / n-gram processors are not on this path."""
+        defaults: top_k 50, top_p 1.0, temperature 1.0); ``processors`` = HF's repetition-penalty / no-repeat-n-gram logits processors
+        when asked for.  Beam search is not on this path."""
         cfg = dict(generation_config) if isinstance(generation_config, dict) else {}
         if generation_config is not None and not isinstance(generation_config, dict):
             cfg = {k: getattr(generation_config, k) for k in ("max_new_tokens", "do_sample", "num_beams", "eos_token_id", "pad_token_id",
@@ -826,8 +849,11 @@ class InternVLChatModel(nn.Module):
         cfg.update(kw)
         if (cfg.get("num_beams") or 1) > 1:
             raise NotImplementedError("beam search is not implemented on the gfx950 path (greedy and multinomial sampling are)")
-        if cfg.get("repetition_penalty") not in (None, 1, 1.0) or cfg.get("no_repeat_ngram_size") not in (None, 0):
-            raise NotImplementedError("repetition_penalty / no_repeat_ngram_size are not implemented on the gfx950 path")
+        processors = []       # HF's order (GenerationMixin._get_logits_processor): repetition penalty, then n-gram blocking
+        if cfg.get("repetition_penalty") not in (None, 1, 1.0):
+            processors.append(InternVLChatModel._repetition_penalty(float(cfg["repetition_penalty"])))
+        if cfg.get("no_repeat_ngram_size") not in (None, 0):
+            processors.append(InternVLChatModel._no_repeat_ngram(int(cfg["no_repeat_ngram_size"])))
         sampler = None
         if cfg.get("do_sample"):
             sampler = dict(temperature=float(cfg["temperature"]) if cfg.get("temperature") is not None else 1.0,
@@ -837,7 +863,42 @@ class InternVLChatModel(nn.Module):
                 raise ValueError(f"bad sampling settings {sampler}")
         eos = cfg.get("eos_token_id")
         eos = [] if eos is None else ([int(eos)] if not isinstance(eos, (list, tuple)) else [int(e) for e in eos])
-        return int(cfg.get("max_new_tokens") or 20), eos, cfg.get("pad_token_id"), sampler
+        return int(cfg.get("max_new_tokens") or 20), eos, cfg.get("pad_token_id"), sampler, processors
+
+    @staticmethod
+    def _repetition_penalty(penalty: float):
+        """HF RepetitionPenaltyLogitsProcessor over the GENERATED tokens (the reference's generate() passes inputs_embeds, so HF's
+        input_ids start empty): the logit of every token already emitted is divided by ``penalty`` if positive, multiplied if negative."""
+        if penalty <= 0:
+            raise ValueError("repetition_penalty must be a strictly positive float")
+
+        def proc(hist: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
+            if hist.shape[1] == 0:
+                return logits
+            sc = logits.gather(1, hist)
+            sc = torch.where(sc < 0, sc * penalty, sc / penalty)
+            return logits.scatter(1, hist, sc)
+        return proc
+
+    @staticmethod
+    def _no_repeat_ngram(n: int):
+        """HF NoRepeatNGramLogitsProcessor: a token that would complete an n-gram already present in the generated tokens gets -inf."""
+        if n <= 0:
+            raise ValueError("no_repeat_ngram_size must be a strictly positive integer")
+
+        def proc(hist: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
+            cur = hist.shape[1]
+            if cur + 1 < n:
+                return logits
+            rows = hist.tolist()          # host glue of generate(): a few dozen tokens per sequence
+            logits = logits.clone()
+            for b, seq in enumerate(rows):
+                prefix = tuple(seq[cur + 1 - n:cur])
+                banned = [seq[i + n - 1] for i in range(cur - n + 1) if tuple(seq[i:i + n - 1]) == prefix]
+                if banned:
+                    logits[b, banned] = float("-inf")
+            return logits
+        return proc
 
     def _row_logits(self, n_rows: int) -> torch.Tensor:
         """fp32 [n_rows, vocab]: lm-head logits of the rows the last native pass consumed (aigv_out_row_logits) - the reference's
@@ -848,6 +909,18 @@ class InternVLChatModel(nn.Module):
         buf = torch.empty((n_rows, ldo), dtype=torch.bfloat16, device=self.device)
         native.check(lib.aigv_out_row_logits(ctx, 0, n_rows, buf.data_ptr(), ldo, native.stream_ptr()), ctx)
         return buf[:, :V].float()
+
+    def last_hidden_rows(self, n_rows: int, first_row: int = 0) -> torch.Tensor:
+        """bf16 [n_rows, H]: final hidden states (after the last RMSNorm) of the rows the last native pass consumed, in the order
+        [score rows | logit rows] (aigv_out_row_hidden).  After ``forward`` rows 0..B-1 are the reference's
+        ``hidden_states[-1][:, -4, :]`` - the score head's input (modeling_internvl_chat.py:469-481)."""
+        lib, ctx = native.load(), self._ctx
+        if ctx is None:
+            raise native.NativeError("no native pass has run yet")
+        H = self.config.llm_config.hidden_size
+        buf = torch.empty((n_rows, H), dtype=torch.bfloat16, device=self.device)
+        native.check(lib.aigv_out_row_hidden(ctx, first_row, n_rows, buf.data_ptr(), H, native.stream_ptr()), ctx)
+        return buf
 
     @staticmethod
     def _sample(logits: torch.Tensor, temperature: float, top_k: int, top_p: float, generator=None) -> torch.Tensor:
@@ -872,7 +945,7 @@ class InternVLChatModel(nn.Module):
         """modeling_internvl_chat.py:769-811: every <IMG_CONTEXT> slot takes a visual token (no motion
         token), then greedy decode with a KV cache.  Returns the NEW tokens [B, <=max_new_tokens]."""
         assert self.img_context_token_id is not None
-        max_new, eos, pad, sampler = self._gen_args(generation_config, generate_kwargs)
+        max_new, eos, pad, sampler, procs = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         dev = self.device
         input_ids = input_ids.to(dev)
@@ -888,13 +961,13 @@ class InternVLChatModel(nn.Module):
             if int(sel.sum()) != n_vis:
                 raise ValueError(f"visual token count mismatch: {int(sel.sum())} slots vs {n_vis} tokens")
             slot[sel] = torch.arange(n_vis, device=dev, dtype=torch.int32)
-        return self._greedy(ids_packed, slot, cu, vis, n_vis, max_new, eos, pad, sampler=sampler)
+        return self._greedy(ids_packed, slot, cu, vis, n_vis, max_new, eos, pad, sampler=sampler, processors=procs)
 
     @torch.no_grad()
     def generate2(self, input_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, visual_features=None,
                   generation_config=None, output_hidden_states=None, return_dict=None, **generate_kwargs) -> torch.Tensor:
         """modeling_internvl_chat.py:812-853: decode from precomputed input embeddings [B, N, C]."""
-        max_new, eos, pad, sampler = self._gen_args(generation_config, generate_kwargs)
+        max_new, eos, pad, sampler, procs = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         dev = self.device
         b, n, c = input_embeds.shape
@@ -907,7 +980,7 @@ class InternVLChatModel(nn.Module):
         T = emb.shape[0]
         ids = torch.zeros(T, dtype=torch.long, device=dev)
         slot = torch.arange(T, dtype=torch.int32, device=dev)          # every row comes from `emb`
-        return self._greedy(ids, slot, cu, emb, T, max_new, eos, pad, sampler=sampler)
+        return self._greedy(ids, slot, cu, emb, T, max_new, eos, pad, sampler=sampler, processors=procs)
 
     @torch.no_grad()
     def generate_stage2(self, pixel_values, input_ids, attention_mask=None, image_flags=None, motion_feature=None,
@@ -918,14 +991,14 @@ class InternVLChatModel(nn.Module):
         token / visual / motion rows - no embedding tensor is assembled on the host side."""
         if self.img_context_token_id is None:
             raise AssertionError("img_context_token_id must be set (stage2_eval.py:810)")
-        max_new, eos, pad, sampler = self._gen_args(generation_config, generate_kwargs)
+        max_new, eos, pad, sampler, procs = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         B = input_ids.shape[0]
         plan = self._plan(input_ids, attention_mask, None, image_flags, pixel_values.shape[0], drop_dead_tail=False)
         motion_feature = self._motion_feature(pixel_values, B, motion_feature)
         self._native(n_frames=pixel_values.shape[0], n_tokens=plan["cu"][-1], n_clips=B)
         vit_embeds, motion = self._visual_inputs(pixel_values, None, motion_feature, plan)
-        return self._greedy(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], max_new, eos, pad, motion=motion, sampler=sampler)
+        return self._greedy(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], max_new, eos, pad, motion=motion, sampler=sampler, processors=procs)
 
     def chat2(self, tokenizer, pixel_values, input_ids, generation_config, attention_mask, history=None,
               return_history=False, image_flags=None, IMG_START_TOKEN="<img>", IMG_END_TOKEN="</img>",
@@ -1037,8 +1110,9 @@ class InternVLChatModel(nn.Module):
     def prof_read(self) -> Dict[str, Dict[str, float]]:
         lib, ctx = self._native()
         out = {}
-        for cls, name in enumerate(("gemm", "attn_vit", "attn_llm", "skinny", "gemm_fp8")):
+        for cls, name in enumerate(("gemm_llm", "attn_vit", "attn_llm", "skinny", "gemm_fp8", "gemm_vit")):
             n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
             native.check(lib.aigv_prof_read(ctx, cls, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), ctx)
             out[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        out["gemm"] = {k: out["gemm_llm"][k] + out["gemm_vit"][k] for k in out["gemm_llm"]}     # every bf16 tile-kernel GEMM launch
         return out

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "aigv_set_gemm_mode": (_I, [_P, _I]),
     "aigv_decode_step": (_I, [_P, _P, _P, _P]),
     "aigv_out_row_logits": (_I, [_P, _I, _I, _P, _I, _P]),
+    "aigv_out_row_hidden": (_I, [_P, _I, _I, _P, _I, _P]),
+    "aigv_decode_eos": (_I, [_P, _P, _P, _I64P, _I, C.c_int64, _P]),
     "aigv_op_gemm": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "aigv_op_gemm_splitk": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "aigv_op_gemm_splitk256": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),

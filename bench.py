@@ -115,16 +115,91 @@ def cpu_baseline(cfg, T, N, budget_s=30.0, slowfast=False):
         t_vit32 = timed(lambda: O.vit_layer(sd32, small, 0, xv.float()), reps=1)
         t_llm32 = timed(lambda: O.llm_layer(sd32, small, 0, xl.float(), mask32, pos), reps=1)
     per_clip32 = t_vit32 * v.num_hidden_layers + t_llm32 * l.num_hidden_layers + t_embed + t_proj + t_logits + t_sf
+    info = host_cpu_info()
     return {
         "value": 1.0 / per_clip, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+        "cores_note": (f"torch intra-op threads used = {torch.get_num_threads()}; host: {info['model']}, {info['physical_cores']} physical cores / "
+                       f"{info['logical_cpus']} logical CPUs visible to this process"),
+        "cpu_model": info["model"], "physical_cores": info["physical_cores"], "logical_cpus": info["logical_cpus"],
         "sample": (f"oracle (torch CPU bf16 eager restatement of the reference path), 1 clip: 1 full-width ViT layer x{v.num_hidden_layers} "
                    f"({t_vit_layer:.2f}s each) + 1 full-width LLM layer x{l.num_hidden_layers} ({t_llm_layer:.2f}s each, N={N}) + patch-embed "
                    f"{t_embed:.2f}s + projector {t_proj:.2f}s + lm-head on all rows {t_logits:.2f}s + SlowFast-R50 branch {t_sf:.2f}s; weight gen {gen_s:.0f}s untimed"),
         "s_per_clip": per_clip,
         "fp32": {"value": 1.0 / per_clip32, "s_per_clip": per_clip32,
                  "sample": f"the same layers in fp32: ViT layer {t_vit32:.2f}s, LLM layer {t_llm32:.2f}s (other terms as above)"},
-        "oracle_vs_reference": "wall time of this oracle against the imported reference on one host: profiles/r2_oracle_vs_reference_walltime.txt",
+        "oracle_vs_reference": ("wall time of this oracle against the imported reference on one host: profiles/r2_oracle_vs_reference_walltime.txt "
+                                "(0.84x bf16 / 0.93x fp32 of the reference's time); the imported reference itself, full depth, in the 8-vCPU AMX build "
+                                "container: 34-38 s per bf16 clip, 70 s fp32 (BASELINE.md)"),
     }
+
+
+def host_cpu_info():
+    """CPU model string, physical cores (unique (package, core) pairs of /proc/cpuinfo) and the logical CPUs this process may run on."""
+    model, pairs, phys, core = "unknown", set(), None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model == "unknown":
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None and core is not None:
+                    pairs.add((phys, core)); phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+    except OSError:
+        pass
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"model": model, "physical_cores": len(pairs) or logical, "logical_cpus": logical}
+
+
+def parity_vs_reference(model, cfg, dev):
+    """The benched configuration against the REFERENCE itself: tests/golden/e2e_8b_r3.pt holds the outputs of the imported reference
+    (CPU eager path, bf16 and fp32) on exactly this batch - 4 clips x 8 frames x 448 px, the seed-0 tokens / frames / motion feature of
+    this file - with the golden's seeded weights (make_golden_8b_r3.py).  The model takes those weights (generated on the CPU generator,
+    ~1.5 min, outside every timed region), scores the batch once and the differences go into the JSON line: the `score D vs ref` half
+    of BASELINE.json's metric.  Returns None when the fixture is not there."""
+    path = os.path.join(ROOT, "tests", "golden", "e2e_8b_r3.pt")
+    if not os.path.exists(path):
+        return None
+    from aigv_assessor_amd import synth
+    g = torch.load(path, weights_only=True)
+    r16, r32 = g["cases"]["batch4/bf16"], g["cases"]["batch4/fp32"]
+    B, T, seed = r16["B"], r16["T"], r16["seed"]
+    t0 = time.time()
+    sd = synth.make_state_dict(cfg, seed=g["w_seed"], rich=True)
+    for k, v in g["overrides"].items():
+        sd[k] = torch.full_like(sd[k], v)
+    model.load_state_dict(sd)
+    del sd
+    gen_s = time.time() - t0
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    model.img_context_token_id = toks["img_context_token_id"]
+    out = model(mos=None, pixel_values=synth.synthetic_frames(B * T, cfg.image_size, seed=seed).to(dev), input_ids=toks["input_ids"],
+                attention_mask=toks["attention_mask"], image_flags=torch.ones(B * T, 1, dtype=torch.long), labels=toks["labels"],
+                motion_feature=synth.synthetic_motion(B, cfg.motion_dim, seed=seed).to(dev))
+    torch.cuda.synchronize()
+    hip = out["score1"].float().cpu()
+    b16, f32 = r16["score1"].float(), r32["score1"].float()
+    got = out["logit"].cpu()[r16["answer_rows"]]
+    diff = (got != r16["logit"]).nonzero().flatten().tolist()
+    outside = 0
+    for i in diff:   # a mismatch is a near-tie when the reference's own logits put the HIP token within 4 bf16 ulps of its maximum
+        ids, vals = r16["top_ids"][i].tolist(), r16["top_values"][i].tolist()
+        ulp = 2.0 ** (torch.tensor(abs(vals[0])).clamp_min(1e-30).log2().floor().item() - 7)
+        if int(got[i]) not in ids or (vals[0] - vals[ids.index(int(got[i]))]) / ulp > 4.0:
+            outside += 1
+    return {"score_delta_vs_ref": float((hip - b16).abs().max()), "score_delta_vs_ref_mean": float((hip - b16).abs().mean()),
+            "score_delta_vs_ref_fp32_mean": float((hip - f32).abs().mean()), "ref_bf16_vs_ref_fp32_mean": float((b16 - f32).abs().mean()),
+            "level_mismatches": len(diff), "level_mismatches_outside_near_ties": outside, "level_rows": int(got.numel()),
+            "level_agreement_with_ref_fp32": {"hip": int((got == r32["logit"]).sum()), "ref_bf16": int((r16["logit"] == r32["logit"]).sum())},
+            "parity_note": ("one pass of THIS batch (4 clips x 8 frames, seed-0 inputs, motion_feature input) with the golden's seeded weights against the imported "
+                            "reference's recorded bf16 / fp32 outputs (tests/golden/e2e_8b_r3.pt); score1 is a bf16 number (ulp 0.0039 in [0.5, 1)), the reference's "
+                            f"own bf16 pass sits {float((b16 - f32).abs().mean()):.4f} (mean) from its fp32 pass on these clips; weight generation {gen_s:.0f} s, untimed")}
 
 
 def device_calibration(dev):
@@ -191,13 +266,17 @@ def decode_metric(model, cfg, toks, pv, T, n_short=9, n_long=41, fp8=False):
     ctx_id = toks["img_context_token_id"]
     ids[0, (ids[0] == ctx_id).nonzero()[-1]] = 7          # generate() prompts carry no motion slot: turn it into a text token
     am = torch.ones_like(ids)
+    # End-of-sequence checking ON, as in every chat() call of the reference (modeling_internvl_chat.py:612): the id is one that never
+    # wins on these weights (the last added special token), so all n tokens are decoded with the device-side EOS bookkeeping and the
+    # host's periodic check inside the measurement.
+    eos_id = l.vocab_size - 1
 
     def run(n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = model.generate(pixel_values=pv[:T], input_ids=ids, attention_mask=am, max_new_tokens=n, do_sample=False, eos_token_id=None)
+        out = model.generate(pixel_values=pv[:T], input_ids=ids, attention_mask=am, max_new_tokens=n, do_sample=False, eos_token_id=eos_id)
         torch.cuda.synchronize()
-        assert out.shape[1] == n
+        assert out.shape[1] == n, f"the end token {eos_id} was generated: pick another id"
         return time.perf_counter() - t0
     run(n_long)                                            # sizes the KV cache (re-creates the context once) and warms up
     t_s = min(run(n_short) for _ in range(3))
@@ -210,7 +289,7 @@ def decode_metric(model, cfg, toks, pv, T, n_short=9, n_long=41, fp8=False):
         post = l.hidden_size * l.hidden_size + 3 * l.hidden_size * l.intermediate_size
         weight_bytes = 1.0 * (l.num_hidden_layers * per_layer - post) + 2.0 * (post + l.vocab_size * l.hidden_size)
     kv_bytes = 2.0 * 2 * l.num_hidden_layers * l.num_key_value_heads * d * (n_prompt + (n_short + n_long) / 2)
-    return {"decode_ms_per_token": ms, "decode_batch": 1, "decode_prompt_tokens": n_prompt,
+    return {"decode_ms_per_token": ms, "decode_batch": 1, "decode_prompt_tokens": n_prompt, "decode_eos_checking": True,
             "decode_bytes_per_token": weight_bytes + kv_bytes, "decode_hbm_tb_per_s": (weight_bytes + kv_bytes) / (ms * 1e-3) / 1e12,
             "decode_hbm_frac_of_8tbps": (weight_bytes + kv_bytes) / (ms * 1e-3) / 8.0e12}
 
@@ -232,12 +311,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event roofline measurement")
     ap.add_argument("--all-rows", action="store_true", help="A/B: run every row through the last decoder layer (no row trimming)")
-    ap.add_argument("--force-dp", action="store_true", help="route a 1-GPU run through the frame/clip-DP scorer too (debug)")
+    ap.add_argument("--force-dp", action="store_true", help="variant: route a 1-GPU run through the frame/clip-DP scorer with its RCCL collectives executed on a one-rank group")
     ap.add_argument("--ingest", action="store_true", help="variant: pinned uint8 720p frames -> H2D -> resize + normalise on the GPU inside every step")
     ap.add_argument("--attn-kernel", type=int, default=0, choices=[0, 4, 8, 64],
                     help="A/B: force one prefill-attention kernel (aigv_tune_attention): 4 / 8 = attention.hip, 64 = attention64.hip; 0 = per-shape default")
     ap.add_argument("--tune-gemm", type=int, default=0, help="A/B: aigv_tune_gemm mode word (kernel choice + 16 * (1 + 256-kernel schedule variant))")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
+    ap.add_argument("--no-parity", action="store_true", help="skip the score / level comparison with the reference's recorded outputs (tests/golden/e2e_8b_r3.pt; ~1.5 min of CPU weight generation)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on gloo / CPU with a stand-in model (no measurement)")
     args = ap.parse_args()
 
@@ -249,6 +329,8 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     dry = args.dry_run_cpu
+    if args.ingest and world > 1:
+        raise SystemExit("--ingest is a single-GPU variant (the per-rank ingest of a frame shard is not wired into score_clips_dp)")
     if dry:
         if world > 1:
             dist.init_process_group("gloo")
@@ -256,8 +338,17 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback (--dry-run-cpu rehearses the control flow only)")
         torch.cuda.set_device(local_rank)
+        if args.force_dp and world == 1 and "RANK" not in os.environ:
+            # `python bench.py --gpus 1 --force-dp`: a one-rank RCCL group of its own, and the collectives of score_clips_dp run although one
+            # rank needs none - the N > 1 code path (all_gather_into_tensor with async work handles, result gathers) on a single MI355X
+            import socket
+            so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if world > 1 or (args.force_dp and "RANK" in os.environ):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if args.force_dp and world == 1:
+                from aigv_assessor_amd import dist_utils as _du
+                _du.force_single_rank_collectives = True
 
     import aigv_assessor_amd as pkg
     from aigv_assessor_amd import synth
@@ -295,8 +386,9 @@ def main():
             from aigv_assessor_amd import native
             native.check(native.load().aigv_tune_gemm(args.tune_gemm, 0.0))
     # inputs resident in HBM before the timed region (token ids are host data in the reference loop; tiny either way)
-    pv = synth.synthetic_frames(B * T, cfg.image_size, seed=0, device=dev)
-    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=0, device=dev) if args.motion == "input" else None
+    # (CPU generator: at N = 1 these are the values tests/golden/e2e_8b_r3.pt was recorded on by the imported reference)
+    pv = synth.synthetic_frames(B * T, cfg.image_size, seed=0).to(dev)
+    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=0).to(dev) if args.motion == "input" else None
     if args.motion == "slowfast" and not dry:
         from aigv_assessor_amd.slowfast import SlowFastR50
         model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=0))
@@ -307,11 +399,11 @@ def main():
         # the variant with the data path inside the step: decoded 720p frames in pinned host memory (what a video decoder hands
         # over) -> one H2D copy -> Pillow-exact BICUBIC resize to the model size + normalise on the GPU (aigv_op_frame_resize_ingest)
         g8 = torch.Generator().manual_seed(5)
-        frames_u8 = torch.randint(0, 256, (B * T // world if world > 1 else B * T, 720, 1280, 3), dtype=torch.uint8, generator=g8).pin_memory()
+        frames_u8 = torch.randint(0, 256, (B * T, 720, 1280, 3), dtype=torch.uint8, generator=g8).pin_memory()
 
     def step():
         x = pv
-        if frames_u8 is not None and world == 1:
+        if frames_u8 is not None:
             x = model.ingest_frames(frames_u8.to(dev, non_blocking=True))
         if world == 1 and not args.force_dp:
             return model(mos=None, pixel_values=x, input_ids=ids, attention_mask=am, image_flags=flags, labels=labels,
@@ -379,7 +471,7 @@ def main():
                        "inputs": ("bf16 NCHW frames resident in HBM before the timed region: no H2D copy, no resize / normalise inside the step"
                                   if frames_u8 is None else "pinned uint8 720p frames: H2D copy + BICUBIC resize + normalise INSIDE the step (--ingest variant)"),
                        "global_batch_clips": B, "frames_per_clip": T, "tokens_per_clip": N,
-                       "parallelism": f"frame/clip-dp{world}" + (" + RCCL all-gather of visual tokens" if world > 1 else "")},
+                       "parallelism": f"frame/clip-dp{world}" + (" + RCCL all-gather of visual tokens" if world > 1 or args.force_dp else "")},
             "slowfast_tflop_per_clip": (model.slowfast_model.flops_per_clip() / 1e12 if args.motion == "slowfast" and not dry else 0.0),   # not in the figures below
             "algorithmic_tflop_per_clip": fl["total"] / 1e12,
             "executed_tflop_per_clip": (fl["total"] if args.all_rows else fl["executed"]) / 1e12,
@@ -393,11 +485,12 @@ def main():
                 ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
                 traffic, tnote = None, None
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (scripts/pmc_summary.py); newest round's file first
-                tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (2, 1)) if os.path.exists(f)), None)
+                tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (3, 2, 1)) if os.path.exists(f)), None)
                 if tf:
                     tj = json.load(open(tf))
                     traffic = tj["all_gemm"]["traffic_bytes_per_launch"]
-                    tnote = f"L2<->fabric bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/{os.path.basename(tf)})"
+                    tnote = (f"NOT measured in this run: a committed constant - L2<->fabric bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                             f"passes of this command (profiles/{os.path.basename(tf)}, scripts/pmc_summary.py); a PMC pass cannot run inside the timed process")
                 line["roofline"] = {
                     "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                     "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": gm["bytes"] / gm["launches"],
@@ -407,6 +500,20 @@ def main():
                     "flops_per_launch": gm["flops"] / gm["launches"], "gemm_ms_per_step": gm["ms"] / args.steps,
                     "other_kernels_ms_per_step": {k: p[k]["ms"] / args.steps for k in ("attn_vit", "attn_llm", "skinny")},
                     "attn_tflops": {k: (p[k]["flops"] / (p[k]["ms"] * 1e-3) / 1e12 if p[k]["ms"] else None) for k in ("attn_vit", "attn_llm")},
+                }
+                # the same measurement per kernel class, so that the weakest class is visible in the line itself
+                def cls(name, label):
+                    c = p[name]
+                    if not c["launches"] or not c["ms"]:
+                        return None
+                    a_ = c["flops"] / (c["ms"] * 1e-3) / 1e12
+                    return {"kernels": label, "bound": "mfma", "achieved": a_, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a_ / PEAK_BF16_TFLOPS,
+                            "ms_per_step": c["ms"] / args.steps, "launches_per_step": c["launches"] / args.steps}
+                line["roofline_by_class"] = {
+                    "gemm_llm": cls("gemm_llm", "InternLM2 linears (wqkv, wo, w1|w3 + SwiGLU, w2; K = 4096 / 14336)"),
+                    "gemm_vit": cls("gemm_vit", "InternViT linears + mlp1 projector (qkv, proj, fc1 + GELU, fc2; K = 1024 / 4096)"),
+                    "attn_vit": cls("attn_vit", "InternViT attention (non-causal, d = 64, 1025 rows per frame)"),
+                    "attn_llm": cls("attn_llm", "InternLM2 prefill attention (causal GQA, d = 128)"),
                 }
         if prof and args.precision == "fp8":
             g8 = p["gemm_fp8"]   # (prof_read consumes the records: `p` is the one read of this run)
@@ -420,7 +527,17 @@ def main():
         if dry:
             line["dry_run"] = True
         if world == 1 and not dry and not args.no_decode and args.model == "8b":
-            line.update(decode_metric(model, cfg, toks, pv, T, fp8=args.precision == "fp8"))
+            dm = decode_metric(model, cfg, toks, pv, T, fp8=args.precision == "fp8")
+            line.update(dm)
+            if "roofline_by_class" in line:
+                line["roofline_by_class"]["decode"] = {"kernels": "generate(): q_len = 1 GEMVs + split-KV attention, batch 1", "bound": "hbm",
+                                                       "achieved": dm["decode_hbm_tb_per_s"] * 1e3, "peak": 8000.0, "unit": "GB/s",
+                                                       "frac": dm["decode_hbm_frac_of_8tbps"], "ms_per_token": dm["decode_ms_per_token"]}
+        if (world == 1 and not dry and not args.no_parity and args.model == "8b" and args.precision == "bf16" and T == 8 and Bl == 4
+                and not args.all_rows and not args.tune_gemm and not args.attn_kernel):
+            par = parity_vs_reference(model, cfg, dev)      # (replaces the model's weights: after every measurement)
+            if par:
+                line.update(par)
         if world == 1 and not dry and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, T, N, slowfast=args.motion == "slowfast")
             line["gpu_over_cpu"] = clips_per_s / line["cpu_baseline"]["value"]

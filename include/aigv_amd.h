@@ -78,9 +78,10 @@ int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out);
 void aigv_ctx_destroy(aigv_ctx* ctx);
 /* Change the CAPACITIES of a context (max_frames, vit_chunk, max_tokens, max_seqs, max_out_rows, kv_capacity, max_positions; every
  * other field of `cfg` must equal the context's): the workspaces are re-allocated, the loaded weights - and in fp8 mode their e4m3
- * copies - stay where they are.  Kept KV state is dropped.  When max_positions changed the rotary tables ("rope.cos" / "rope.sin")
- * must be loaded again at the new length and aigv_finalize_weights called before the next pass.  Synchronises the device.  A
- * failed resize (out of memory) leaves the context unusable: destroy it. */
+ * copies and the mode itself - stay where they are.  Kept KV state is dropped.  When max_positions changed the rotary tables
+ * ("rope.cos" / "rope.sin") must be loaded again at the new length and aigv_finalize_weights called before the next pass; that
+ * finalize keeps the fp8 mode (see aigv_set_precision).  Synchronises the device.  A failed resize (out of memory) leaves the
+ * context unusable: destroy it. */
 int aigv_ctx_resize(aigv_ctx* ctx, const aigv_config* cfg);
 const char* aigv_last_error(const aigv_ctx* ctx);     /* ctx may be NULL (creation errors) */
 
@@ -138,7 +139,9 @@ int aigv_kv_fork(aigv_ctx* ctx, int copies, void* stream);
  * to 4 sequences and hidden / intermediate widths of 2048 j (j = 2, 3 / 2, 3, 7, 8), else it decodes from the bf16 weights.  The reference
  * has no fp8 path: results move by the quantisation noise (oracle/fp8.py restates this mode; measured drift in DESIGN.md).  First call
  * quantises the weights (extra memory: one byte per InternLM2 linear weight).  Needs H, qkv width, 2*I multiples of 256.
- * aigv_finalize_weights (i.e. any reload of weights) drops the e4m3 copies and returns the context to bf16: set the mode again after it. */
+ * aigv_finalize_weights after a reload of an InternLM2 linear (wqkv / wo / w1 / w3 / w2 of any layer) drops the e4m3 copies and returns the
+ * context to bf16: set the mode again after it.  A finalize that follows other uploads only (the rotary tables after aigv_ctx_resize, a
+ * score head, ViT weights) keeps the copies and the mode. */
 enum aigv_precision { AIGV_PRECISION_BF16 = 0, AIGV_PRECISION_FP8_LLM = 1 };
 int aigv_set_precision(aigv_ctx* ctx, int mode);
 /* Last-layer row trimming in aigv_llm_prefill (default on): when at most 64 rows are consumed (score rows + logit rows), the
@@ -160,6 +163,18 @@ int aigv_decode_step(aigv_ctx* ctx, const int64_t* ids, int64_t* next, void* str
  * logits: DEVICE bf16 [n_rows, ldo], ldo >= vocab rounded up to a multiple of 4 (columns >= vocab are padding).  For
  * generate() with do_sample (HF sampling needs the distribution; the greedy paths use the fused argmax and never call this). */
 int aigv_out_row_logits(aigv_ctx* ctx, int first_row, int n_rows, void* logits_bf16, int ldo, void* stream);
+/* The final hidden states (after the last RMSNorm, modeling_internlm2.py:984) of the same rows, bf16 [n_rows, ldo >= llm_hidden]: for the
+ * score rows this is the reference's hidden_states[-1][:, -4, :], the input of its score head (modeling_internvl_chat.py:469-481) - the
+ * slice of `output_hidden_states=True` the eval path consumes.  Rows in the order [score rows | logit rows]. */
+int aigv_out_row_hidden(aigv_ctx* ctx, int first_row, int n_rows, void* hidden_bf16, int ldo, void* stream);
+/* End-of-sequence bookkeeping of generate()'s token loop on the device (the reference defers to HF's loop: next = next * unfinished +
+ * pad * (1 - unfinished); unfinished &= next not in eos_token_id; stop when every sequence has finished - modeling_internvl_chat.py:
+ * 798-809).  tokens: DEVICE int64[n] (n = sequences of the kept KV state), in: the step's raw tokens (aigv_decode_step's `next`, or the
+ * prefill's argmax), out: the tokens the loop emits (pad_id for finished sequences).  state: DEVICE int32[n + 1], zeroed by the caller
+ * before the first token: state[b] = 1 once sequence b has emitted an end token, state[n] = number of emitted columns in which some
+ * sequence was still live (the output length HF returns).  eos_ids: HOST, at most 8.  The host reads `state` only every few tokens,
+ * so the loop runs without a per-token host synchronisation. */
+int aigv_decode_eos(aigv_ctx* ctx, int64_t* tokens, int32_t* state, const int64_t* eos_ids, int n_eos, int64_t pad_id, void* stream);
 
 /* ---- single operators (parity tests call these through the same ABI) --------------------------------- */
 /* C = epilogue(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch */
@@ -234,8 +249,15 @@ int aigv_op_frame_ingest(const void* hwc_u8, int n_frames, int height, int width
 int aigv_op_frame_resize_ingest(const void* hwc_u8, int n_frames, int in_h, int in_w, int out_h, int out_w, const float* mean,
                                 const float* stdv, void* tmp_u8, void* out_u8_hwc, void* out_nchw, void* stream);
 
+/* ---- tuning knobs: TESTS AND EXPERIMENTS ONLY ---------------------------------------------------------------------------------------
+ * aigv_tune_gemm / aigv_tune_attention / aigv_tune_skinny set PROCESS-WIDE defaults (plain globals: not thread-safe, shared by every
+ * context and every aigv_op_* call of the process); they exist for in-process A/B measurements and for tests that must force a kernel
+ * form.  A deployment never calls them: what a context needs per instance is aigv_set_gemm_mode / aigv_set_precision /
+ * aigv_set_row_trimming above. */
 /* GEMM tile-kernel selection: mode 0 = cost model (default), 1 = always the 128x128 kernel, 2 = always the 256x256
  * phase-interleaved kernel where N % 256 == 0; rate256 > 0 overrides the model's relative throughput of the 256 kernel. */
+/* mode bits 4..6: 1 + v selects schedule variant v of the 256 kernel (0 = keep); bits 10..13: tile order of the 256 kernel, 0 = by weight
+ * size (default), 1 = row groups, 1 + g = groups of g column tiles. */
 int aigv_tune_gemm(int mode, double rate256);
 /* The row bands run_gemm would cut an M x N x K problem into (host logic only, no GPU): plan[0] = row tiles (x256 rows) on the
  * 256x256 kernel in whole rounds, or -1 = the whole problem in one launch of that kernel; plan[1] = row tiles on the 256x256
@@ -255,8 +277,10 @@ int aigv_tune_skinny(int p);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* When enabled every GEMM / attention launch of the hot path is bracketed by HIP events on the launch stream. */
+/* AIGV_PROF_GEMM = the bf16 tile-kernel GEMMs of the InternLM2 pass, AIGV_PROF_GEMM_VIT = those of InternViT and the mlp1 projector
+ * (aigv_vit_forward / aigv_project) - two classes because the short-K InternViT shapes run at a different fraction of the MFMA peak. */
 enum aigv_prof_class { AIGV_PROF_GEMM = 0, AIGV_PROF_ATTN_VIT = 1, AIGV_PROF_ATTN_LLM = 2, AIGV_PROF_SKINNY = 3,
-                       AIGV_PROF_GEMM_FP8 = 4, AIGV_PROF_COUNT = 5 };
+                       AIGV_PROF_GEMM_FP8 = 4, AIGV_PROF_GEMM_VIT = 5, AIGV_PROF_COUNT = 6 };
 int aigv_prof_enable(aigv_ctx* ctx, int on);
 /* Synchronises the recorded events and returns (and clears) launches, total milliseconds and algorithmic
  * FLOPs (2*M*N*K; attention 4*sum(len_q*len_kv_visible)*d*heads) and bytes per class. */

@@ -258,3 +258,105 @@ def test_context_grows_without_reloading_the_weights(precision):
     g1 = grown.generate(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=4, do_sample=False).cpu()
     g2 = fresh.generate(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=4, do_sample=False).cpu()
     assert len(uploads) == 1 and torch.equal(g1, g2)
+
+
+def _free_running(model, pv, ids, am, n):
+    return model.generate(pixel_values=pv, input_ids=ids, attention_mask=am, max_new_tokens=n, do_sample=False).cpu()
+
+
+def test_eos_bookkeeping_runs_on_the_device_and_follows_hf(rig):
+    """generate() with eos_token_id (every chat() call sets it: modeling_internvl_chat.py:612): HF's loop emits pad_token_id for a
+    finished sequence, marks a sequence finished when it emits an end token and stops once all are finished.  Here the flags live on
+    the device (aigv_decode_eos) and the host looks at them every EOS_CHECK_EVERY tokens only, so the loop may run a few steps
+    longer than HF's and cuts the surplus columns off.  Expected output = HF's rule applied to the free-running tokens (sequences
+    are independent, so what a finished sequence is fed cannot change the others)."""
+    model, cfg, sd, tok = rig
+    B, T, n_new = 2, 2, 21
+    toks = synth.canonical_tokens(cfg, B, T, seed=66)
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    ids = toks["input_ids"][:, :n_prompt].clone()
+    ctx = toks["img_context_token_id"]
+    for b in range(B):
+        ids[b, (ids[b] == ctx).nonzero()[-1]] = 7          # generate() prompts carry no motion slot
+    am = torch.ones_like(ids)
+    pv = synth.synthetic_frames(B * T, 224, seed=66)
+    model.img_context_token_id = ctx
+    free = _free_running(model, pv, ids, am, n_new)
+    assert free.shape == (B, n_new)
+    pad = 2
+    cases = [[int(free[0, 3])], [int(free[1, 10])], [int(free[0, 3]), int(free[1, 10])], [int(free[0, 12]), int(free[1, 1])], [cfg.llm_config.vocab_size - 1]]
+    for eos in cases:
+        want = free.clone()
+        ends = []
+        for b in range(B):
+            hit = [t for t in range(n_new) if int(free[b, t]) in eos]
+            ends.append(hit[0] if hit else n_new - 1)
+            if hit:
+                want[b, hit[0] + 1:] = pad
+        want = want[:, : max(ends) + 1]
+        got = model.generate(pixel_values=pv, input_ids=ids, attention_mask=am, max_new_tokens=n_new, do_sample=False,
+                             eos_token_id=eos if len(eos) > 1 else eos[0], pad_token_id=pad).cpu()
+        assert got.shape == want.shape and torch.equal(got, want), (eos, got.tolist(), want.tolist())
+    assert model.EOS_CHECK_EVERY < n_new          # the case list crosses at least two host checks
+
+
+def test_repetition_processors_in_generate(rig):
+    """repetition_penalty / no_repeat_ngram_size (HF processors the reference's generate() inherits, modeling_internvl_chat.py:798-809;
+    pinned against transformers' own classes in tests/test_host.py): with no_repeat_ngram_size = 1 no token may repeat, the first
+    token is the greedy one, and a penalty of 1.0 is plain greedy decoding."""
+    model, cfg, sd, tok = rig
+    pv = synth.synthetic_frames(2, 224, seed=67)
+    query = render(model, "<image>\nIs it sharp?", [2])
+    enc = tok(query, return_tensors="pt")
+    ids, am = enc["input_ids"], enc["attention_mask"]
+    model.img_context_token_id = tok.convert_tokens_to_ids("<IMG_CONTEXT>")
+    greedy = _free_running(model, pv, ids, am, 10)
+    same = model.generate(pixel_values=pv, input_ids=ids, attention_mask=am, max_new_tokens=10, do_sample=False, repetition_penalty=1.0).cpu()
+    assert torch.equal(same, greedy)
+    uniq = model.generate(pixel_values=pv, input_ids=ids, attention_mask=am, max_new_tokens=10, do_sample=False, no_repeat_ngram_size=1).cpu()
+    assert uniq.shape == (1, 10) and len(set(uniq[0].tolist())) == 10 and int(uniq[0, 0]) == int(greedy[0, 0])
+    # teacher-forced: every token is the argmax of that step's lm-head logits with the already generated tokens removed
+    pen = model.generate(pixel_values=pv, input_ids=ids, attention_mask=am, max_new_tokens=10, do_sample=False, repetition_penalty=1.3).cpu()
+    assert pen.shape == (1, 10) and int(pen[0, 0]) == int(greedy[0, 0])
+    if len(set(greedy[0].tolist())) < 10:         # greedy repeats itself on this random-weight model: the penalty must change something
+        assert not torch.equal(pen, greedy) or len(set(pen[0].tolist())) == len(set(greedy[0].tolist()))
+
+
+def test_process_default_gemm_mode_1_is_batch_invariant(rig):
+    """aigv_tune_gemm(1) as the PROCESS default with the context left at -1: every GEMM form - tile kernels, the skinny
+    GEMMs of the trimmed last layer and of the decode step - must then be independent of the batch: a clip scored or decoded alone
+    gives the bits it gives inside a batch."""
+    from aigv_assessor_amd import native
+    model, cfg, sd, tok = rig
+    lib = native.load()
+    B, T = 3, 2
+    toks = synth.canonical_tokens(cfg, B, T, seed=68)
+    model.img_context_token_id = toks["img_context_token_id"]
+    pv = synth.synthetic_frames(B * T, 224, seed=68)
+    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=68)
+    flags = torch.ones(B * T, 1, dtype=torch.long)
+    n1 = toks["input_ids"].shape[1] - 1
+
+    def score(sl_c, sl_f):
+        return model(pixel_values=pv[sl_f], input_ids=toks["input_ids"][sl_c], attention_mask=toks["attention_mask"][sl_c], image_flags=flags[sl_f],
+                     labels=toks["labels"][sl_c], motion_feature=motion[sl_c])
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    gids = toks["input_ids"][:, :n_prompt].clone()
+    for b in range(B):
+        gids[b, (gids[b] == toks["img_context_token_id"]).nonzero()[-1]] = 7
+
+    def decode(sl_c, sl_f):
+        out = model.generate(pixel_values=pv[sl_f], input_ids=gids[sl_c], attention_mask=torch.ones_like(gids[sl_c]), max_new_tokens=4, do_sample=False).cpu()
+        return out, model._row_logits(out.shape[0]).cpu()            # the last decode step's lm-head logits, bit for bit
+    assert getattr(model, "_gemm_mode", -1) == -1
+    native.check(lib.aigv_tune_gemm(1, 0.0))
+    try:
+        both = score(slice(0, B), slice(0, B * T))
+        tok_all, log_all = decode(slice(0, B), slice(0, B * T))
+        for b in range(B):
+            one = score(slice(b, b + 1), slice(T * b, T * b + T))
+            assert torch.equal(one["score1"], both["score1"][b:b + 1]) and torch.equal(one["logit"], both["logit"][b * n1:(b + 1) * n1])
+            tok_one, log_one = decode(slice(b, b + 1), slice(T * b, T * b + T))
+            assert torch.equal(tok_one, tok_all[b:b + 1]) and torch.equal(log_one.view(torch.int32), log_all[b:b + 1].view(torch.int32))
+    finally:
+        native.check(lib.aigv_tune_gemm(0, 0.0))

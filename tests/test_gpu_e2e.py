@@ -3,12 +3,14 @@ oracle on the same seeded inputs, and against the golden vectors recorded from t
 
 Bars (BASELINE.json north_star): quality-level tokens (answer-row argmax ids) bit-exact; score1 within 1e-3.
 score1 is a bf16 number in the reference (one ulp = 3.9e-3 in [0.5, 1), 2e-3 in [0.25, 0.5)), and the reference's own
-bf16 path sits up to 6e-3 away from its fp32 path (profiles/parity_score_noise_r1.txt), so "within 1e-3" is only
-reachable as "the same bf16 value".  Tolerance written here: |d| <= 1e-3 OR <= 2^-6 * max(1, |score|) (four bf16 ulps of
-the top binade of the trained score range [0.5, 1) — the spread the reference's own bf16 path shows around its fp32
-path on these random-weight models), plus a statistical bar over several seeds: the HIP path must be as close to the fp32 oracle as the bf16 oracle is
-(test_score_accuracy_matches_reference_bf16_path).  Measured: identical bf16 value in 10 of 14 seeded cases, 1-2 ulps
-in the rest (DESIGN.md "Parity").
+bf16 path sits up to 6e-3 away from its fp32 path at 2 layers and 0.002-0.026 at full depth (profiles/parity_score_noise_r2.txt,
+profiles/parity_full_size_r2.txt), so "within 1e-3" is only reachable as "the same bf16 value".  Tolerances written in the tests:
+  * tiny configurations: |d| <= 1e-3 OR <= 1 bf16 ulp of the expected value (score_ok);
+  * 4096-wide shallow configurations: <= 4 bf16 ulps AND anchored on the fp32 oracle (score_near_fp32);
+  * full depth (32 + 24 layers) against the REFERENCE's recorded outputs: <= 5 bf16 ulps per clip from its bf16 value, and over the
+    clips as close to its fp32 value as its own bf16 pass is (test_full_size_8b_* below);
+  * level tokens: identical, except rows where the reference's OWN top logits are within 2 (tiny) / 4 (full depth) bf16 ulps; hard
+    equality on the planted-margin weights.
 """
 import os
 
@@ -126,6 +128,24 @@ def test_stage2_tiny_224(capsys):
     check_levels(out, ref)
     score_ok(out["score1"], ref["score1"])
     assert abs(out["loss"].float().item() - ref["loss"].float().item()) <= 4e-3
+
+
+@pytest.mark.parametrize("select_layer", [-2, 1])
+def test_select_layer_other_than_the_last(select_layer):
+    """vision_select_layer != -1 (modeling_internvl_chat.py:509-518: ``hidden_states[select_layer]`` of the InternViT encoder, whose
+    tuple is [embeddings, layer 1 output, ..., layer L output], modeling_intern_vit.py:250-294): -2 = the output of the second-to-last
+    layer, 1 = the output of the first.  The native ViT pass then stops after that many layers (aigv_vit_forward)."""
+    cfg = pkg.tiny(image_size=224, vit_layers=3, llm_layers=1)
+    cfg.select_layer = select_layer
+    model, sd, toks, pv, motion, ref, out = run_case(cfg, B=2, T=2, seed=9)
+    assert model.select_layer == select_layer
+    vt = model.vit_tokens(pv)
+    want = O.shuffled_tokens(O.vit_forward(sd, cfg, pv, select_layer))
+    rel_close(vt, want, 0.01, 0.25)
+    last = O.shuffled_tokens(O.vit_forward(sd, cfg, pv, -1))
+    assert (want.float() - last.float()).abs().mean() > 0.05 * last.float().abs().mean()      # the layers that are skipped do matter
+    check_levels(out, ref)
+    score_ok(out["score1"], ref["score1"])
 
 
 def test_stage2_448_cls_tail_and_batch_invariance():
@@ -419,7 +439,7 @@ def test_greedy_generate_with_many_sequences(B, T):
 
 def test_against_reference_golden_vectors(golden_dir):
     """The fixtures were produced by the imported REFERENCE (tests/golden/make_golden.py), not by the oracle."""
-    e2e = torch.load(os.path.join(golden_dir, "e2e.pt"), weights_only=False)
+    e2e = torch.load(os.path.join(golden_dir, "e2e.pt"), weights_only=True)
     cfg = pkg.InternVLChatConfig.from_dict(dict(vision_config=e2e["vision_config"], llm_config=e2e["llm_config"],
                                                 force_image_size=448, select_layer=-1))
     for tag in ("bf16_b1", "bf16_b2"):
@@ -666,7 +686,7 @@ def full_8b(golden_dir):
     """The full-size model with the golden's seeded weights.  The weights come from the CPU generator (the values the
     reference run used; ~2 min for 8.1 G parameters) and are shared by the full-size tests of this module."""
     from aigv_assessor_amd.modeling import InternVLChatModel
-    g = torch.load(os.path.join(golden_dir, "e2e_8b_full.pt"), weights_only=False)
+    g = torch.load(os.path.join(golden_dir, "e2e_8b_full.pt"), weights_only=True)
     cfg = pkg.InternVLChatConfig.from_dict(dict(vision_config=g["vision_config"], llm_config=g["llm_config"],
                                                 force_image_size=448, select_layer=-1))
     assert cfg.llm_config.num_hidden_layers == 32 and cfg.vision_config.num_hidden_layers == 24 and cfg.llm_config.rope_scaling
@@ -690,6 +710,7 @@ def _golden_inputs(cfg, seed, dev):
 
 
 LEVEL_TIE_ULPS = 4.0
+FULL_SCORE_ULPS = 5.0      # full depth: |hip - reference bf16| per clip, in bf16 ulps of the score's binade
 
 
 def _bf16_ulp(x: float) -> float:
@@ -704,18 +725,19 @@ def test_full_size_8b_matches_the_reference_golden(full_8b):
       (a) per row, the HIP token is the bf16 reference's token or one of its top four whose logit the reference itself puts within
       LEVEL_TIE_ULPS = 4 bf16 ulps of its maximum (0.12 at |logit| ~ 5: the logit noise of 1-2 % of bf16 rounding noise in the
       final hidden state; two independent bf16-noisy evaluations differ by sqrt 2 of that); (b) against the FP32 reference the
-      HIP tokens agree at least as often as the bf16 reference's tokens do (minus 3 rows).  The hard form of "levels bit-exact"
+      HIP tokens agree at least as often as the bf16 reference's tokens do (minus 4 rows: 40 against 44 measured).  The hard form of "levels bit-exact"
       is the planted-margin test below;
     * score1: the reference's bf16 number is itself ~0.011 away from its fp32 number at this depth (32 + 24 layers of bf16
       rounding on a random-weight model), so "within 1e-3 of the reference" is below the reference's own arithmetic noise.
       Bar: over the input seeds the HIP score is as close to the reference's FP32 score as the reference's bf16 score is
-      (mean |hip - fp32| <= 1.5 x mean |ref bf16 - fp32| + one bf16 ulp), and never further than 0.04 from the bf16 one."""
+      (mean |hip - fp32| <= 1.5 x mean |ref bf16 - fp32| + one bf16 ulp), and never further than FULL_SCORE_ULPS = 5 bf16 ulps from the bf16
+      one (measured 3.5); the head's INPUT (hidden[:, -4]) is checked too: relative L2 to the fp32 reference <= 1.2 x the reference bf16's."""
     model, cfg, g = full_8b
     dev = model.device
     seeds = sorted({int(k.split("/")[1]) for k in g["cases"] if k.startswith("bf16/")})
     assert len(seeds) >= 3
     e_hip, e_ref, n_rows, n_tie, worst, bad = [], [], 0, 0, 0.0, []
-    agree_hip, agree_ref = 0, 0
+    agree_hip, agree_ref, h_hip, h_ref = 0, 0, [], []
     for seed in seeds:
         r16, r32 = g["cases"][f"bf16/{seed}"], g["cases"][f"fp32/{seed}"]
         toks, pv, motion = _golden_inputs(cfg, seed, dev)
@@ -742,7 +764,11 @@ def test_full_size_8b_matches_the_reference_golden(full_8b):
         n_rows += len(rows)
         hip, b16, f32 = out["score1"].float().item(), r16["score1"].float().item(), r32["score1"].float().item()
         e_hip.append(abs(hip - f32)); e_ref.append(abs(b16 - f32)); worst = max(worst, abs(hip - b16))
-        print(f"seed {seed}: score1 hip {hip:.6f} reference bf16 {b16:.6f} fp32 {f32:.6f}")
+        hid = model.last_hidden_rows(1).float().cpu()[:, ::16]
+        h32 = r32["hidden_m4_sub"].float()
+        h_hip.append(float((hid - h32).norm() / h32.norm())); h_ref.append(float((r16["hidden_m4_sub"].float() - h32).norm() / h32.norm()))
+        print(f"seed {seed}: score1 hip {hip:.6f} reference bf16 {b16:.6f} fp32 {f32:.6f}; hidden[:, -4] rel L2 vs fp32 reference: hip {h_hip[-1]:.4f}, "
+              f"reference bf16 {h_ref[-1]:.4f}")
     m_hip, m_ref = sum(e_hip) / len(seeds), sum(e_ref) / len(seeds)
     print(f"full size: level tokens {n_rows - n_tie}/{n_rows} identical to the bf16 reference ({n_tie} near-ties); agreement with the fp32 "
           f"reference: hip {agree_hip}/{n_rows}, bf16 reference {agree_ref}/{n_rows}; mean |hip - fp32| {m_hip:.5f}, "
@@ -751,9 +777,12 @@ def test_full_size_8b_matches_the_reference_golden(full_8b):
     assert n_tie <= n_rows // 4
     # 50 rows: the count moves by +-3 with the kernel choice alone (44 with the pipelined ViT attention, 40 with the default one, against
     # 44 for the reference's own bf16 pass) - every disagreement is a near-tie (asserted above); a wrong kernel lands far below this
-    assert agree_hip >= agree_ref - 6
+    assert agree_hip >= agree_ref - 4
     assert m_hip <= 1.5 * m_ref + 2.0 ** -8
-    assert worst <= 0.04
+    assert worst <= FULL_SCORE_ULPS * 2.0 ** -8, worst      # scores of these clips lie in [0.5, 1): one bf16 ulp = 2^-8 (measured: 3.5 ulps)
+    # the score head's input, hidden_states[-1][:, -4, :] (a 256-value subsample is recorded): relative L2 distance to the fp32
+    # reference no larger than 1.2 x the reference bf16 pass's own
+    assert max(h_hip) <= 1.2 * max(h_ref) and sum(h_hip) <= 1.2 * sum(h_ref), (h_hip, h_ref)
 
 
 def test_full_size_8b_planted_margin_levels_are_bit_exact(full_8b):
@@ -778,7 +807,7 @@ def test_full_size_8b_planted_margin_levels_are_bit_exact(full_8b):
         assert torch.equal(got, rec["logit"])
         assert len(set(got.tolist())) >= 3 and set(got.tolist()) <= set(rec["level_ids"])
         d = abs(out["score1"].float().item() - rec["score1"].float().item())
-        assert d <= 0.04, d
+        assert d <= 4 * _bf16_ulp(rec["score1"].float().item()), d
     finally:
         w.data[rec["level_ids"]] = keep
         model._invalidate()
@@ -814,7 +843,7 @@ def test_full_size_8b_properties(full_8b):
         one = run(slice(b, b + 1), slice(8 * b, 8 * b + 8))
         d = (one["score1"].float() - both["score1"][b:b + 1].float()).abs().item()
         print(f"clip {b}: alone {one['score1'].item():.4f} vs in batch {both['score1'][b].item():.4f}")
-        assert d <= 0.06
+        assert d <= 0.03           # measured 0.016: row bands / split-K tails differ between M = 2176 and M = 8704
     model.set_gemm_mode(1)
     try:
         both1 = run(slice(0, B), slice(0, B * T))
@@ -830,6 +859,129 @@ def test_full_size_8b_properties(full_8b):
     assert torch.isfinite(both["score1"].float()).all() and (both["score1"].float() >= 0).all()      # ReLU head
     dp = score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion)
     assert torch.equal(dp["score1"], both["score1"]) and torch.equal(dp["logit"], both["logit"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 3: the reference's recorded outputs (tests/golden/make_golden_8b_r3.py -> e2e_8b_r3.pt) for (1) the batch bench.py times,
+# (2) a stage-1 pass on a 16-frame clip, (3) generate() through the reference's own KV-cache path with planted-margin level rows.
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_r3(golden_dir):
+    return torch.load(os.path.join(golden_dir, "e2e_8b_r3.pt"), weights_only=True)
+
+
+def _level_rows_ok(got, r16, tag):
+    """Level tokens against the reference's bf16 pass: identical, or a token the reference itself puts within LEVEL_TIE_ULPS of its
+    maximum (its recorded top four).  Returns the number of such near-ties; raises on any other difference."""
+    bad, n_tie = [], 0
+    for i in (got != r16["logit"]).nonzero().flatten().tolist():
+        ids, vals = r16["top_ids"][i].tolist(), r16["top_values"][i].tolist()
+        if int(got[i]) not in ids:
+            bad.append(f"{tag} row {i}: token {int(got[i])} is not among the reference's top four {ids}")
+            continue
+        gap = (vals[0] - vals[ids.index(int(got[i]))]) / _bf16_ulp(vals[0])
+        print(f"{tag} answer row {i}: reference {int(r16['logit'][i])} vs hip {int(got[i])}, reference's own logit gap {gap:.2f} bf16 ulps")
+        if gap > LEVEL_TIE_ULPS:
+            bad.append(f"{tag} row {i}: argmax differs beyond a near-tie of the reference ({gap:.2f} ulps)")
+        n_tie += 1
+    assert not bad, bad
+    return n_tie
+
+
+def test_full_size_8b_benched_batch_matches_the_reference(full_8b, golden_r3):
+    """BASELINE.json configs[1] AS bench.py TIMES IT - 4 clips x 8 frames x 448 px in one call (8704-row GEMM bands, split-K tails, the
+    column-group tile order of the large InternLM2 matrices), bench.py's own inputs (seed 0 tokens / frames, motion_feature as an input) -
+    against the imported reference's bf16 and fp32 passes over the same batch.  Same bars as the one-clip test above."""
+    model, cfg, g = full_8b
+    assert golden_r3["w_seed"] == g["w_seed"] and golden_r3["overrides"] == g["overrides"]
+    r16, r32 = golden_r3["cases"]["batch4/bf16"], golden_r3["cases"]["batch4/fp32"]
+    B, T, seed = r16["B"], r16["T"], r16["seed"]
+    assert (B, T, seed) == (4, 8, 0)
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    model.img_context_token_id = toks["img_context_token_id"]
+    dev = model.device
+    out = model(mos=None, pixel_values=synth.synthetic_frames(B * T, 448, seed=seed).to(dev), input_ids=toks["input_ids"],
+                attention_mask=toks["attention_mask"], image_flags=torch.ones(B * T, 1, dtype=torch.long), labels=toks["labels"],
+                motion_feature=synth.synthetic_motion(B, cfg.motion_dim, seed=seed).to(dev))
+    torch.cuda.synchronize()
+    rows = r16["answer_rows"]
+    assert torch.equal(out["label"].cpu()[rows], r16["label"]) and r16["n_rows"] == out["label"].numel()
+    got = out["logit"].cpu()[rows]
+    n_tie = _level_rows_ok(got, r16, "batch of 4")
+    agree_hip, agree_ref = int((got == r32["logit"]).sum()), int((r16["logit"] == r32["logit"]).sum())
+    hip, b16, f32 = out["score1"].float().cpu(), r16["score1"].float(), r32["score1"].float()
+    m_hip, m_ref, worst = float((hip - f32).abs().mean()), float((b16 - f32).abs().mean()), float((hip - b16).abs().max())
+    hid, h32 = model.last_hidden_rows(B).float().cpu(), r32["hidden_m4"].float()
+    h_hip = ((hid - h32).norm(dim=1) / h32.norm(dim=1)).tolist()
+    h_ref = ((r16["hidden_m4"].float() - h32).norm(dim=1) / h32.norm(dim=1)).tolist()
+    print(f"benched batch: score1 hip {hip.tolist()} reference bf16 {b16.tolist()} fp32 {f32.tolist()}; level tokens {len(rows) - n_tie}/{len(rows)} identical "
+          f"({n_tie} near-ties), agreement with fp32: hip {agree_hip}, reference bf16 {agree_ref}; mean |hip - fp32| {m_hip:.5f}, mean |ref bf16 - fp32| "
+          f"{m_ref:.5f}, max |hip - ref bf16| {worst:.5f}; hidden[:, -4] rel L2 vs fp32: hip {[round(x, 4) for x in h_hip]} reference bf16 {[round(x, 4) for x in h_ref]}")
+    assert n_tie <= len(rows) // 4
+    assert agree_hip >= agree_ref - 4
+    assert m_hip <= 1.5 * m_ref + 2.0 ** -8
+    for b in range(B):
+        assert abs(float(hip[b] - b16[b])) <= FULL_SCORE_ULPS * _bf16_ulp(float(b16[b])), (b, float(hip[b]), float(b16[b]))
+    assert max(h_hip) <= 1.2 * max(h_ref) and sum(h_hip) <= 1.2 * sum(h_ref)
+
+
+def test_full_size_8b_stage1_16_frames_matches_the_reference(full_8b, golden_r3):
+    """The STAGE-1 flavour (internvl_chat_eval1/modeling_internvl_chat.py:250-366: the same pass, {'label', 'logit'} only, no score
+    head) at full depth on a 16-frame clip (N = 4281: BASELINE config 4's clip shape at the 8B dims), against the reference's eval1
+    class built around the same weights.  The model object is switched to stage 1 for the call: the stage decides which rows are
+    consumed and what is returned, not the weights."""
+    model, cfg, _g = full_8b
+    r16, r32 = golden_r3["cases"]["stage1/bf16"], golden_r3["cases"]["stage1/fp32"]
+    T, seed = r16["T"], r16["seed"]
+    toks = synth.canonical_tokens(cfg, 1, T, seed=seed)
+    model.img_context_token_id = toks["img_context_token_id"]
+    dev = model.device
+    model._native()            # the (stage-2) weights are on the device before the stage flips: nothing is re-uploaded under stage 1
+    model.stage = 1
+    try:
+        out = model(mos=None, pixel_values=synth.synthetic_frames(T, 448, seed=seed).to(dev), input_ids=toks["input_ids"],
+                    attention_mask=toks["attention_mask"], image_flags=torch.ones(T, 1, dtype=torch.long), labels=toks["labels"],
+                    motion_feature=synth.synthetic_motion(1, cfg.motion_dim, seed=seed).to(dev))
+        torch.cuda.synchronize()
+    finally:
+        model.stage = 2
+    assert set(out) == {"label", "logit"}                                              # eval1's return dict (:365-366)
+    rows = r16["answer_rows"]
+    assert r16["n_rows"] == out["label"].numel() == toks["input_ids"].shape[1] - 1 == 4280
+    assert torch.equal(out["label"].cpu()[rows], r16["label"])
+    got = out["logit"].cpu()[rows]
+    n_tie = _level_rows_ok(got, r16, "stage 1")
+    agree_hip, agree_ref = int((got == r32["logit"]).sum()), int((r16["logit"] == r32["logit"]).sum())
+    print(f"stage 1, 16 frames: level tokens {len(rows) - n_tie}/{len(rows)} identical to the bf16 reference, agreement with fp32: hip {agree_hip}, reference bf16 {agree_ref}")
+    assert n_tie <= max(2, len(rows) // 4) and agree_hip >= agree_ref - 2
+
+
+def test_full_size_8b_generate_matches_the_reference_cache_path(full_8b, golden_r3):
+    """generate() (modeling_internvl_chat.py:769-811) at full depth: 12 greedy tokens behind clip 0's 8-frame prompt, against the
+    REFERENCE's own KV-cache loop (modeling_internlm2.py:397-402, :1126-1163) on the golden's weights with five planted-margin
+    lm-head rows (every step won by >= the recorded margin, so token equality is a hard assert), end-of-sequence checking on."""
+    model, cfg, g = full_8b
+    rec = golden_r3["cases"]["greedy/bf16"]
+    toks = synth.canonical_tokens(cfg, 4, 8, seed=rec["seed"])
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    assert n_prompt == rec["prompt_len"]
+    ids = toks["input_ids"][:1, :n_prompt].clone()
+    ctx = toks["img_context_token_id"]
+    ids[0, (ids[0] == ctx).nonzero()[-1]] = 7                                          # as the generator: no motion slot in generate() prompts
+    pv = synth.synthetic_frames(32, 448, seed=rec["seed"])[:8].to(model.device)
+    model.img_context_token_id = ctx
+    w = model.language_model.output.weight
+    keep = w.data[rec["level_ids"]].clone()
+    try:
+        w.data[rec["level_ids"]] = keep * golden_r3["plant_scale"]
+        model._invalidate()
+        got = model.generate(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=rec["n_new"], do_sample=False,
+                             eos_token_id=toks["im_end_id"]).cpu()
+        print("generate at full depth: hip", got.tolist(), "reference", rec["tokens"].tolist(), "margins (sigma)", [round(float(x), 2) for x in rec["margin_sigma"]])
+        assert torch.equal(got, rec["tokens"])
+    finally:
+        w.data[rec["level_ids"]] = keep
+        model._invalidate()
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -143,6 +143,39 @@ def test_gemm_tile_kernels_agree(lib, mode, M, N, K, epi):
     ulp_check(dC, want, frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_tile_order_changes_no_bit(lib, epi):
+    """The 256x256 kernel's workgroup -> tile map (row groups / groups of g column tiles: GemmArgs::order, gemm256.hip) only decides WHICH
+    workgroup computes a tile, never how: every order must produce the same bits.  8708 x 1280 x 512 = 35 row tiles (the last with 4 rows)
+    x 5 column tiles on the 256 kernel for every row (mode 2): with groups of 4 and of 2 column tiles the last column group is ragged
+    (5 % 4, 5 % 2 != 0), with row groups of 4 the last row group is (35 % 4 != 0).  The default rule switches to column groups only for
+    N x K >= 32 Mi with M >= 8192 - InternLM2's w1|w3 / w2 at batch 4 - which no other op-level case reaches."""
+    from aigv_assessor_amd import native
+    from aigv_assessor_amd.native import ptr
+    M, N, K = 8708, 1280, 512
+    g = torch.Generator().manual_seed(4100 + epi)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(BF)
+    W = (torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K))).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF) if epi in (0, 1, 2) else None
+    ls = (torch.rand(N, generator=g) + 0.5).to(BF) if epi == 2 else None
+    nout = N // 2 if epi == 4 else N
+    resid = torch.randn(M, nout, generator=g).to(BF) if epi in (2, 3) else None
+    dA, dW = dev(A), dev(W)
+    db, dl, dr = (dev(t) if t is not None else None for t in (bias, ls, resid))
+    outs = {}
+    try:
+        for field in (1, 5, 3, 2):     # aigv_tune_gemm bits 10..13: 1 = row groups, 1 + g = groups of g column tiles (4, 2, 1)
+            native.check(lib.aigv_tune_gemm(2 | (field << 10), 0.0))
+            dC = torch.full((M, nout), float("nan"), dtype=BF, device="cuda")
+            sync(lib.aigv_op_gemm(ptr(dA), K, ptr(dW), K, ptr(dC), nout, ptr(db), ptr(dl), ptr(dr), nout, None, 0, M, N, K, epi, None), lib)
+            outs[field] = dC.cpu()
+    finally:
+        native.check(lib.aigv_tune_gemm(0, 0.0))           # auto dispatch, tile order by weight size again
+    ulp_check(outs[1], gemm_ref(A, W, epi, bias, ls, resid), frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
+    for field in (5, 3, 2):
+        assert torch.equal(outs[field].view(torch.int16), outs[1].view(torch.int16)), f"tile order field {field} changed the result"
+
+
 @pytest.mark.parametrize("M,N,K,epi,S", [(516, 512, 2048, 3, 2), (200, 256, 3072, 0, 3), (4, 1024, 4096, 4, 4), (300, 384, 1024, 2, 2),
                                           (130, 256, 512, 1, 4), (512, 512, 2048, 3, -8), (768, 256, 1536, 0, -3), (300, 1024, 1024, 4, -2),
                                           (256, 768, 4096, 2, -4), (513, 256, 768, 1, -6)])

@@ -391,7 +391,7 @@ def test_build_inputs_and_get_index_match_the_reference(golden_dir):
     from stub_tokenizer import StubTokenizer
     from aigv_assessor_amd import prompts
     from aigv_assessor_amd.conversation import get_conv_template
-    g = torch.load(os.path.join(golden_dir, "host_inputs.pt"), weights_only=False)
+    g = torch.load(os.path.join(golden_dir, "host_inputs.pt"), weights_only=True)
     tok = StubTokenizer(92553)
     assert len(g["samples"]) >= 6
     for s in g["samples"]:
@@ -426,3 +426,50 @@ def test_build_inputs_and_get_index_match_the_reference(golden_dir):
     b = prompts.batch_inputs([prompts.build_inputs(tok, q, a, 4, 64) for q, a in (("Q one?", "Short."), ("A longer question?", "A longer answer."))])
     assert b["input_ids"].shape[0] == 2 and int(b["attention_mask"][0].sum()) < b["input_ids"].shape[1] == int(b["attention_mask"][1].sum())
     assert bool((b["labels"][0][~b["attention_mask"][0]] == -100).all()) and bool((b["input_ids"][0][~b["attention_mask"][0]] == 2).all())
+
+
+def test_generation_logits_processors_match_transformers():
+    """The host glue of generate(): HF's RepetitionPenaltyLogitsProcessor and NoRepeatNGramLogitsProcessor (the reference's generate()
+    hands its generation_config to HF, modeling_internvl_chat.py:798-809).  The processors here are checked against transformers'
+    own classes on random logits and token histories (a third-party dependency of the reference, installed here as 5.x; the
+    reference pins 4.37.2 - the two classes' arithmetic has not changed)."""
+    from transformers.generation.logits_process import NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor
+    g = torch.Generator().manual_seed(5)
+    B, V = 3, 50
+    for cur in (0, 1, 2, 5, 12):
+        hist = torch.randint(0, 6, (B, cur), generator=g)              # few distinct tokens: repeated n-grams do occur
+        logits = torch.randn(B, V, generator=g)
+        for pen in (1.3, 0.7):
+            ours = InternVLChatModel._repetition_penalty(pen)(hist, logits.clone())
+            theirs = RepetitionPenaltyLogitsProcessor(pen)(hist, logits.clone()) if cur else logits
+            assert torch.equal(ours, theirs)
+        for n in (1, 2, 3):
+            ours = InternVLChatModel._no_repeat_ngram(n)(hist, logits.clone())
+            theirs = NoRepeatNGramLogitsProcessor(n)(hist, logits.clone())
+            assert torch.equal(ours, theirs), (cur, n)
+    mx, eos, pad, sampler, procs = InternVLChatModel._gen_args(dict(max_new_tokens=7, eos_token_id=[5, 9], repetition_penalty=1.2, no_repeat_ngram_size=2), {})
+    assert (mx, eos, pad, sampler, len(procs)) == (7, [5, 9], None, None, 2)
+    assert InternVLChatModel._gen_args(None, dict(repetition_penalty=1.0, no_repeat_ngram_size=0))[4] == []
+    with pytest.raises(NotImplementedError):
+        InternVLChatModel._gen_args(dict(num_beams=2), {})
+
+
+def test_full_size_round3_fixture_is_plain_data(golden_dir):
+    """tests/golden/e2e_8b_r3.pt (recorded from the imported reference by make_golden_8b_r3.py): loads with weights_only=True and holds
+    the cases the -m gpu tests consume."""
+    path = os.path.join(golden_dir, "e2e_8b_r3.pt")
+    g = torch.load(path, weights_only=True)
+    assert g["llm_config"]["num_hidden_layers"] == 32 and g["vision_config"]["num_hidden_layers"] == 24
+    for key in ("batch4/fp32", "batch4/bf16", "stage1/fp32", "stage1/bf16", "greedy/bf16"):
+        assert key in g["cases"], key
+    b4 = g["cases"]["batch4/bf16"]
+    assert b4["B"] == 4 and b4["T"] == 8 and b4["seed"] == 0 and b4["score1"].shape == (4,) and b4["logit"].numel() == 40
+    assert b4["hidden_m4"].shape == (4, 4096) and b4["top_ids"].shape == (40, 4)
+    s1 = g["cases"]["stage1/bf16"]
+    assert s1["T"] == 16 and "score1" not in s1 and s1["n_rows"] == synth.canonical_len(pkg.internvl2_8b(), 16) - 1
+    gr = g["cases"]["greedy/bf16"]
+    assert gr["tokens"].shape == (1, gr["n_new"]) and set(gr["tokens"][0].tolist()) <= set(gr["level_ids"])
+    assert float(gr["margin_sigma"].min()) >= 0.99 * gr["margin_floor"]
+    # the older fixture loads as plain data too (ADVICE r2)
+    g2 = torch.load(os.path.join(golden_dir, "e2e_8b_full.pt"), weights_only=True)
+    assert "planted/201" in g2["cases"]

@@ -29,12 +29,12 @@ def close(a, b, dtype, frac=0.002):
 
 @pytest.fixture(scope="module")
 def comp(golden_dir):
-    return torch.load(os.path.join(golden_dir, "components.pt"), weights_only=False)
+    return torch.load(os.path.join(golden_dir, "components.pt"), weights_only=True)
 
 
 @pytest.fixture(scope="module")
 def e2e(golden_dir):
-    return torch.load(os.path.join(golden_dir, "e2e.pt"), weights_only=False)
+    return torch.load(os.path.join(golden_dir, "e2e.pt"), weights_only=True)
 
 
 @pytest.mark.parametrize("flavour,norm_type,qkn,qkv_bias", [("ln", "layer_norm", False, True),
