@@ -549,6 +549,15 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
   // 4 waves (128 query rows) per workgroup.  With the XCD-aware block order the K/V stream of a head is shared in L2, and
   // 8-wave workgroups (half the K/V reads, half the resident workgroups) measured equal or slower on every headline shape
   // (scripts/attn_bench.py with AB_WAVES=1); the 8-wave form stays reachable through aigv_tune_attention for such A/Bs.
+  if (g_attn_waves == 43 || g_attn_waves == 83) {   // experiments: a three-deep K/V ring (two tiles in flight) with 4 / 8 waves
+    const bool w8 = g_attn_waves == 83;
+    if (head_dim == 64) {
+      if (a.causal) return w8 ? launch_attn<64, true, 8, 3>(a, s) : launch_attn<64, true, 4, 3>(a, s);
+      return w8 ? launch_attn<64, false, 8, 3>(a, s) : launch_attn<64, false, 4, 3>(a, s);
+    }
+    if (a.causal) return w8 ? launch_attn<128, true, 8, 3>(a, s) : launch_attn<128, true, 4, 3>(a, s);
+    return w8 ? launch_attn<128, false, 8, 3>(a, s) : launch_attn<128, false, 4, 3>(a, s);
+  }
   const int nw = g_attn_waves == 8 ? 8 : 4;
   if (head_dim == 64) {
     if (a.causal) return nw == 8 ? launch_attn<64, true, 8>(a, s) : launch_attn<64, true, 4>(a, s);
