@@ -14,13 +14,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "attention64.hip", "rowops.hip", "head.hip", "head8.hip", "ingest.hip", "slowfast.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "rowops.hip", "head.hip", "head8.hip", "ingest.hip", "slowfast.hip"]
 HEADERS = ["common.h", "kernels.h", "attn_lay.h", os.path.join("..", "..", "include", "aigv_amd.h")]
 OUT = os.path.join(HERE, "libaigv_amd.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-# per-file additions.  attention64: no NaN is ever produced in that file (finite "no key yet" sentinel), and without the flag
-# every fmaxf on an MFMA result is preceded by a canonicalising v_max_f32 - a third of the row-maximum instructions
-EXTRA_FLAGS = {"attention64.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {}      # per-file additions (none at present)
 
 
 def _mtime(p: str) -> float:

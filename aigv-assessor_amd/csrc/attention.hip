@@ -19,6 +19,8 @@
 // reference rounds its score matrix to bf16 once or twice - extra noise this kernel does not reproduce), P rounds
 // to bf16 before P·V (un-normalised; the row is divided at the end), the output rounds to bf16.  Against fp64
 // truth the kernel is at least as accurate as the reference's eager path (tests/test_gpu_ops.py).
+#include <cstring>
+
 #include "common.h"
 #include "kernels.h"
 #include "attn_lay.h"
@@ -28,6 +30,20 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int KT = 64;    // keys per tile
+
+// Diagnostic build only (-DAIGV_ATTN_STAMP, scripts/attn_stamp.py): where a wave's cycles go, summed over all waves of all launches.
+// Slots per head dim (0: d = 64, 1: d = 128): 0 waves, 1 total, 2 prologue (Q fragments, first DMA), 3 wait for the tile + barrier,
+// 4 DMA issue, 5 S^T = K Q^T incl. fragment reads and the row maximum, 6 softmax + P V, 7 epilogue, 8 tiles computed.  The stamps
+// (s_memtime, an lgkmcnt wait each) perturb the schedule by ~10 %: read shares, not absolute times.  Never defined in the product build.
+#ifdef AIGV_ATTN_STAMP
+constexpr int STAMP_REPL = 2048;     // replicas of the accumulators, indexed by workgroup: a single hot address would serialise the atomics
+__device__ unsigned long long g_attn_stamp[2][STAMP_REPL][16];
+#define STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define STAMP_ADD(slot, a, b) do { if (lane == 0) st_acc[slot] += (b) - (a); } while (0)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
 
 // NW = waves per workgroup (32 query rows each).  More waves share one K/V tile: the LDS-DMA issue cost per wave and tile
 // (the dominant overhead next to the MFMAs) halves going from 4 to 8 waves.
@@ -44,6 +60,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
+#ifdef AIGV_ATTN_STAMP
+  unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  STAMP(t_begin);
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs, so the linear id is remapped (bijectively) to
   // give each XCD a contiguous run of (sequence, head, query block) - the query blocks of one head, and the heads of one GQA
   // group, then stream the same K/V through ONE L2 instead of eight.
@@ -83,37 +103,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
   const int qw = ksplit ? q0 : q0 + wave * 32;    // first query row of this wave
 
   // ---- Q^T fragments: lane (c,h) holds Q[qw+c][16*ks + 8h + j] --------------------------------------
+  // Prologue order: the query rows (and their rotary rows) are REQUESTED first, then the first K/V tiles' LDS-DMA goes out, and only
+  // then the query math runs - it waits for the loads with the DMA already in flight behind them (one memory latency instead of two).
   bf16x8 qf[NKS];
+  const int qr0 = qw + c;
+  const bool q_ok = qr0 < len;
+  u16x8 raw[NKS], rco[NKS / 2], rsi[NKS / 2];
   {
-    const int qr = qw + c;
-    const bool ok = qr < len;
-    const bf16_t* qp = p.q + (size_t)(row0 + (ok ? qr : 0)) * p.ldq + (size_t)(hq / g) * p.q_group_stride + (hq % g) * D;
-    u16x8 raw[NKS];
+    const bf16_t* qp = p.q + (size_t)(row0 + (q_ok ? qr0 : 0)) * p.ldq + (size_t)(hq / g) * p.q_group_stride + (hq % g) * D;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) raw[ks] = *(const u16x8*)(qp + 16 * ks + 8 * h);
     if (p.rope_cos) {
       // rotate_half pairs dimension i with i + D/2: k-steps ks and ks + NKS/2 of the same lane (modeling_internlm2.py:247-261)
-      const size_t tb = (size_t)p.rope_pos[row0 + (ok ? qr : 0)] * (D / 2);
+      const size_t tb = (size_t)p.rope_pos[row0 + (q_ok ? qr0 : 0)] * (D / 2);
 #pragma unroll
       for (int ks = 0; ks < NKS / 2; ++ks) {
-        const u16x8 co = *(const u16x8*)(p.rope_cos + tb + 16 * ks + 8 * h), si = *(const u16x8*)(p.rope_sin + tb + 16 * ks + 8 * h);
-        const u16x8 lo = raw[ks], hi = raw[ks + NKS / 2];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x1 = bf2f(lo[e]), x2 = bf2f(hi[e]), cc = bf2f(co[e]), ss = bf2f(si[e]);
-          raw[ks][e] = f2bf(rbf(x1 * cc) + rbf(-x2 * ss));
-          raw[ks + NKS / 2][e] = f2bf(rbf(x2 * cc) + rbf(x1 * ss));
-        }
+        rco[ks] = *(const u16x8*)(p.rope_cos + tb + 16 * ks + 8 * h);
+        rsi[ks] = *(const u16x8*)(p.rope_sin + tb + 16 * ks + 8 * h);
       }
-    }
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      if (p.q_prescale != 1.0f) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) raw[ks][e] = f2bf(bf2f(raw[ks][e]) * p.q_prescale);
-      }
-      if (!ok) raw[ks] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      qf[ks] = __builtin_bit_cast(bf16x8, raw[ks]);
     }
   }
 
@@ -163,6 +170,36 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     }
   };
 
+  // each wave issues 2*IPW LDS-DMA instructions per tile; nothing else in the loop touches vmcnt
+#pragma unroll
+  for (int t0 = 0; t0 < NB - 1; ++t0)
+    if (t0 < n_tiles) stage(t0, t0);
+  // ---- the query math (RoPE, pre-scale), behind the first DMA ------------------------------------------------
+  {
+    if (p.rope_cos) {
+#pragma unroll
+      for (int ks = 0; ks < NKS / 2; ++ks) {
+        const u16x8 co = rco[ks], si = rsi[ks];
+        const u16x8 lo = raw[ks], hi = raw[ks + NKS / 2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x1 = bf2f(lo[e]), x2 = bf2f(hi[e]), cc = bf2f(co[e]), ss = bf2f(si[e]);
+          raw[ks][e] = f2bf(rbf(x1 * cc) + rbf(-x2 * ss));
+          raw[ks + NKS / 2][e] = f2bf(rbf(x2 * cc) + rbf(x1 * ss));
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      if (p.q_prescale != 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[ks][e] = f2bf(bf2f(raw[ks][e]) * p.q_prescale);
+      }
+      if (!q_ok) raw[ks] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8, raw[ks]);
+    }
+  }
+
   f32x16 oacc[NDT];
 #pragma unroll
   for (int i = 0; i < NDT; ++i)
@@ -176,18 +213,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
   const int tr_key = 4 * (gi >> 1) + (li >> 2);       // + 32*st + 16*s + 8*jh
   const int tr_dcol = 16 * (gi & 1) + 4 * (li & 3);   // + 32*dt
 
-  // each wave issues 2*IPW LDS-DMA instructions per tile; nothing else in the loop touches vmcnt
-#pragma unroll
-  for (int t0 = 0; t0 < NB - 1; ++t0)
-    if (t0 < n_tiles) stage(t0, t0);
+  STAMP(t_loop);
+  STAMP_ADD(2, t_begin, t_loop);
   for (int kt = 0; kt < n_tiles; ++kt) {
+    STAMP(t0);
     // tile kt must have landed; up to NB-2 younger tiles may stay in flight
     const int younger = min(NB - 2, n_tiles - 1 - kt);
     if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * IPW) : "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // tile kt visible to every wave; everyone is done reading buffer (kt-1) % NB, which is refilled now
+    STAMP(t1);
+    STAMP_ADD(3, t0, t1);
     if (kt + NB - 1 < n_tiles) stage(kt + NB - 1, (kt + NB - 1) % NB);
+    STAMP(t2);
+    STAMP_ADD(4, t1, t2);
     const char* sK = smem + (kt % NB) * (2 * KT * ROWB);
     const char* sV = sK + KT * ROWB;
 
@@ -237,6 +277,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
         for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[st][e]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    STAMP(t3);
+    STAMP_ADD(5, t2, t3);
     const float m_new = fmaxf(m_run, tmax);
     // Lazy rescale: the running reference m_run only moves when some row's maximum has grown by more than 2^8 in the exp2
     // domain (a new row maximum turns up in almost every tile, a jump of 8 octaves almost never after the first).  Until
@@ -253,22 +295,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
       m_run = m_new;
     }
     const float mc = (m_run == -INFINITY) ? 0.f : m_run * sc;
-    // element pairs: one v_pk_fma_f32 and one v_pk_add_f32 per two scores (the loop is VALU-issue-bound: SQ counters in
-    // profiles/r1_attn_sq.txt); raw v_exp_f32: p underflows to 0, no fix-up needed
-    f32x2 psum2 = f32x2{0.f, 0.f};
-    const f32x2 sc2 = f32x2{sc, sc}, nmc2 = f32x2{-mc, -mc};
+    // (the loop is VALU-issue-bound: SQ counters in profiles/r1_attn_sq.txt, phase stamps in profiles/r3_attn_stamps.txt); raw
+    // v_exp_f32: p underflows to 0, no fix-up needed
+    // One v_fma_f32 / v_add_f32 per score, through asm so that hipcc's SLP pass cannot re-pack them into v_pk_*_f32: the packed forms
+    // halve the instruction count but not the issue time (the guide prices them as an anti-lever beside MFMAs); in-step A/B round 3:
+    // InternViT attention 4.94 -> 4.85 ms, InternLM2 7.17 -> 7.12 ms per step (profiles/r3_attn_stamps.txt).  Two running sums.
+    float ps0 = 0.f, ps1 = 0.f;
+    const float nmc = -mc;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        const f32x2 t = __builtin_elementwise_fma(f32x2{sacc[st][e], sacc[st][e + 1]}, sc2, nmc2);
-        const f32x2 pv = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-        psum2 += pv;
-        sacc[st][e] = pv.x;
-        sacc[st][e + 1] = pv.y;
+        float t0, t1;
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(sacc[st][e]), "v"(sc), "v"(nmc));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(sacc[st][e + 1]), "v"(sc), "v"(nmc));
+        const float p0 = __builtin_amdgcn_exp2f(t0), p1 = __builtin_amdgcn_exp2f(t1);
+        asm("v_add_f32 %0, %1, %2" : "=v"(ps0) : "v"(ps0), "v"(p0));
+        asm("v_add_f32 %0, %1, %2" : "=v"(ps1) : "v"(ps1), "v"(p1));
+        sacc[st][e] = p0;
+        sacc[st][e + 1] = p1;
       }
     }
-    float psum = psum2.x + psum2.y;
+    float psum = ps0 + ps1;
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
 
@@ -296,7 +344,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
         }
       }
     }
+#ifdef AIGV_ATTN_STAMP
+    asm volatile("" :: "v"(oacc[0][0]));     // the stamp below must not move in front of the last MFMA's result
+    {
+      STAMP(t4);
+      STAMP_ADD(6, t3, t4);
+      if (lane == 0) st_acc[8] += 1;
+    }
+#endif
   }
+  STAMP(t_epi);
 
   if (ksplit) {
     // ---- merge the NW key-split states: waves 1.. publish (m, l, O^T) in the K/V ring (free now), wave 0 combines in wave order ----
@@ -347,6 +404,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
         *(u16x4*)(op + 32 * dt + 8 * e4 + 4 * h) = o;
       }
   }
+#ifdef AIGV_ATTN_STAMP
+  {
+    STAMP(t_end);
+    STAMP_ADD(7, t_epi, t_end);
+    if (lane == 0) {
+      st_acc[1] = t_end - t_begin;
+      st_acc[0] = 1;
+      for (int i = 0; i < 9; ++i) atomicAdd(&g_attn_stamp[D == 64 ? 0 : 1][blockIdx.x % STAMP_REPL][i], st_acc[i]);
+    }
+  }
+#endif
 }
 
 // ---- decode attention (q_len = 1 per sequence) against the KV cache: split-KV, two passes ------------------------
@@ -518,6 +586,27 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __r
 
 }  // namespace
 
+#ifdef AIGV_ATTN_STAMP
+extern "C" int aigv_debug_attn_stamps(unsigned long long* out32, int reset) {   // diagnostic build only: 2 x 16 accumulators
+  static unsigned long long host[2][STAMP_REPL][16];
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (out32) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamp), sizeof host) != hipSuccess) return -2;
+    for (int d = 0; d < 2; ++d)
+      for (int i = 0; i < 16; ++i) {
+        unsigned long long t = 0;
+        for (int r = 0; r < STAMP_REPL; ++r) t += host[d][r][i];
+        out32[d * 16 + i] = t;
+      }
+  }
+  if (reset) {
+    memset(host, 0, sizeof host);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp), host, sizeof host) != hipSuccess) return -2;
+  }
+  return 0;
+}
+#endif
+
 const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
   if (head_dim != 64 && head_dim != 128) return "attention: head_dim must be 64 or 128";
   if (a.n_seq <= 0 || a.max_len <= 0) return "attention: empty problem";
@@ -531,7 +620,7 @@ const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
   return nullptr;
 }
 
-int g_attn_waves = 0;   // 0 = per-shape default; forced for A/B experiments: 4 / 8 = the 32-row kernel with that many waves, 64 = the 64-row kernel
+int g_attn_waves = 0;   // 0 = default (4 waves, two-deep ring); forced for A/B experiments: 4 / 8 waves, 43 / 83 = with a three-deep ring
 
 // NB = 2: deeper rings (3, 4 buffers) measured 5-15 % slower on the ViT shape - they cost resident workgroups (LDS), and
 // with four workgroups per CU the wait for the next tile is already covered by the others' work
@@ -567,26 +656,23 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
   return nw == 8 ? launch_attn<128, false, 8>(a, s) : launch_attn<128, false, 4>(a, s);
 }
 
-// Which kernel runs.  Default: the one-tile-at-a-time kernel above, for every shape.  The software-pipelined kernel of attention64.hip
-// wins the ISOLATED A/B on the non-causal shapes (scripts/attn_bench.py with AB_WAVES=1, profiles/r2_attn_ab.txt: 824-844 vs 753-784
-// TFLOP/s on 32 x 1024 rows at d = 64, the same launch repeated on inputs that then sit in the Infinity Cache) but loses it INSIDE the
-// scorer's step (bench.py --attn-kernel 0 / 4 / 64 on one box, profiles/r2_attn_inmodel_ab.txt: InternViT attention 5.03 vs 4.75 ms per
-// step, body 204 us per layer against 165 us isolated): with two workgroups of four waves per CU it hides less of the latency of
-// q / k / v rows that the qkv GEMM has only just written.  Causal shapes: 766 vs 802 TFLOP/s isolated.  It stays reachable through
-// aigv_tune_attention(64) (tests, A/B); uniform sequences whose last 256-row block holds at most 32 rows (1025 = 4 x 256 + 1) then
-// run that block on the kernel above in its key-split form over a compact grid.  4 / 8 force the kernel above with that many waves.
-hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
-  if (g_attn_waves != 64) return launch_attention32(a, head_dim, s);
-  const int rem = a.max_len % 256;
-  if (!a.causal && a.uniform_len && a.q_tail == 0 && a.max_len > 256 && rem > 0 && rem <= 32) {
-    AttnArgs body = a, tail = a;
-    body.q_end = a.max_len - rem;
-    tail.q_begin = a.max_len - rem;
-    hipError_t e = aigv_launch_attention64(body, head_dim, s);
-    if (e != hipSuccess) return e;
-    return launch_attention32(tail, head_dim, s);
+// The one kernel above runs every shape.  A software-pipelined 64-rows-per-wave kernel (round 2, attention64.hip) won the isolated
+// A/B by 7 % and lost the in-step one by 6 % twice (profiles/r2_attn_ab.txt, r2_attn_inmodel_ab.txt) and was removed in round 3; so
+// did three-deep K/V rings (profiles/r3_attn_ring_negative.txt).  aigv_tune_attention: 4 / 8 waves per workgroup, 43 / 83 = with a
+// three-deep ring (A/B only).
+hipError_t aigv_launch_attention(const AttnArgs& a_in, int head_dim, hipStream_t s) {
+  AttnArgs a = a_in;
+  {
+    // A power-of-two query pre-scale (InternViT: d^-1/2 = 2^-3) commutes exactly with the bf16 rounding of q and with the fp32 dot
+    // products, so it is folded into the softmax's exp2 scale instead of being applied to every query element: the same bits
+    // (the scores the kernel sees are 2^k times larger, their scale 2^k times smaller), ~100 fewer VALU instructions per wave.
+    int ex = 0;
+    if (a.q_prescale > 0.f && a.q_prescale != 1.0f && frexpf(a.q_prescale, &ex) == 0.5f && ex > -60 && ex < 60) {
+      a.post_div = a.post_div / a.q_prescale;
+      a.q_prescale = 1.0f;
+    }
   }
-  return aigv_launch_attention64(a, head_dim, s);
+  return launch_attention32(a, head_dim, s);
 }
 
 size_t aigv_attention_decode_ws_floats(int n_seq, int n_kv, int g, int cap) {

@@ -1,4 +1,4 @@
-// LDS images of the K / V tiles shared by the attention kernels (attention.hip, attention64.hip): 64-key tiles of D-wide bf16 rows,
+// LDS images of the K / V tiles of the attention kernel (attention.hip): 64-key tiles of D-wide bf16 rows,
 // filled by LDS-DMA (lane-linear destination, so the bank swizzle is applied to the per-lane SOURCE chunk and again on the read).
 #pragma once
 

@@ -83,12 +83,10 @@ struct AttnArgs {
   int q_tail;                   // > 0: only the last q_tail query rows of every sequence are computed (others left unwritten)
   int uniform_len;              // every sequence has max_len rows (InternViT frames): lets the dispatcher split the query rows between kernels
   // row range of ONE kernel launch (set by aigv_launch_attention when it splits the rows between the two kernels; 0 = no limit):
-  int q_begin;                  // attention.hip's 32-row-per-wave kernel computes query rows >= q_begin (a multiple of 256) only
-  int q_end;                    // attention64.hip's 64-row-per-wave kernel computes query rows < q_end only
+  int q_begin;                  // the kernel computes query rows >= q_begin (a multiple of the workgroup's rows) only; 0 everywhere at present
 };
 const char* aigv_attn_check(const AttnArgs& a, int head_dim);
 hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s);
-hipError_t aigv_launch_attention64(const AttnArgs& a, int head_dim, hipStream_t s);   // attention64.hip: 4 waves x 64 query rows, one wave per SIMD
 // decode: one query row per sequence (fused qkv row), KV cache [seq][kv head][cap][D]; split-KV two-pass kernel,
 // ws = aigv_attention_decode_ws_floats(...) floats of scratch
 size_t aigv_attention_decode_ws_floats(int n_seq, int n_kv, int g, int cap);

@@ -398,10 +398,10 @@ def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False):
     return out.cpu().view(T, h, d)
 
 
-# kernel: 0 = the dispatcher's choice (with the uniform-length hint where the lengths are equal: the 1025-row ViT shape then runs
-# its 1024 full rows on the pipelined kernel and the left-over row on the key-split kernel), 4 = the one-tile-at-a-time kernel
-# (attention.hip), 64 = the software-pipelined kernel (attention64.hip) for every row, short blocks and ragged tiles included
-@pytest.mark.parametrize("kernel", [0, 4, 64])
+# kernel (aigv_tune_attention): 0 = the default form (4 waves per workgroup, two-deep K/V ring; with the uniform-length hint where the
+# lengths are equal, so that the 1025-row ViT shape runs its left-over row in the key-split form), 8 = 8 waves per workgroup,
+# 43 = a three-deep ring (the forms kept for A/B)
+@pytest.mark.parametrize("kernel", [0, 8, 43])
 @pytest.mark.parametrize("d,causal,h,hk,lens", [
     (64, False, 2, 2, [1025, 1025, 1025]),       # ViT: 448 px frames, cls tail row
     (64, False, 3, 3, [257, 257]),               # ViT: 224 px
