@@ -18,7 +18,9 @@ SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "rowops.hip", 
 HEADERS = ["common.h", "kernels.h", "attn_lay.h", os.path.join("..", "..", "include", "aigv_amd.h")]
 OUT = os.path.join(HERE, "libaigv_amd.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-EXTRA_FLAGS = {}      # per-file additions (none at present)
+# per-file additions.  The attention kernels' softmax is written one score at a time on purpose (v_pk_*_f32 is slower beside MFMAs): keep
+# hipcc's SLP vectoriser from re-packing it
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 
 
 def _mtime(p: str) -> float:

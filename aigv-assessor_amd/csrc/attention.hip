@@ -297,21 +297,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     const float mc = (m_run == -INFINITY) ? 0.f : m_run * sc;
     // (the loop is VALU-issue-bound: SQ counters in profiles/r1_attn_sq.txt, phase stamps in profiles/r3_attn_stamps.txt); raw
     // v_exp_f32: p underflows to 0, no fix-up needed
-    // One v_fma_f32 / v_add_f32 per score, through asm so that hipcc's SLP pass cannot re-pack them into v_pk_*_f32: the packed forms
-    // halve the instruction count but not the issue time (the guide prices them as an anti-lever beside MFMAs); in-step A/B round 3:
-    // InternViT attention 4.94 -> 4.85 ms, InternLM2 7.17 -> 7.12 ms per step (profiles/r3_attn_stamps.txt).  Two running sums.
+    // One v_fma_f32 / v_add_f32 per score (the file is built with -fno-slp-vectorize so that hipcc does not re-pack them into
+    // v_pk_*_f32: the packed forms halve the instruction count but not the issue time - the guide prices them as an anti-lever beside
+    // MFMAs).  Plain C, not inline asm: hipcc inserts the wait state a VALU read of a v_exp_f32 result needs only for instructions it
+    // can see (an asm v_add_f32 right behind the v_exp_f32 summed stale registers).  Two running sums.
     float ps0 = 0.f, ps1 = 0.f;
     const float nmc = -mc;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        float t0, t1;
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(sacc[st][e]), "v"(sc), "v"(nmc));
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(sacc[st][e + 1]), "v"(sc), "v"(nmc));
-        const float p0 = __builtin_amdgcn_exp2f(t0), p1 = __builtin_amdgcn_exp2f(t1);
-        asm("v_add_f32 %0, %1, %2" : "=v"(ps0) : "v"(ps0), "v"(p0));
-        asm("v_add_f32 %0, %1, %2" : "=v"(ps1) : "v"(ps1), "v"(p1));
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[st][e], sc, nmc));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[st][e + 1], sc, nmc));
+        ps0 += p0;
+        ps1 += p1;
         sacc[st][e] = p0;
         sacc[st][e + 1] = p1;
       }
@@ -658,8 +657,8 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
 
 // The one kernel above runs every shape.  A software-pipelined 64-rows-per-wave kernel (round 2, attention64.hip) won the isolated
 // A/B by 7 % and lost the in-step one by 6 % twice (profiles/r2_attn_ab.txt, r2_attn_inmodel_ab.txt) and was removed in round 3; so
-// did three-deep K/V rings (profiles/r3_attn_ring_negative.txt).  aigv_tune_attention: 4 / 8 waves per workgroup, 43 / 83 = with a
-// three-deep ring (A/B only).
+// did three-deep K/V rings (profiles/r3_attn_ring_negative.txt) and an 8-wave kernel with role-alternating halves (round 3,
+// profiles/r3_attn8_negative.txt).  aigv_tune_attention: 4 / 8 waves per workgroup, 43 / 83 = with a three-deep ring (A/B only).
 hipError_t aigv_launch_attention(const AttnArgs& a_in, int head_dim, hipStream_t s) {
   AttnArgs a = a_in;
   {

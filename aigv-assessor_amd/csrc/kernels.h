@@ -83,7 +83,7 @@ struct AttnArgs {
   int q_tail;                   // > 0: only the last q_tail query rows of every sequence are computed (others left unwritten)
   int uniform_len;              // every sequence has max_len rows (InternViT frames): lets the dispatcher split the query rows between kernels
   // row range of ONE kernel launch (set by aigv_launch_attention when it splits the rows between the two kernels; 0 = no limit):
-  int q_begin;                  // the kernel computes query rows >= q_begin (a multiple of the workgroup's rows) only; 0 everywhere at present
+  int q_begin;                  // the launch computes query rows >= q_begin (a multiple of the workgroup's 128 rows) only; 0 everywhere at present
 };
 const char* aigv_attn_check(const AttnArgs& a, int head_dim);
 hipError_t aigv_launch_attention(const AttnArgs& a, int head_dim, hipStream_t s);

@@ -19,10 +19,11 @@ if sys.argv[1:2] == ["build"]:
     b = importlib.import_module("aigv_assessor_amd.build")
     b.build()
     os.makedirs(OUT, exist_ok=True)
-    objs = [os.path.join(PKG, "build", s.replace(".hip", ".o")) for s in b.SOURCES if s != "attention.hip"]
+    SRC = os.environ.get("ATTN_VARIANT_SRC", "attention.hip")      # which source the variant flags apply to
+    objs = [os.path.join(PKG, "build", s.replace(".hip", ".o")) for s in b.SOURCES if s != SRC]
     o = os.path.join(OUT, "attention_stamp.o")
     flags = sys.argv[2:] if os.environ.get("ATTN_VARIANT_LIB") else ["-DAIGV_ATTN_STAMP"] + sys.argv[2:]     # a named variant library carries only the flags given
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.FLAGS + flags + ["-c", os.path.join(PKG, "csrc", "attention.hip"), "-o", o])
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.FLAGS + b.EXTRA_FLAGS.get(SRC, []) + flags + ["-c", os.path.join(PKG, "csrc", SRC), "-o", o])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [o])
     os.remove(o)
     print("built", LIB)
@@ -34,6 +35,7 @@ else:
     from aigv_assessor_amd import native, synth
     from aigv_assessor_amd.modeling import InternVLChatModel
     lib = native.load()
+    K8 = 0
     dbg = lib.aigv_debug_attn_stamps
     dbg.restype, dbg.argtypes = ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     cfg = pkg.internvl2_8b()
