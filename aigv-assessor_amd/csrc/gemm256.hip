@@ -49,6 +49,17 @@ namespace {
 
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// Diagnostic build only (-DAIGV_GEMM_STAMP, scripts/gemm_stamp.py): cycles per wave in the prologue (tile mapping, first DMA, wait for the
+// first units), the K loop and the epilogue, per epilogue kind and K-tile count class, summed over all waves of all launches.
+// g_gemm_stamp[EPI][nk <= 16 ? 0 : 1][replica][0 waves, 1 total, 2 prologue, 3 K loop, 4 epilogue, 5 K tiles].  Never defined in the product build.
+#ifdef AIGV_GEMM_STAMP
+constexpr int GSTAMP_REPL = 1024;
+__device__ unsigned long long g_gemm_stamp[8][2][GSTAMP_REPL][8];
+#define GSTAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define GSTAMP(var)
+#endif
+
 __device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uniform
   if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -72,6 +83,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2, wc = wave & 3;
+  GSTAMP(gs_begin);
 
   // ---- tile mapping: XCD-aware bijective remap, then groups of GROUP_M256 row-tiles sweep the column tiles ----
   const int nbm = (p.M + TM - 1) / TM, nbn = p.N / TN;
@@ -295,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 
   using T = std::true_type;
   using F = std::false_type;
+  GSTAMP(gs_loop);
   int t = 0;
   for (; t + 3 < nk; t += 2) {   // tiles t, t+1 issue units of tiles <= t+3: all in range
     tile_body(t, I0{}, T{});
@@ -305,6 +318,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     if (t + 1 < nk) tile_body(t + 1, I1{}, F{});
   }
   if (g == 0) RAW_BARRIER();   // balance the stagger barrier
+#ifdef AIGV_GEMM_STAMP
+  asm volatile("" :: "v"(acc[0][0][0][0][0]), "v"(acc[1][3][1][1][3]));
+  const unsigned long long gs_epi = __builtin_readcyclecounter();
+  auto gstamp_finish = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the epilogue's stores have been acknowledged: what the workgroup's exit waits for
+    const unsigned long long gs_end = __builtin_readcyclecounter();
+    if (lane == 0) {
+      unsigned long long* d = g_gemm_stamp[EPI < 8 ? EPI : 7][nk <= 16 ? 0 : 1][blockIdx.x % GSTAMP_REPL];
+      atomicAdd(d + 0, 1ull); atomicAdd(d + 1, gs_end - gs_begin); atomicAdd(d + 2, gs_loop - gs_begin);
+      atomicAdd(d + 3, gs_epi - gs_loop); atomicAdd(d + 4, gs_end - gs_epi); atomicAdd(d + 5, (unsigned long long)nk);
+    }
+  };
+#define GSTAMP_FINISH() gstamp_finish()
+#else
+#define GSTAMP_FINISH()
+#endif
 
   if constexpr (EPI == EPI_PARTIAL) {
     // ---- split-K slice: fp32 partial sums into slab blockIdx.y ([M][N], the layout gemm_finalize_kernel sums) ----
@@ -326,6 +355,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             *(f32x4*)(row + nh * 32 + nt * 16) = v;
           }
       }
+    GSTAMP_FINISH();
     return;
   } else if constexpr (RESID_PF) {
     // ---- residual epilogue: residual from LDS (prefetched), output staged 16 rows at a time in the wave's private region ----
@@ -390,6 +420,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         }
       }
     }
+    GSTAMP_FINISH();
     return;
   } else if constexpr ((VAR & 4) != 0) {
     // ---- LDS-staged epilogue ------------------------------------------------------------------------------------
@@ -504,6 +535,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         }
       }
     }
+    GSTAMP_FINISH();
     return;
   }
   // ---- epilogue: lane owns C[m][n .. n+3] ----
@@ -574,6 +606,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           }
       }
     }
+  GSTAMP_FINISH();
 }
 
 template <int EPI, int VAR>
@@ -608,6 +641,28 @@ hipError_t launch256v(const GemmArgs& a, int epi, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef AIGV_GEMM_STAMP
+extern "C" int aigv_debug_gemm_stamps(unsigned long long* out /*[8][2][8]*/, int reset) {   // diagnostic build only
+  static unsigned long long host[8][2][GSTAMP_REPL][8];
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (out) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamp), sizeof host) != hipSuccess) return -2;
+    for (int e = 0; e < 8; ++e)
+      for (int c = 0; c < 2; ++c)
+        for (int i = 0; i < 8; ++i) {
+          unsigned long long t = 0;
+          for (int r = 0; r < GSTAMP_REPL; ++r) t += host[e][c][r][i];
+          out[(e * 2 + c) * 8 + i] = t;
+        }
+  }
+  if (reset) {
+    for (auto& a : host) for (auto& b : a) for (auto& c : b) for (auto& d : c) d = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamp), host, sizeof host) != hipSuccess) return -2;
+  }
+  return 0;
+}
+#endif
 
 int g_gemm256_variant = 1;   // balanced reads + no s_setprio + LDS-staged epilogue: fastest in interleaved A/B (profiles/r1_gemm_variants.txt)
 
