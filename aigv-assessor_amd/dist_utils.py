@@ -114,11 +114,13 @@ def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch
 
 def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
                    image_flags: Optional[torch.Tensor], labels: torch.Tensor, motion_feature: Optional[torch.Tensor],
-                   mos: Optional[torch.Tensor] = None, group=None) -> Dict[str, torch.Tensor]:
+                   mos: Optional[torch.Tensor] = None, group=None, prefer_gathered: bool = False) -> Dict[str, torch.Tensor]:
     """Score a batch of B clips (F frames in total) over all ranks of `group`; every rank passes the same host
     tensors and gets the full result: {'score1' [B], 'logit' [B*(N-1)], 'label' [B*(N-1)]}.
 
-    `model` is an InternVLChatModel (or any object with vit_tokens / forward(visual_tokens=...) / device / stage)."""
+    `model` is an InternVLChatModel (or any object with vit_tokens / forward(visual_tokens=...) / device / stage).
+    ``prefer_gathered``: always feed the projector / LLM pass from the ALL-GATHERED token buffer, also where the rank's own shard would
+    do (it then waits for the collective instead of overlapping it) - the form in which the collective's output is what gets scored."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B, N = input_ids.shape
@@ -155,7 +157,7 @@ def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, a
     n1 = N - 1
     score_l = torch.zeros((chi - clo,), dtype=torch.float32, device=dev)
     logit_l = torch.full(((chi - clo) * n1,), -1, dtype=torch.long, device=dev)
-    own = chi > clo and lo <= clo * fpc and chi * fpc <= hi
+    own = chi > clo and lo <= clo * fpc and chi * fpc <= hi and not prefer_gathered
     tokens = None if own else finish_tokens()
     if chi > clo:
         vis = local[clo * fpc - lo: chi * fpc - lo] if own else tokens[fl]

@@ -50,8 +50,11 @@ def main():
     plain = model(mos=None, pixel_values=pv, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"], image_flags=flags,
                   labels=toks["labels"], motion_feature=motion)
     dp = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion)
+    # the same with the LLM pass fed from the buffer the RCCL all-gather produced (not from the rank's own shard)
+    dpg = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion, prefer_gathered=True)
     torch.cuda.synchronize()
     assert torch.equal(dp["score1"], plain["score1"]) and torch.equal(dp["logit"], plain["logit"]) and torch.equal(dp["label"], plain["label"])
+    assert torch.equal(dpg["score1"], plain["score1"]) and torch.equal(dpg["logit"], plain["logit"])
     # 3. a rank-0-style reduction the driver uses (bench.py: all_reduce(MAX) of the step time)
     t = torch.tensor([1.5], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

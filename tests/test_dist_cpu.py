@@ -61,14 +61,14 @@ def _case(B=3, T=2):
     return cfg, sd, toks, pv, motion, B, T
 
 
-def _worker(rank, world, port, q, use_branch=False, n_clips=3, n_frames=2):
+def _worker(rank, world, port, q, use_branch=False, n_clips=3, n_frames=2, prefer_gathered=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     dist_utils.init_dist("pytorch", backend="gloo")
     cfg, sd, toks, pv, motion, B, T = _case(n_clips, n_frames)
     model = OracleBackedModel(cfg, sd, toks["img_context_token_id"])
     out = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
-                                    toks["labels"], None if use_branch else motion)
+                                    toks["labels"], None if use_branch else motion, prefer_gathered=prefer_gathered)
     q.put((rank, out["score1"].float().tolist(), out["logit"].tolist()))
     dist.barrier()
     dist.destroy_process_group()
@@ -78,10 +78,12 @@ def _worker(rank, world, port, q, use_branch=False, n_clips=3, n_frames=2):
 # frames: every rank's clips lie inside its own frame shard, so the LLM pass overlaps the token all-gather), a clip count the
 # ranks do not divide (5 clips, 10 frames -> 3+3+2+2 frames, 2+1+1+1 clips), and fewer clips than ranks (2 clips on 4 ranks)
 @pytest.mark.parametrize("world,use_branch,n_clips,n_frames", [(2, False, 3, 2), (2, True, 3, 2), (2, True, 1, 2), (2, False, 4, 2),
-                                                                (4, True, 8, 16), (4, False, 5, 2), (4, True, 2, 4)])
+                                                                (4, True, 8, 16), (4, False, 5, 2), (4, True, 2, 4), (2, False, -4, 2)])
 def test_frame_dp_equals_single_process(world, use_branch, n_clips, n_frames):
     """use_branch: motion_feature=None - every rank runs the model's own motion branch on the frames of ITS clips (the native SlowFast
     branch in the product; a frame-dependent stand-in here)."""
+    prefer_gathered = n_clips < 0        # (a negative clip count marks the case that scores from the all-gathered buffer on every rank)
+    n_clips = abs(n_clips)
     cfg, sd, toks, pv, motion, B, T = _case(n_clips, n_frames)
     if use_branch:
         motion = _clip_feature(pv, B, cfg.motion_dim)
@@ -93,7 +95,7 @@ def test_frame_dp_equals_single_process(world, use_branch, n_clips, n_frames):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, use_branch, n_clips, n_frames)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, use_branch, n_clips, n_frames, prefer_gathered)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
