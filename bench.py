@@ -429,6 +429,19 @@ def main():
         out = step()
     fence()
     dt = time.perf_counter() - t0
+    # host side of a step: how long the launching thread needs to ENQUEUE one step on an idle GPU (no synchronisation inside; the GPU
+    # then works through it).  The step is GPU-bound as long as this stays well under ms_per_step; on a contended host it is the first
+    # thing to look at (a box of the pool once returned 282 ms/step with every kernel class at its usual duration).
+    host_enqueue_ms = None
+    if not dry:
+        hs = []
+        for _ in range(3):
+            fence()
+            th = time.perf_counter()
+            out = step()
+            hs.append((time.perf_counter() - th) * 1e3)
+        fence()
+        host_enqueue_ms = sorted(hs)[1]
     # ---- roofline pass: the same K steps again with one HIP-event pair around every GEMM / attention launch on the
     # launch stream.  Kept out of the timed region above because ~900 event records per step cost ~10 % of wall time;
     # the per-launch durations themselves are unaffected (they agree with the rocprofv3 kernel trace in profiles/).
@@ -475,6 +488,7 @@ def main():
             "slowfast_tflop_per_clip": (model.slowfast_model.flops_per_clip() / 1e12 if args.motion == "slowfast" and not dry else 0.0),   # not in the figures below
             "algorithmic_tflop_per_clip": fl["total"] / 1e12,
             "executed_tflop_per_clip": (fl["total"] if args.all_rows else fl["executed"]) / 1e12,
+            "host_enqueue_ms_per_step": host_enqueue_ms,
             "achieved_tflops_whole_step_per_gpu": (fl["total"] if args.all_rows else fl["executed"]) * B / dt / 1e12 / world * args.steps,
         }
         if prof:

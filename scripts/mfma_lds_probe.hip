@@ -68,6 +68,142 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe_kernel(const uint
   if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// The same wave tile built from v_mfma_f32_32x32x16_bf16 (MT x NT tiles of 32x32, K-step 16): identical LDS fragment bytes per FLOP,
+// half the MFMA instructions, half the A/B operand register reads, accumulators twice as large per instruction (round 3: is the MFMA
+// SHAPE an energy lever?).  Lane layout of a fragment: row = lane & 31, 16-B chunk = 2 * k16 + (lane >> 5).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int MT, int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe32_kernel(const uint4* __restrict__ src, float* __restrict__ out, int iters,
+                                                                         unsigned long long* __restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 65536 / 16; i += WAVES * 64) ((uint4*)smem)[i] = src[(blockIdx.x * 131 + i) & 4095];
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5, sw = fr & 7;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+  int off[4];
+#pragma unroll
+  for (int k16 = 0; k16 < 4; ++k16) off[k16] = fr * 128 + (((k16 * 2 + fh) ^ sw) * 16);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+    const char* base = smem + ((it + wave) & 1) * 32768;
+#pragma unroll
+    for (int k16 = 0; k16 < 4; ++k16) {
+      bf16x8 fa[MT], fb[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fa[m] = *(const bf16x8*)(base + off[k16] + (m & 3) * 4096);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) fb[n] = *(const bf16x8*)(base + 16384 + off[k16] + (n & 3) * 4096);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n], fa[m], acc[m][n], 0, 0, 0);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += acc[m][n][e];
+  out[blockIdx.x * WAVES * 64 + tid] = s;
+  if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+// register-only forms (no LDS reads inside the loop): what the MFMA pipe alone sustains for each shape
+template <int SHAPE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe_reg_kernel(const uint4* __restrict__ src, float* __restrict__ out, int iters,
+                                                                           unsigned long long* __restrict__ stamps) {
+  const int tid = threadIdx.x;
+  bf16x8 fa[4], fb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    fa[i] = __builtin_bit_cast(bf16x8, src[(tid * 8 + i) & 4095]);
+    fb[i] = __builtin_bit_cast(bf16x8, src[(tid * 8 + 4 + i) & 4095]);
+  }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  if constexpr (SHAPE == 16) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[(n + kh) & 3], fa[(m + kh) & 3], acc[m][n], 0, 0, 0);
+      asm volatile("" : "+v"(fa[0]), "+v"(fb[0]));
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+  } else {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[(n + k16) & 3], fa[(m + k16) & 3], acc[m][n], 0, 0, 0);
+      asm volatile("" : "+v"(fa[0]), "+v"(fb[0]));
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[m][n][e];
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  out[blockIdx.x * WAVES * 64 + tid] = s;
+  if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <typename K>
+void run_generic(const char* name, K kern, int waves, double flops, const uint4* src, float* out, unsigned long long* stamps, int iters) {
+  const int blocks = 256;
+  CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), 65536, 0, src, out, iters, stamps);
+  CHECK(hipDeviceSynchronize());
+  const int reps = 20;
+  CHECK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), 65536, 0, src, out, iters, stamps);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipDeviceSynchronize());
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  std::vector<unsigned long long> h(2 * blocks);
+  CHECK(hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost));
+  double clk = 0;
+  for (int b = 0; b < blocks; ++b) clk += (double)h[2 * b] / (double)h[2 * b + 1] * 100.0;   // MHz
+  clk /= blocks;
+  printf("%-60s %7.3f ms  %7.1f TFLOP/s  in-kernel clock %6.0f MHz\n", name, ms, flops * blocks / (ms * 1e-3) / 1e12, clk);
+}
+
 template <int MT, int NT, int WAVES>
 void run(const char* name, const uint4* src, float* out, unsigned long long* stamps, int iters) {
   const int blocks = 256;
@@ -117,6 +253,11 @@ int main() {
     run<8, 4, 8>("128x64 wave tile, 8 waves (2 per SIMD)", src, out, stamps, iters);
     run<8, 8, 4>("128x128 wave tile, 4 waves (1 per SIMD)", src, out, stamps, iters / 2);
     run<4, 4, 8>("64x64 wave tile, 8 waves", src, out, stamps, iters * 2);
+    // MFMA shape (round 3): per workgroup and iteration 8 waves x 128x64x64 either way
+    const double fl = 2.0 * 128 * 64 * 64 * 8 * (double)iters;
+    run_generic("128x64 wave tile from 32x32x16 MFMAs + LDS reads, 8 waves", probe32_kernel<4, 2, 8>, 8, fl, src, out, stamps, iters);
+    run_generic("registers only, 16x16x32 (32 MFMAs per K-64), 8 waves", probe_reg_kernel<16, 8>, 8, fl, src, out, stamps, iters);
+    run_generic("registers only, 32x32x16 (16 MFMAs per K-64... x2), 8 waves", probe_reg_kernel<32, 8>, 8, fl, src, out, stamps, iters);
   }
   return 0;
 }
