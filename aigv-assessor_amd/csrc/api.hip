@@ -1050,6 +1050,52 @@ static int final_rows(aigv_ctx* c, float* score, int B, int R, int64_t* argmax, 
   return 0;
 }
 
+// ---- the two halves of an InternLM2 decoder layer around its attention, shared by aigv_llm_prefill and aigv_llm_extend (rows of
+// c->l_h, T of them).  fp8 mode: every linear of the layer in e4m3 except the post-attention half of the LAST layer (wo, w1|w3, w2
+// there act on the few consumed rows - weight streaming, nothing for fp8 MFMA to gain - and stay bf16 with or without row trimming).
+// attention_norm -> wqkv -> RoPE on K in place (one of g + 2 slots per group; the query heads are rotated by the attention kernel as
+// it loads them)
+static int llm_layer_qkv(aigv_ctx* c, int li, int T, hipStream_t s) {
+  const aigv_config& k = c->cfg;
+  const LlmLayer& L = c->llm[li];
+  const int H = k.llm_hidden, D = c->head_dim, g = c->g, nkv = k.llm_kv_heads;
+  if (c->fp8_llm) {
+    HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.an, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
+    TRY(run_gemm_fp8(c, nullptr, H, H, c->llm8[li].wqkv, c->llm8[li].s_wqkv, c->l_qkv, c->qkv_out, T, c->qkv_out, EPI_STORE, nullptr, 0, s));
+  } else {
+    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
+    TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
+  }
+  HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, 1, g + 2, nkv, D, s, g));
+  return 0;
+}
+
+// h += wo(attention output);  h += w2(silu(w1 n) * w3 n), n = ffn_norm(h)
+static int llm_layer_post(aigv_ctx* c, int li, int T, hipStream_t s) {
+  const aigv_config& k = c->cfg;
+  const LlmLayer& L = c->llm[li];
+  const int H = k.llm_hidden, I = k.llm_inter;
+  if (c->fp8_llm && li != k.llm_layers - 1) {
+    const LlmLayerFp8& Q = c->llm8[li];
+    TRY(run_gemm_fp8(c, c->l_ao, H, H, Q.wo, Q.s_wo, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
+    HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.fn, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
+    TRY(run_gemm_fp8(c, nullptr, H, H, Q.w13, Q.s_w13, c->l_ffn, I, T, 2 * I, EPI_SWIGLU, nullptr, 0, s));
+    TRY(run_gemm_fp8(c, c->l_ffn, I, I, Q.w2, Q.s_w2, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
+    return 0;
+  }
+  {
+    GemmArgs a = gemm_args(c->l_ao, H, L.wo, H, c->l_h, H, T, H, H);
+    a.resid = c->l_h; a.ldr = H;
+    TRY(run_gemm(c, a, EPI_RESID, s));
+  }
+  HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, T, H, k.rms_eps, nullptr, s));
+  TRY(run_gemm(c, gemm_args(c->l_t, H, L.w13, H, c->l_ffn, I, T, 2 * I, H), EPI_SWIGLU, s));
+  GemmArgs a = gemm_args(c->l_ffn, I, L.w2, I, c->l_h, H, T, H, I);
+  a.resid = c->l_h; a.ldr = H;
+  TRY(run_gemm(c, a, EPI_RESID, s));
+  return 0;
+}
+
 int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const int32_t* cu, int B, const void* vis,
                      int n_vis, const void* motion, const int32_t* score_rows, float* score, const int32_t* logit_rows,
                      int R, int64_t* argmax, int keep_kv, void* stream) {
@@ -1098,18 +1144,7 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
   for (int li = 0; li < k.llm_layers; ++li) {
     const LlmLayer& L = c->llm[li];
-    // fp8 mode: every linear of the layer except the post-attention half of the LAST layer (wo, w1|w3, w2 there act on the few
-    // consumed rows - weight streaming, nothing for fp8 MFMA to gain - and stay bf16 with or without row trimming)
-    const bool f8 = c->fp8_llm, f8_post = f8 && li != k.llm_layers - 1;
-    if (f8) {
-      HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.an, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
-      TRY(run_gemm_fp8(c, nullptr, H, H, c->llm8[li].wqkv, c->llm8[li].s_wqkv, c->l_qkv, c->qkv_out, T, c->qkv_out, EPI_STORE, nullptr, 0, s));
-    } else {
-      HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
-      TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
-    }
-    // RoPE: K in place (one of g + 2 slots per group); the query heads are rotated by the attention kernel as it loads them
-    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, 1, g + 2, nkv, D, s, g));
+    TRY(llm_layer_qkv(c, li, T, s));
     if (keep_kv)
       HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, T,
                                      nkv, g, D, k.kv_capacity, s));
@@ -1142,26 +1177,7 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       TRY(final_rows(c, score, B, R, argmax, t_h, true, s));
       break;
     }
-    if (f8_post) {
-      const LlmLayerFp8& Q = c->llm8[li];
-      TRY(run_gemm_fp8(c, c->l_ao, H, H, Q.wo, Q.s_wo, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
-      HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.fn, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
-      TRY(run_gemm_fp8(c, nullptr, H, H, Q.w13, Q.s_w13, c->l_ffn, I, T, 2 * I, EPI_SWIGLU, nullptr, 0, s));
-      TRY(run_gemm_fp8(c, c->l_ffn, I, I, Q.w2, Q.s_w2, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
-      continue;
-    }
-    {
-      GemmArgs a = gemm_args(c->l_ao, H, L.wo, H, c->l_h, H, T, H, H);
-      a.resid = c->l_h; a.ldr = H;
-      TRY(run_gemm(c, a, EPI_RESID, s));
-    }
-    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, T, H, k.rms_eps, nullptr, s));
-    TRY(run_gemm(c, gemm_args(c->l_t, H, L.w13, H, c->l_ffn, I, T, 2 * I, H), EPI_SWIGLU, s));
-    {
-      GemmArgs a = gemm_args(c->l_ffn, I, L.w2, I, c->l_h, H, T, H, I);
-      a.resid = c->l_h; a.ldr = H;
-      TRY(run_gemm(c, a, EPI_RESID, s));
-    }
+    TRY(llm_layer_post(c, li, T, s));
   }
   if (!trim) TRY(final_rows(c, score, B, R, argmax, c->l_h, false, s));
   if (keep_kv) {
@@ -1208,7 +1224,7 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
   if ((score && !score_rows) || (R > 0 && (!logit_rows || !argmax))) return fail(c, AIGV_ERR_ARG, "output rows/buffers inconsistent");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
-  const int H = k.llm_hidden, I = k.llm_inter, D = c->head_dim, g = c->g, nkv = k.llm_kv_heads;
+  const int H = k.llm_hidden, D = c->head_dim, g = c->g, nkv = k.llm_kv_heads;
   // positions continue after the cached tokens; the cached lengths are the per-sequence key offsets of the attention
   HIPCHK(c, aigv_launch_seqpos(cu, B, c->l_pos, c->l_seq, c->l_cu, T, s, c->h_kvlen.data()));
   HIPCHK(c, aigv_launch_write_ints(c->h_kvlen.data(), B, c->l_kvlen, s));
@@ -1218,19 +1234,9 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
   for (int b = 0; b < B; ++b) { const double n = cu[b + 1] - cu[b]; attn_flops += 4.0 * n * (c->h_kvlen[b] + (n + 1) / 2) * D * k.llm_heads; }
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
   for (int li = 0; li < k.llm_layers; ++li) {
-    const LlmLayer& L = c->llm[li];
-    // fp8 mode: the linears aigv_llm_prefill runs in e4m3 run in e4m3 here too (all but the post-attention half of the last layer),
-    // so a continuation scores like the same tokens inside one prefill of that mode
-    const bool f8 = c->fp8_llm, f8_post = f8 && li != k.llm_layers - 1;
-    if (f8) {
-      HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.an, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
-      TRY(run_gemm_fp8(c, nullptr, H, H, c->llm8[li].wqkv, c->llm8[li].s_wqkv, c->l_qkv, c->qkv_out, T, c->qkv_out, EPI_STORE, nullptr, 0, s));
-    } else {
-      HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
-      TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
-    }
-    // RoPE: K in place (one of g + 2 slots per group); the query heads are rotated by the attention kernel as it loads them
-    HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, 1, g + 2, nkv, D, s, g));
+    // (fp8 mode: the linears aigv_llm_prefill runs in e4m3 run in e4m3 here too, so a continuation scores like the same tokens inside
+    // one prefill of that mode)
+    TRY(llm_layer_qkv(c, li, T, s));
     HIPCHK(c, aigv_launch_kv_store(c->l_qkv, c->qkv_out, c->l_seq, c->l_pos, c->kc + li * kv_layer, c->vc + li * kv_layer, T, nkv, g, D,
                                    k.kv_capacity, s));
     {
@@ -1249,26 +1255,7 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
       ProfScope ps(c, AIGV_PROF_ATTN_LLM, attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
       HIPCHK(c, aigv_launch_attention(a, D, s));
     }
-    if (f8_post) {
-      const LlmLayerFp8& Q = c->llm8[li];
-      TRY(run_gemm_fp8(c, c->l_ao, H, H, Q.wo, Q.s_wo, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
-      HIPCHK(c, aigv_launch_rmsnorm_quant_fp8(c->l_h, H, L.fn, c->q8, H, c->q8_scale, T, H, k.rms_eps, s));
-      TRY(run_gemm_fp8(c, nullptr, H, H, Q.w13, Q.s_w13, c->l_ffn, I, T, 2 * I, EPI_SWIGLU, nullptr, 0, s));
-      TRY(run_gemm_fp8(c, c->l_ffn, I, I, Q.w2, Q.s_w2, c->l_h, H, T, H, EPI_RESID, c->l_h, H, s));
-      continue;
-    }
-    {
-      GemmArgs a = gemm_args(c->l_ao, H, L.wo, H, c->l_h, H, T, H, H);
-      a.resid = c->l_h; a.ldr = H;
-      TRY(run_gemm(c, a, EPI_RESID, s));
-    }
-    HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, T, H, k.rms_eps, nullptr, s));
-    TRY(run_gemm(c, gemm_args(c->l_t, H, L.w13, H, c->l_ffn, I, T, 2 * I, H), EPI_SWIGLU, s));
-    {
-      GemmArgs a = gemm_args(c->l_ffn, I, L.w2, I, c->l_h, H, T, H, I);
-      a.resid = c->l_h; a.ldr = H;
-      TRY(run_gemm(c, a, EPI_RESID, s));
-    }
+    TRY(llm_layer_post(c, li, T, s));
   }
   TRY(final_rows(c, score, B, R, argmax, c->l_h, false, s));
   if (commit) {

@@ -118,6 +118,60 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe32_kernel(const ui
   if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// 128x128 wave tile, ONE wave per SIMD, software-pipelined by hand: the 16 fragment reads of K-step k+1 are spread between the 64 MFMAs
+// of K-step k (one ds_read_b128 behind every four MFMAs, pinned with sched_group_barrier).  Question (round 3): does the lowest
+// LDS-bytes-per-MFMA form (0.25 KB) beat the shipped two-waves-per-SIMD form once its issue order is fixed by hand?
+__global__ __launch_bounds__(256, 1) void probe_pipe128_kernel(const uint4* __restrict__ src, float* __restrict__ out, int iters,
+                                                                unsigned long long* __restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 65536 / 16; i += 256) ((uint4*)smem)[i] = src[(blockIdx.x * 131 + i) & 4095];
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int off[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) off[kh] = fr * 128 + (((kh * 4 + fq) ^ sw) * 16);
+  bf16x8 fa[2][8], fb[2][8];
+  const char* base0 = smem + (wave & 1) * 32768;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) { fa[0][m] = *(const bf16x8*)(base0 + off[0] + m * 2048); fb[0][m] = *(const bf16x8*)(base0 + 16384 + off[0] + m * 2048); }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const int cur = kh, nxt = kh ^ 1;
+      const char* nb = smem + ((it + wave + (kh == 1)) & 1) * 32768;   // K-step after this one: other half-tile, or the next buffer
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        fa[nxt][m] = *(const bf16x8*)(nb + off[nxt] + m * 2048);
+        fb[nxt][m] = *(const bf16x8*)(nb + 16384 + off[nxt] + m * 2048);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][n], fa[cur][m], acc[m][n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) s += (float)fa[0][m][0] + (float)fb[0][m][0];
+  out[blockIdx.x * 256 + tid] = s;
+  if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 // register-only forms (no LDS reads inside the loop): what the MFMA pipe alone sustains for each shape
 template <int SHAPE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe_reg_kernel(const uint4* __restrict__ src, float* __restrict__ out, int iters,
@@ -256,6 +310,7 @@ int main() {
     // MFMA shape (round 3): per workgroup and iteration 8 waves x 128x64x64 either way
     const double fl = 2.0 * 128 * 64 * 64 * 8 * (double)iters;
     run_generic("128x64 wave tile from 32x32x16 MFMAs + LDS reads, 8 waves", probe32_kernel<4, 2, 8>, 8, fl, src, out, stamps, iters);
+    run_generic("128x128 wave tile, 1 wave per SIMD, hand-pipelined reads", probe_pipe128_kernel, 4, 2.0 * 128 * 128 * 64 * 4 * (double)(iters / 2), src, out, stamps, iters / 2);
     run_generic("registers only, 16x16x32 (32 MFMAs per K-64), 8 waves", probe_reg_kernel<16, 8>, 8, fl, src, out, stamps, iters);
     run_generic("registers only, 32x32x16 (16 MFMAs per K-64... x2), 8 waves", probe_reg_kernel<32, 8>, 8, fl, src, out, stamps, iters);
   }
