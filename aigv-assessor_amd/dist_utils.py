@@ -141,7 +141,6 @@ def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, a
     # 1-2. frame shard -> ViT tokens
     fsplit = even_split(F_total, world)
     lo, hi = fsplit[rank]
-    ntok_shape = None
     if hi > lo:
         local = model.vit_tokens(pixel_values[lo:hi])
     else:

@@ -3,7 +3,7 @@ correlation metrics — deterministic string/array code, restated from internvl/
 from __future__ import annotations
 
 import csv
-from typing import Iterable, List, Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 LEVELS = (("bad", 1), ("poor", 2), ("fair", 3), ("good", 4), ("excellent", 5))
 CSV_COLUMNS = ("video_name", "answer", "output", "mos", "pred_score", "level")   # stage2_eval.py:654

@@ -582,7 +582,6 @@ class InternVLChatModel(nn.Module):
         if self.img_context_token_id is None:
             raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
         B, N = input_ids.shape
-        dev = self.device
         n_frames = visual_tokens.shape[0] if visual_tokens is not None else pixel_values.shape[0]
         # ---- index bookkeeping first, on the host (one small D2H copy if the ids live on the device), so that
         # every kernel of the step can then be enqueued back to back without a host sync in between ----
@@ -753,7 +752,6 @@ class InternVLChatModel(nn.Module):
         native.check(lib.aigv_kv_fork(ctx, P, native.stream_ptr()), ctx)
         parts, cu_s, lrows, srows, n_l = [], [0], [], [], []
         for pl in plans:
-            base = cu_s[-1]
             starts = []
             for b in range(B):
                 parts.append(pl["ids_packed"][pl["cu"][b] + pre[b]:pl["cu"][b + 1]])
@@ -970,7 +968,7 @@ class InternVLChatModel(nn.Module):
         max_new, eos, pad, sampler, procs = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         dev = self.device
-        b, n, c = input_embeds.shape
+        b, n, _ = input_embeds.shape
         mask = torch.ones((b, n), dtype=torch.bool, device=dev) if attention_mask is None else attention_mask.to(dev).bool()
         emb = input_embeds.to(dev)[mask].to(torch.bfloat16).contiguous()
         lens = mask.sum(1).tolist()

@@ -173,7 +173,7 @@ def perspective_prompts(base: Dict[str, torch.Tensor], n_prompts: int, seed: int
     """Variants of a canonical prompt that share everything up to the motion block and differ in the question / answer tokens
     behind it - the shape of the reference's four quality perspectives (`...Motion Feature:
     <img><IMG_CONTEXT></img>{question}<|im_end|><|im_start|>assistant\n{answer}<|im_end|>`).  Prompt 0 is `base` itself."""
-    ids0, lab0 = base["input_ids"], base["labels"]
+    ids0 = base["input_ids"]
     n_clips, n0 = ids0.shape
     cut = n0 - 16 - (answer_len + 1)                 # first question token of the canonical layout
     g = torch.Generator().manual_seed(7000 + seed)
