@@ -1700,8 +1700,8 @@ int aigv_tune_skinny(int p) {
 }
 
 int aigv_tune_attention(int waves) {
-  if (waves != 0 && waves != 4 && waves != 8 && waves != 43 && waves != 83)
-    return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_attention: 0 (default), 4 / 8 waves per workgroup, 43 / 83 = with a three-deep K/V ring, got %d", waves);
+  if (waves != 0 && waves != 4 && waves != 8)
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_attention: 0 (default), 4 or 8 waves per workgroup, got %d", waves);
   g_attn_waves = waves;
   return 0;
 }

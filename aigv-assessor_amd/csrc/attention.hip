@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 #include "attn_lay.h"
 
 namespace {
@@ -49,7 +50,7 @@ __device__ unsigned long long g_attn_stamp[2][STAMP_REPL][16];
 // (the dominant overhead next to the MFMAs) halves going from 4 to 8 waves.
 // NB = K/V ring depth: tile t is multiplied while tiles t+1 .. t+NB-2 are in flight behind a counted vmcnt.
 template <int D, bool CAUSAL, int NW, int NB>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int QB = NW * 32;                // query rows per workgroup
   constexpr int ROWB = Lay<D>::ROWB;
   constexpr int CPR = D / 8;                 // 16-byte chunks per row
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
   // SOURCE chunk (the same XOR the fragment reads apply).  Keys past kv_len re-read the last valid row (masked later).
   constexpr int RPI = 1024 / ROWB;            // rows per wave-instruction (8 for D=64, 4 for D=128)
   constexpr int IPW = KT / RPI / NW;          // wave-instructions per wave per operand
+  constexpr bool SPREAD_DMA = D == 128 && NKS % IPW == 0 && NKS / IPW >= 1;   // see the loop: requests issued between the MFMAs of S^T
   const int s_r = lane / CPR, s_c = lane % CPR;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
@@ -225,31 +227,76 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     __syncthreads();   // tile kt visible to every wave; everyone is done reading buffer (kt-1) % NB, which is refilled now
     STAMP(t1);
     STAMP_ADD(3, t0, t1);
-    if (kt + NB - 1 < n_tiles) stage(kt + NB - 1, (kt + NB - 1) % NB);
-    STAMP(t2);
-    STAMP_ADD(4, t1, t2);
     const char* sK = smem + (kt % NB) * (2 * KT * ROWB);
     const char* sV = sK + KT * ROWB;
-
     const int key0 = kt * KT;
     // wave-uniform skips: tiles entirely in this wave's causal future; waves whose 32 query rows all lie past the sequence
     // (1025 = 8 x 128 + 1 rows per ViT frame: three of the last workgroup's four waves).  Such a wave still stages its share
     // of every tile and joins the barriers, but leaves its SIMD's issue slots to the co-resident workgroups.
-    if (CAUSAL && key0 > qw + 31 + kv_off) continue;
-    if (qw >= len || (p.q_tail > 0 && qw + 32 <= len - p.q_tail)) continue;
-    if (ksplit && (kt % NW) != wave) continue;
+    const bool skip = (CAUSAL && key0 > qw + 31 + kv_off) || (qw >= len || (p.q_tail > 0 && qw + 32 <= len - p.q_tail)) || (ksplit && (kt % NW) != wave);
+    // The LDS-DMA requests of tile kt + NB - 1.  d = 128: not in one burst behind the barrier (the stamps priced that burst at 11 % of a
+    // wave's lifetime: eight 1-KB requests queue at the CU's address unit) but one behind every second MFMA of S^T = K Q^T; a wave that
+    // skips the tile, and the ragged last tile of a sequence, keep the burst.  d = 64 (half the requests, half the MFMAs to hide them
+    // behind) measured 5 % slower spread out and keeps the burst (profiles/r3_attn_interleave.txt).
+    const int st_kt = kt + NB - 1, st_buf = st_kt % NB;
+    const bool st_any = st_kt < n_tiles;
+    const bool st_spread = SPREAD_DMA && st_any && !skip && (st_kt * KT + KT <= kv_len);
+    if (st_any && !st_spread) stage(st_kt, st_buf);
+    STAMP(t2);
+    STAMP_ADD(4, t1, t2);
+    if (skip) continue;
 
-    // ---- S^T = K · Q^T -------------------------------------------------------------------------
+    // ---- S^T = K · Q^T: the two 32-key chains alternate (no MFMA waits for its predecessor's result), the K fragments are read four
+    // MFMAs ahead; sched_barrier pins that order (left alone, hipcc reads a fragment right in front of the MFMA that needs it) ----
     f32x16 sacc[2];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[st][e] = 0.f;
-      const int kr = st * 32 + c;
+    {
+      const unsigned dK = lds0 + st_buf * (2 * KT * ROWB) + wave_u * IPW * 1024, dV = dK + KT * ROWB;
+      const char* kb = (const char*)(kbase + (size_t)st_kt * KT * p.ldk);
+      const char* vb = (const char*)(vbase + (size_t)st_kt * KT * p.ldv);
+      auto kread = [&](int idx) {
+        const int kr = (idx & 1) * 32 + c;
+        return *(const bf16x8*)(sK + kr * ROWB + Lay<D>::kchunk(kr, 2 * (idx >> 1) + h) * 16);
+      };
+      auto qk = [&](auto with_dma) {
+        bf16x8 kf[4];
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(sK + kr * ROWB + Lay<D>::kchunk(kr, 2 * ks + h) * 16);
-        sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[st], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) kf[i] = kread(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int idx = 0; idx < 2 * NKS; ++idx) {
+          sacc[idx & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[idx & 3], qf[idx >> 1], sacc[idx & 1], 0, 0, 0);
+          if (idx + 4 < 2 * NKS) kf[idx & 3] = kread(idx + 4);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (decltype(with_dma)::value) {
+            constexpr int EVERY = NKS / IPW;          // 2 * IPW requests over 2 * NKS MFMAs
+            if (idx % EVERY == EVERY - 1) {
+              const int u = idx / EVERY, i = u >> 1;
+              if (u & 1) glds16_saddr(vb, voff[i], dV + i * 1024);
+              else glds16_saddr(kb, koff[i], dK + i * 1024);
+            }
+          }
+        }
+      };
+      if constexpr (SPREAD_DMA) {
+        if (st_spread) qk(std::true_type{});
+        else qk(std::false_type{});
+      } else {
+        // (d = 64: the compiler's own order of these eight MFMAs and reads, pinned only by read-ahead groups)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+          for (int st = 0; st < 2; ++st) sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kread(2 * ks + st), qf[ks], sacc[st], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * NKS - 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
     }
 
@@ -301,25 +348,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
     // v_pk_*_f32: the packed forms halve the instruction count but not the issue time - the guide prices them as an anti-lever beside
     // MFMAs).  Plain C, not inline asm: hipcc inserts the wait state a VALU read of a v_exp_f32 result needs only for instructions it
     // can see (an asm v_add_f32 right behind the v_exp_f32 summed stale registers).  Two running sums.
+    // Quarter-wise: the softmax of keys [16 q, 16 q + 16) is followed by their share of O^T += V^T P^T, and the schedule below moves each
+    // quarter's MFMAs between the NEXT quarter's softmax instructions (inside one wave a few independent VALU instructions behind every
+    // MFMA are almost free: profiles/r3_mfma_valu_overlap_probe.txt).
     float ps0 = 0.f, ps1 = 0.f;
     const float nmc = -mc;
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-#pragma unroll
-      for (int e = 0; e < 16; e += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[st][e], sc, nmc));
-        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[st][e + 1], sc, nmc));
-        ps0 += p0;
-        ps1 += p1;
-        sacc[st][e] = p0;
-        sacc[st][e + 1] = p1;
-      }
-    }
-    float psum = ps0 + ps1;
-    psum += __shfl_xor(psum, 32, 64);
-    l_run += psum;
-
-    // ---- O^T += V^T · P^T ---------------------------------------------------------------------------
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
@@ -327,7 +360,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
         typedef __attribute__((ext_vector_type(8))) float f32x8;
         f32x8 pw;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pw[j] = sacc[st][8 * s2 + j];
+        for (int j = 0; j < 8; j += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[st][8 * s2 + j], sc, nmc));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[st][8 * s2 + j + 1], sc, nmc));
+          ps0 += p0;
+          ps1 += p1;
+          pw[j] = p0;
+          pw[j + 1] = p1;
+        }
         const bf16x8 pf = __builtin_convertvector(pw, bf16x8);   // four v_cvt_pk_bf16_f32
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
@@ -343,6 +383,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs p) 
         }
       }
     }
+    {
+      float psum = ps0 + ps1;
+      psum += __shfl_xor(psum, 32, 64);
+      l_run += psum;
+    }
+    // quarter 0's softmax (8 fma, 8 exp, 8 add, 4 cvt), then per MFMA of quarters 0..2 its two transposed reads and 28 / NDT of the
+    // next quarter's VALU instructions, then quarter 3's MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x002, 28, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);            // the reads of an MFMA are issued two MFMAs ahead of it
+#pragma unroll
+    for (int i = 0; i < 3 * NDT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 28 / NDT, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NDT - 2; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #ifdef AIGV_ATTN_STAMP
     asm volatile("" :: "v"(oacc[0][0]));     // the stamp below must not move in front of the last MFMA's result
     {
@@ -619,7 +680,7 @@ const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
   return nullptr;
 }
 
-int g_attn_waves = 0;   // 0 = default (4 waves, two-deep ring); forced for A/B experiments: 4 / 8 waves, 43 / 83 = with a three-deep ring
+int g_attn_waves = 0;   // 0 = default (4 waves per workgroup); forced for A/B experiments: 4 / 8 waves
 
 // NB = 2: deeper rings (3, 4 buffers) measured 5-15 % slower on the ViT shape - they cost resident workgroups (LDS), and
 // with four workgroups per CU the wait for the next tile is already covered by the others' work
@@ -637,15 +698,6 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
   // 4 waves (128 query rows) per workgroup.  With the XCD-aware block order the K/V stream of a head is shared in L2, and
   // 8-wave workgroups (half the K/V reads, half the resident workgroups) measured equal or slower on every headline shape
   // (scripts/attn_bench.py with AB_WAVES=1); the 8-wave form stays reachable through aigv_tune_attention for such A/Bs.
-  if (g_attn_waves == 43 || g_attn_waves == 83) {   // experiments: a three-deep K/V ring (two tiles in flight) with 4 / 8 waves
-    const bool w8 = g_attn_waves == 83;
-    if (head_dim == 64) {
-      if (a.causal) return w8 ? launch_attn<64, true, 8, 3>(a, s) : launch_attn<64, true, 4, 3>(a, s);
-      return w8 ? launch_attn<64, false, 8, 3>(a, s) : launch_attn<64, false, 4, 3>(a, s);
-    }
-    if (a.causal) return w8 ? launch_attn<128, true, 8, 3>(a, s) : launch_attn<128, true, 4, 3>(a, s);
-    return w8 ? launch_attn<128, false, 8, 3>(a, s) : launch_attn<128, false, 4, 3>(a, s);
-  }
   const int nw = g_attn_waves == 8 ? 8 : 4;
   if (head_dim == 64) {
     if (a.causal) return nw == 8 ? launch_attn<64, true, 8>(a, s) : launch_attn<64, true, 4>(a, s);
@@ -658,7 +710,7 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
 // The one kernel above runs every shape.  A software-pipelined 64-rows-per-wave kernel (round 2, attention64.hip) won the isolated
 // A/B by 7 % and lost the in-step one by 6 % twice (profiles/r2_attn_ab.txt, r2_attn_inmodel_ab.txt) and was removed in round 3; so
 // did three-deep K/V rings (profiles/r3_attn_ring_negative.txt) and an 8-wave kernel with role-alternating halves (round 3,
-// profiles/r3_attn8_negative.txt).  aigv_tune_attention: 4 / 8 waves per workgroup, 43 / 83 = with a three-deep ring (A/B only).
+// profiles/r3_attn8_negative.txt).  aigv_tune_attention: 4 / 8 waves per workgroup (A/B only).
 hipError_t aigv_launch_attention(const AttnArgs& a_in, int head_dim, hipStream_t s) {
   AttnArgs a = a_in;
   {

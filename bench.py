@@ -313,8 +313,8 @@ def main():
     ap.add_argument("--all-rows", action="store_true", help="A/B: run every row through the last decoder layer (no row trimming)")
     ap.add_argument("--force-dp", action="store_true", help="variant: route a 1-GPU run through the frame/clip-DP scorer with its RCCL collectives executed on a one-rank group")
     ap.add_argument("--ingest", action="store_true", help="variant: pinned uint8 720p frames -> H2D -> resize + normalise on the GPU inside every step")
-    ap.add_argument("--attn-kernel", type=int, default=0, choices=[0, 4, 8, 43, 83],
-                    help="A/B: force one form of the prefill-attention kernel (aigv_tune_attention): 4 / 8 waves, 43 / 83 = with a three-deep K/V ring; 0 = default")
+    ap.add_argument("--attn-kernel", type=int, default=0, choices=[0, 4, 8],
+                    help="A/B: force one form of the prefill-attention kernel (aigv_tune_attention): 4 / 8 waves per workgroup; 0 = default")
     ap.add_argument("--tune-gemm", type=int, default=0, help="A/B: aigv_tune_gemm mode word (kernel choice + 16 * (1 + 256-kernel schedule variant))")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
     ap.add_argument("--no-parity", action="store_true", help="skip the score / level comparison with the reference's recorded outputs (tests/golden/e2e_8b_r3.pt; ~1.5 min of CPU weight generation)")

@@ -267,8 +267,8 @@ int aigv_tune_gemm(int mode, double rate256);
  * 0 = no column split); `plan` holds 7 ints; est_us = the model's time. */
 int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us);
 /* Prefill-attention kernel form (process-wide; experiments and tests): 0 = default (attention.hip: 4 waves x 32 query rows per
- * workgroup, two-deep K/V ring); 4 or 8 = that many waves per workgroup; 43 / 83 = 4 / 8 waves with a three-deep ring (both lost the
- * in-step A/B: profiles/r3_attn_ring_negative.txt). */
+ * workgroup, two-deep K/V ring); 4 or 8 = that many waves per workgroup (three-deep rings lost the in-step A/B and were removed:
+ * profiles/r3_attn_ring_negative.txt). */
 int aigv_tune_attention(int waves);
 /* Form of the decode GEMVs (process-wide; experiments and tests): 0 = default (per-shape choice in aigv_decode_step, 16-row slabs
  * in aigv_op_skinny_gemm); 1 / 2 / 4 = 16 / 8 / 4 rows of W per workgroup and slab wherever legal (R <= 16 / p, epi store /
