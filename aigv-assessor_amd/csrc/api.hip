@@ -86,6 +86,8 @@ struct aigv_ctx {
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 3 (attention out, hidden, normed) + [64, I]
   bf16_t* l_score_ws = nullptr;
   bf16_t *kc = nullptr, *vc = nullptr;   // [layer][seq][kv head][cap][D]
+  bf16_t *kc_alt = nullptr, *vc_alt = nullptr;   // second cache of the same size, made by the first aigv_kv_reorder (beam search gathers into it, then the two swap)
+  int32_t* beam_ints = nullptr;                  // [2 * max_seqs]: parent slots | live lengths of a reorder
   float* dec_ws = nullptr;
   int32_t *dec_pos = nullptr, *dec_seq = nullptr, *dec_kvlen = nullptr, *dec_slot = nullptr;   // device-side decode state
   std::vector<int32_t> h_dec;
@@ -528,6 +530,7 @@ static int alloc_workspaces(aigv_ctx* c) {
   int rc = 0;
   c->ws_phase = true;
   c->kc = c->vc = nullptr;   // (no KV capacity: no caches)
+  c->kc_alt = c->vc_alt = nullptr; c->beam_ints = nullptr;
   c->dec_ws = nullptr; c->dec_pos = c->dec_seq = c->dec_kvlen = c->dec_slot = nullptr;
   const size_t vr = (size_t)k.vit_chunk * c->S;
   const size_t pr = (size_t)k.vit_chunk * c->ntok;
@@ -1301,6 +1304,42 @@ int aigv_kv_fork(aigv_ctx* c, int copies, void* stream) {
   HIPCHK(c, aigv_launch_write_ints(c->h_dec.data() + 2 * N, N, c->dec_kvlen, s));
   HIPCHK(c, aigv_launch_write_ints(c->h_dec.data() + 3 * N, N, c->dec_slot, s));
   c->kv_seqs = N;
+  return 0;
+}
+
+// Beam search over the kept sequences: sequence i continues from what sequence parent[i] has cached (its first len[i] positions); the
+// device-side positions of aigv_decode_step are untouched (all beams of a search have one length).  A gather into a second cache that
+// is allocated on first use (workspace: freed and re-made by aigv_ctx_resize), after which the two caches swap.
+int aigv_kv_reorder(aigv_ctx* c, const int32_t* parent, const int32_t* len, int n, void* stream) {
+  if (!c || !parent || !len) return fail(c, AIGV_ERR_ARG, "aigv_kv_reorder: null argument");
+  if (!c->kv_valid) return fail(c, AIGV_ERR_STATE, "aigv_kv_reorder: no KV state (run aigv_llm_prefill with keep_kv)");
+  const aigv_config& k = c->cfg;
+  if (n != c->kv_seqs) return fail(c, AIGV_ERR_ARG, "aigv_kv_reorder: %d sequences, the cache holds %d", n, c->kv_seqs);
+  int max_len = 0;
+  for (int i = 0; i < n; ++i) {
+    if (parent[i] < 0 || parent[i] >= n) return fail(c, AIGV_ERR_ARG, "aigv_kv_reorder: parent[%d] = %d outside 0..%d", i, parent[i], n - 1);
+    if (len[i] <= 0 || len[i] > k.kv_capacity) return fail(c, AIGV_ERR_ARG, "aigv_kv_reorder: len[%d] = %d outside 1..%d", i, len[i], k.kv_capacity);
+    max_len = std::max(max_len, len[i]);
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (!c->kc_alt) {
+    const size_t per = (size_t)k.llm_layers * k.max_seqs * k.llm_kv_heads * k.kv_capacity * c->head_dim;
+    c->ws_phase = true;
+    int rc = dalloc(c, &c->kc_alt, per);
+    if (!rc) rc = dalloc(c, &c->vc_alt, per);
+    if (!rc) rc = dalloc(c, &c->beam_ints, (size_t)2 * k.max_seqs);
+    c->ws_phase = false;
+    if (rc) return rc;
+  }
+  HIPCHK(c, aigv_launch_write_ints(parent, n, c->beam_ints, s));
+  HIPCHK(c, aigv_launch_write_ints(len, n, c->beam_ints + k.max_seqs, s));
+  const size_t kv_layer = (size_t)k.max_seqs * k.llm_kv_heads * k.kv_capacity * c->head_dim;
+  hipError_t e = aigv_launch_kv_reorder(c->kc, c->vc, c->kc_alt, c->vc_alt, c->beam_ints, c->beam_ints + k.max_seqs, n, k.llm_layers, k.llm_kv_heads,
+                                        k.kv_capacity, c->head_dim, kv_layer, max_len, s);
+  if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "aigv_kv_reorder (n=%d): %s", n, hipGetErrorString(e));
+  std::swap(c->kc, c->kc_alt);
+  std::swap(c->vc, c->vc_alt);
   return 0;
 }
 

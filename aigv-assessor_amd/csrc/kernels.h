@@ -184,3 +184,6 @@ struct SmallInts { int32_t v[AIGV_SMALL_INTS]; };
 hipError_t aigv_launch_seqpos(const int32_t* cu_host, int n_seq, int32_t* pos, int32_t* seq, int32_t* cu_dev, int tokens,
                               hipStream_t s, const int32_t* pos_offset_host = nullptr);
 hipError_t aigv_launch_write_ints(const int32_t* host, int n, int32_t* dst, hipStream_t s);
+// beam search: new KV cache slot i = the first lens[i] positions of slot parent[i] of the current cache (all layers, all kv heads); dst != src
+hipError_t aigv_launch_kv_reorder(const bf16_t* sk, const bf16_t* sv, bf16_t* dk, bf16_t* dv, const int32_t* parent, const int32_t* lens, int n,
+                                  int layers, int nkv, int cap, int D, size_t kv_layer, int max_len, hipStream_t s);

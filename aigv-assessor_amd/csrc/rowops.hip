@@ -1,5 +1,6 @@
 // Row-wise and element-wise kernels of the scorer hot path (all HBM-bound: 16-byte vector accesses,
 // fp32 statistics, bf16 rounding points as in the reference's eager path).
+#include <algorithm>
 #include "common.h"
 #include "kernels.h"
 
@@ -407,6 +408,39 @@ hipError_t aigv_launch_seqpos(const int32_t* cu_host, int n_seq, int32_t* pos, i
   if (pos_offset_host)
     for (int i = 0; i < n_seq; ++i) a.v[AIGV_SMALL_INTS / 2 + i] = pos_offset_host[i];
   hipLaunchKernelGGL(seqpos_kernel, dim3((tokens + 255) / 256), dim3(256), 0, s, a, n_seq, pos, seq, cu_dev, tokens);
+  return hipGetLastError();
+}
+
+// Beam search: slot i of the NEW cache takes the first len[i] positions of slot parent[i] of the current one, for every layer and kv head
+// (dst and src are different buffers: a gather, never in place).  grid (16-byte chunks of a head's live region, kv heads, layers * n).
+namespace {
+__global__ __launch_bounds__(256) void kv_reorder_kernel(const bf16_t* __restrict__ sk, const bf16_t* __restrict__ sv, bf16_t* __restrict__ dk,
+                                                         bf16_t* __restrict__ dv, const int32_t* __restrict__ parent,
+                                                         const int32_t* __restrict__ lens, int n, int nkv, int cap, int D, size_t kv_layer) {
+  const int layer = blockIdx.z / n, slot = blockIdx.z % n, head = blockIdx.y;
+  const int src = parent[slot];
+  const size_t live = (size_t)lens[slot] * D / 8;          // 16-byte chunks to copy (D % 8 == 0)
+  const size_t so = (size_t)layer * kv_layer + ((size_t)src * nkv + head) * cap * D;
+  const size_t dO = (size_t)layer * kv_layer + ((size_t)slot * nkv + head) * cap * D;
+  const uint4* k0 = (const uint4*)(sk + so);
+  const uint4* v0 = (const uint4*)(sv + so);
+  uint4* k1 = (uint4*)(dk + dO);
+  uint4* v1 = (uint4*)(dv + dO);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < live; i += (size_t)gridDim.x * blockDim.x) {
+    k1[i] = k0[i];
+    v1[i] = v0[i];
+  }
+}
+}  // namespace
+
+hipError_t aigv_launch_kv_reorder(const bf16_t* sk, const bf16_t* sv, bf16_t* dk, bf16_t* dv, const int32_t* parent, const int32_t* lens, int n,
+                                  int layers, int nkv, int cap, int D, size_t kv_layer, int max_len, hipStream_t s) {
+  if (n <= 0 || layers <= 0 || nkv <= 0 || cap <= 0 || D % 8 || max_len <= 0 || max_len > cap || !sk || !sv || !dk || !dv || !parent || !lens ||
+      sk == dk || sv == dv || (long)layers * n > 65535)
+    return hipErrorInvalidValue;
+  const size_t chunks = (size_t)max_len * D / 8;
+  const int gx = (int)std::min<size_t>((chunks + 255) / 256, 64);
+  hipLaunchKernelGGL(kv_reorder_kernel, dim3(gx, nkv, layers * n), dim3(256), 0, s, sk, sv, dk, dv, parent, lens, n, nkv, cap, D, kv_layer);
   return hipGetLastError();
 }
 

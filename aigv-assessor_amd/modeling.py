@@ -24,7 +24,7 @@ Documented deviations from the reference (all outside what its eval scripts exer
     callable with the reference's interface.
   * ``generate`` implements greedy decoding and multinomial sampling (temperature / top-k / top-p, HF's warper order) with HF's
     repetition_penalty / no_repeat_ngram_size processors; the reference defers to HF ``generate`` - its eval configs use
-    do_sample=False.  Beam search raises NotImplementedError.
+    do_sample=False.  num_beams > 1 runs HF's beam search (beam.py: best hypothesis only; beam sampling / beam groups raise).
 """
 from __future__ import annotations
 
@@ -783,7 +783,7 @@ class InternVLChatModel(nn.Module):
     EOS_CHECK_EVERY = 8     # tokens between two host reads of the device-side "finished" flags
 
     def _greedy(self, ids_packed, slot, cu, vis, n_vis, max_new_tokens: int, eos_ids: List[int], pad_id: int, motion=None, sampler=None,
-                processors=None):
+                processors=None, beams=None):
         """The token loop of generate(): HF's greedy search / multinomial sampling loop (the reference calls ``language_model.generate``,
         modeling_internvl_chat.py:798-809).  The end-of-sequence bookkeeping runs on the device (aigv_decode_eos): a finished sequence
         emits ``pad_id``, the loop stops once every sequence has emitted an end token - checked by the host only every EOS_CHECK_EVERY
@@ -797,10 +797,13 @@ class InternVLChatModel(nn.Module):
             raise NotImplementedError("decoding past max_position_embeddings with dynamic-NTK rope scaling is not implemented")
         if len(eos_ids) > 8:
             raise ValueError("at most 8 eos_token_id values")
-        self._native(seq_len=longest)
+        nb = beams["num_beams"] if beams else 1
+        self._native(seq_len=longest, n_clips=b * nb, out_rows=b * nb)       # (beam search: room for every beam before the prompt pass)
         _, nxt = self._prefill(ids_packed, slot, cu, vis, n_vis, motion, None, last_rows, keep_kv=True,
                                kv_cap=longest + max_new_tokens + 1)
         lib, ctx = native.load(), self._ctx
+        if beams:
+            return self._beam_decode(b, [cu[i + 1] - cu[i] for i in range(b)], max_new_tokens, eos_ids, pad_id, processors or [], **beams)
         eos_a = (C.c_int64 * max(len(eos_ids), 1))(*[int(e) for e in eos_ids]) if eos_ids else None
         state = torch.zeros(b + 1, dtype=torch.int32, device=self.device)     # finished flags + live-column count (aigv_amd.h)
         outs: List[torch.Tensor] = []
@@ -833,20 +836,60 @@ class InternVLChatModel(nn.Module):
             out = out[:, : max(1, int(state[b].item()))]     # HF stops after the column in which the last live sequence ended
         return out
 
+    def _beam_decode(self, b: int, prompt_lens: List[int], max_new_tokens: int, eos_ids: List[int], pad_id, processors, num_beams: int,
+                     length_penalty: float = 1.0, early_stopping=False) -> torch.Tensor:
+        """HF beam search (beam.beam_search) behind a prompt pass that kept its KV: the prompts' caches are replicated once per beam
+        (aigv_kv_fork: sequence k * b + i is beam k of prompt i), every step decodes all b * num_beams sequences in one aigv_decode_step
+        (the decoder weights stream once for all beams) and the chosen parents are gathered in the cache (aigv_kv_reorder)."""
+        from . import beam
+        lib, ctx = native.load(), self._ctx
+        V = self.config.llm_config.vocab_size
+        n = b * num_beams
+        first = self._row_logits(b)
+        native.check(lib.aigv_kv_fork(ctx, num_beams, native.stream_ptr()), ctx)
+        fed = [0]                                  # tokens every beam has been fed so far = cached positions behind its prompt
+        slot_of = lambda i, k: k * b + i
+
+        def reorder(parent: torch.Tensor):
+            if fed[0] == 0:
+                return                             # the copies are still identical
+            src = beam.parents_to_slots(parent.cpu(), slot_of)
+            if src == list(range(n)):
+                return
+            lens = [prompt_lens[s % b] + fed[0] for s in range(n)]
+            native.check(lib.aigv_kv_reorder(ctx, native.i32_array(src), native.i32_array(lens), n, native.stream_ptr()), ctx)
+
+        def step(tok: torch.Tensor) -> torch.Tensor:
+            t = tok.t().contiguous().view(-1)      # [b, nb] -> cache order
+            new = torch.empty_like(t)
+            native.check(lib.aigv_decode_step(ctx, t.data_ptr(), new.data_ptr(), native.stream_ptr()), ctx)
+            fed[0] += 1
+            return self._row_logits(n).view(num_beams, b, V).transpose(0, 1)
+
+        return beam.beam_search(first, step, reorder, num_beams, max_new_tokens, eos_ids=eos_ids, pad_id=pad_id, length_penalty=length_penalty,
+                                early_stopping=early_stopping, processors=processors)
+
     @staticmethod
     def _gen_args(generation_config, kw):
-        """(max_new_tokens, eos ids, pad id, sampler) from a HF-style generation config / kwargs.  ``sampler`` is None for greedy
+        """(max_new_tokens, eos ids, pad id, sampler, processors, beams) from a HF-style generation config / kwargs.  ``sampler`` is None for greedy
         decoding or the warper settings of HF's multinomial sampling (temperature -> top-k -> top-p, transformers' order and
         defaults: top_k 50, top_p 1.0, temperature 1.0); ``processors`` = HF's repetition-penalty / no-repeat-n-gram logits processors
-        when asked for.  Beam search is not on this path."""
+        when asked for; ``beams`` is None or HF's beam-search settings (num_beams > 1: num_beams, length_penalty, early_stopping)."""
         cfg = dict(generation_config) if isinstance(generation_config, dict) else {}
         if generation_config is not None and not isinstance(generation_config, dict):
             cfg = {k: getattr(generation_config, k) for k in ("max_new_tokens", "do_sample", "num_beams", "eos_token_id", "pad_token_id",
-                                                              "temperature", "top_k", "top_p", "repetition_penalty", "no_repeat_ngram_size")
+                                                              "temperature", "top_k", "top_p", "repetition_penalty", "no_repeat_ngram_size",
+                                                              "length_penalty", "early_stopping", "num_return_sequences", "num_beam_groups")
                    if hasattr(generation_config, k)}
         cfg.update(kw)
+        beams = None
         if (cfg.get("num_beams") or 1) > 1:
-            raise NotImplementedError("beam search is not implemented on the gfx950 path (greedy and multinomial sampling are)")
+            if cfg.get("do_sample"):
+                raise NotImplementedError("beam-search multinomial sampling is not implemented on the gfx950 path (beam search, greedy and sampling are)")
+            if (cfg.get("num_return_sequences") or 1) != 1 or (cfg.get("num_beam_groups") or 1) != 1:
+                raise NotImplementedError("beam search returns the best hypothesis only (num_return_sequences = 1, no beam groups)")
+            beams = dict(num_beams=int(cfg["num_beams"]), length_penalty=float(cfg["length_penalty"]) if cfg.get("length_penalty") is not None else 1.0,
+                         early_stopping=cfg.get("early_stopping") if cfg.get("early_stopping") is not None else False)
         processors = []       # HF's order (GenerationMixin._get_logits_processor): repetition penalty, then n-gram blocking
         if cfg.get("repetition_penalty") not in (None, 1, 1.0):
             processors.append(InternVLChatModel._repetition_penalty(float(cfg["repetition_penalty"])))
@@ -861,7 +904,7 @@ class InternVLChatModel(nn.Module):
                 raise ValueError(f"bad sampling settings {sampler}")
         eos = cfg.get("eos_token_id")
         eos = [] if eos is None else ([int(eos)] if not isinstance(eos, (list, tuple)) else [int(e) for e in eos])
-        return int(cfg.get("max_new_tokens") or 20), eos, cfg.get("pad_token_id"), sampler, processors
+        return int(cfg.get("max_new_tokens") or 20), eos, cfg.get("pad_token_id"), sampler, processors, beams
 
     @staticmethod
     def _repetition_penalty(penalty: float):
@@ -943,7 +986,7 @@ class InternVLChatModel(nn.Module):
         """modeling_internvl_chat.py:769-811: every <IMG_CONTEXT> slot takes a visual token (no motion
         token), then greedy decode with a KV cache.  Returns the NEW tokens [B, <=max_new_tokens]."""
         assert self.img_context_token_id is not None
-        max_new, eos, pad, sampler, procs = self._gen_args(generation_config, generate_kwargs)
+        max_new, eos, pad, sampler, procs, beams = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         dev = self.device
         input_ids = input_ids.to(dev)
@@ -959,13 +1002,13 @@ class InternVLChatModel(nn.Module):
             if int(sel.sum()) != n_vis:
                 raise ValueError(f"visual token count mismatch: {int(sel.sum())} slots vs {n_vis} tokens")
             slot[sel] = torch.arange(n_vis, device=dev, dtype=torch.int32)
-        return self._greedy(ids_packed, slot, cu, vis, n_vis, max_new, eos, pad, sampler=sampler, processors=procs)
+        return self._greedy(ids_packed, slot, cu, vis, n_vis, max_new, eos, pad, sampler=sampler, processors=procs, beams=beams)
 
     @torch.no_grad()
     def generate2(self, input_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, visual_features=None,
                   generation_config=None, output_hidden_states=None, return_dict=None, **generate_kwargs) -> torch.Tensor:
         """modeling_internvl_chat.py:812-853: decode from precomputed input embeddings [B, N, C]."""
-        max_new, eos, pad, sampler, procs = self._gen_args(generation_config, generate_kwargs)
+        max_new, eos, pad, sampler, procs, beams = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         dev = self.device
         b, n, _ = input_embeds.shape
@@ -978,7 +1021,7 @@ class InternVLChatModel(nn.Module):
         T = emb.shape[0]
         ids = torch.zeros(T, dtype=torch.long, device=dev)
         slot = torch.arange(T, dtype=torch.int32, device=dev)          # every row comes from `emb`
-        return self._greedy(ids, slot, cu, emb, T, max_new, eos, pad, sampler=sampler, processors=procs)
+        return self._greedy(ids, slot, cu, emb, T, max_new, eos, pad, sampler=sampler, processors=procs, beams=beams)
 
     @torch.no_grad()
     def generate_stage2(self, pixel_values, input_ids, attention_mask=None, image_flags=None, motion_feature=None,
@@ -989,14 +1032,14 @@ class InternVLChatModel(nn.Module):
         token / visual / motion rows - no embedding tensor is assembled on the host side."""
         if self.img_context_token_id is None:
             raise AssertionError("img_context_token_id must be set (stage2_eval.py:810)")
-        max_new, eos, pad, sampler, procs = self._gen_args(generation_config, generate_kwargs)
+        max_new, eos, pad, sampler, procs, beams = self._gen_args(generation_config, generate_kwargs)
         pad = self.config.llm_config.pad_token_id if pad is None else pad
         B = input_ids.shape[0]
         plan = self._plan(input_ids, attention_mask, None, image_flags, pixel_values.shape[0], drop_dead_tail=False)
         motion_feature = self._motion_feature(pixel_values, B, motion_feature)
         self._native(n_frames=pixel_values.shape[0], n_tokens=plan["cu"][-1], n_clips=B)
         vit_embeds, motion = self._visual_inputs(pixel_values, None, motion_feature, plan)
-        return self._greedy(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], max_new, eos, pad, motion=motion, sampler=sampler, processors=procs)
+        return self._greedy(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], max_new, eos, pad, motion=motion, sampler=sampler, processors=procs, beams=beams)
 
     def chat2(self, tokenizer, pixel_values, input_ids, generation_config, attention_mask, history=None,
               return_history=False, image_flags=None, IMG_START_TOKEN="<img>", IMG_END_TOKEN="</img>",

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "aigv_llm_prefill": (_I, [_P, _P, _P, _I32P, _I, _P, _I, _P, _I32P, _P, _I32P, _I, _P, _I, _P]),
     "aigv_llm_extend": (_I, [_P, _P, _I32P, _I, _I32P, _P, _I32P, _I, _P, _I, _P]),
     "aigv_kv_fork": (_I, [_P, _I, _P]),
+    "aigv_kv_reorder": (_I, [_P, _P, _P, _I, _P]),
     "aigv_set_row_trimming": (_I, [_P, _I]),
     "aigv_set_gemm_mode": (_I, [_P, _I]),
     "aigv_decode_step": (_I, [_P, _P, _P, _P]),

@@ -128,6 +128,13 @@ int aigv_llm_extend(aigv_ctx* ctx, const int64_t* ids, const int32_t* cu, int n_
  * then take DIFFERENT continuations in one aigv_llm_extend call over n * copies sequences (sequence c * n + b continues clip b),
  * which streams the decoder weights once for all of them. */
 int aigv_kv_fork(aigv_ctx* ctx, int copies, void* stream);
+/* Beam search (HF generate(num_beams > 1): the cache reorder of GenerationMixin._beam_search, transformers/generation/utils.py; the
+ * reference inherits it through language_model.generate, modeling_internvl_chat.py:798-809).  After this call kept sequence i holds
+ * what sequence parent[i] had cached - its first len[i] positions - in every layer; parent / len are HOST arrays of n = the number of
+ * kept sequences (aigv_llm_prefill(keep_kv) x aigv_kv_fork).  The positions aigv_decode_step keeps on the device are not touched: the
+ * beams of one search all have the same length.  The first call allocates a second KV cache of the context's size (the gather is never
+ * in place; the two caches swap). */
+int aigv_kv_reorder(aigv_ctx* ctx, const int32_t* parent, const int32_t* len, int n, void* stream);
 
 /* Arithmetic of the InternLM2 linears (aigv_llm_prefill, aigv_llm_extend, aigv_decode_step; BASELINE config 5).  AIGV_PRECISION_BF16 (default) is the reference's
  * dtype flow.  AIGV_PRECISION_FP8_LLM: wqkv, wo, w1|w3, w2 of every decoder layer - except wo / w1|w3 / w2 of the LAST layer, which act on

@@ -79,8 +79,10 @@ def test_chat_single_turn_and_history(rig):
     resp2 = model.chat(tok, pv, "And its motion?", dict(max_new_tokens=NEW, do_sample=False), history=list(hist))
     want2, _ = expected_response(sd, cfg, tok, render(model, "And its motion?", [4], history=hist), pv)
     assert resp2 == want2, (resp2, want2)
-    with pytest.raises(NotImplementedError):        # beam search is not on this path: loud, not silently greedy
-        model.chat(tok, pv, "Rate the clip.", dict(max_new_tokens=2, num_beams=4))
+    with pytest.raises(NotImplementedError):        # beam SAMPLING is not on this path: loud, not silently something else
+        model.chat(tok, pv, "Rate the clip.", dict(max_new_tokens=2, num_beams=4, do_sample=True))
+    beamed = model.chat(tok, pv, "Rate the clip.", dict(max_new_tokens=NEW, num_beams=3, do_sample=False))      # chat() through HF's beam search
+    assert isinstance(beamed, str)
 
 
 def test_batch_chat_left_padded_prompts(rig):
@@ -360,3 +362,114 @@ def test_process_default_gemm_mode_1_is_batch_invariant(rig):
             assert torch.equal(tok_one, tok_all[b:b + 1]) and torch.equal(log_one.view(torch.int32), log_all[b:b + 1].view(torch.int32))
     finally:
         native.check(lib.aigv_tune_gemm(0, 0.0))
+
+
+def _oracle_beam(sd, cfg, emb, num_beams, max_new, eos, pad, **kw):
+    """beam.beam_search (pinned against transformers in tests/test_host.py) over the ORACLE's KV-cache path: HF's loop with the reference's
+    prepare_inputs_for_generation - embeddings on step 0, then the last token ids; the cache reorder is an index_select on the batch axis."""
+    from aigv_assessor_amd import beam
+    B, P, _ = emb.shape
+    hidden, past, _ = O.llm_forward(sd, cfg, emb)
+    first = O.lm_logits(sd, hidden[:, -1:, :])[:, -1, :]
+    st = {"past": [tuple(t.repeat_interleave(num_beams, dim=0) for t in layer) for layer in past], "len": P}   # row b * nb + k
+
+    def reorder(parent):
+        idx = (parent + torch.arange(B)[:, None] * num_beams).reshape(-1)
+        st["past"] = [tuple(t.index_select(0, idx) for t in layer) for layer in st["past"]]
+
+    def step(tok):
+        e = torch.nn.functional.embedding(tok.reshape(-1, 1), sd["language_model.model.tok_embeddings.weight"])
+        pos = torch.full((B * num_beams, 1), st["len"], dtype=torch.long)
+        h, st["past"], _ = O.llm_forward(sd, cfg, e, None, pos, st["past"])
+        st["len"] += 1
+        return O.lm_logits(sd, h[:, -1:, :])[:, -1, :].view(B, num_beams, -1)
+
+    return beam.beam_search(first, step, reorder, num_beams, max_new, eos_ids=eos, pad_id=pad, **kw)
+
+
+@pytest.mark.parametrize("num_beams,eos_pick,kw", [(2, None, {}), (3, (0, 2), {}), (4, (1, 1), dict(length_penalty=0.5, early_stopping=True)),
+                                                  (3, (0, 3), dict(repetition_penalty=1.4))])
+def test_beam_search_generate_matches_the_oracle_driven_search(rig, num_beams, eos_pick, kw):
+    """generate(num_beams > 1) - HF's beam search, which the reference inherits through language_model.generate
+    (modeling_internvl_chat.py:798-809) - on the GPU path (prompt pass, aigv_kv_fork, one aigv_decode_step for all beams per step,
+    aigv_kv_reorder) against the same search logic driven by the oracle's cache path: the same hypotheses, token for token.  An end
+    token is planted from the free-running greedy tokens so that beams finish at different steps."""
+    model, cfg, sd, tok = rig
+    B, T, n_new = 2, 2, 7
+    toks = synth.canonical_tokens(cfg, B, T, seed=67)
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    ids = toks["input_ids"][:, :n_prompt].clone()
+    ctx = toks["img_context_token_id"]
+    for b in range(B):
+        ids[b, (ids[b] == ctx).nonzero()[-1]] = 7
+    am = torch.ones_like(ids)
+    pv = synth.synthetic_frames(B * T, 224, seed=67)
+    model.img_context_token_id = ctx
+    free = _free_running(model, pv, ids, am, n_new)
+    eos = [int(free[eos_pick[0], eos_pick[1]])] if eos_pick else []
+    emb = O.scatter_embeds(sd, ids, ctx, O.extract_feature(sd, cfg, pv), None)
+    search = {k: v for k, v in kw.items() if k in ("length_penalty", "early_stopping")}
+    procs = []
+    if "repetition_penalty" in kw:
+        from aigv_assessor_amd.modeling import InternVLChatModel
+        procs = [InternVLChatModel._repetition_penalty(kw["repetition_penalty"])]
+    want = _oracle_beam(sd, cfg, emb, num_beams, n_new, eos, 2, processors=procs, **search)
+    got = model.generate(pixel_values=pv, input_ids=ids, attention_mask=am, max_new_tokens=n_new, do_sample=False, num_beams=num_beams,
+                         eos_token_id=(eos[0] if eos else None), pad_token_id=2, **kw).cpu()
+    greedy = model.generate(pixel_values=pv, input_ids=ids, attention_mask=am, max_new_tokens=n_new, do_sample=False,
+                            eos_token_id=(eos[0] if eos else None), pad_token_id=2).cpu()
+    print(f"beams {num_beams} eos {eos}: {got.tolist()} (greedy {greedy.tolist()})")
+    assert got.shape == want.shape and torch.equal(got, want), (got.tolist(), want.tolist())
+
+
+def test_kv_reorder_is_a_gather_of_the_parents_caches(rig):
+    """aigv_kv_reorder: after it, sequence i decodes exactly as sequence parent[i] would have - bit for bit - and the gather is not in
+    place (a permutation with a cycle and a duplicated parent)."""
+    import ctypes as C
+    from aigv_assessor_amd import native
+    model, cfg, sd, tok = rig
+    lib = native.load()
+    B, T, nb = 2, 2, 3
+    toks = synth.canonical_tokens(cfg, B, T, seed=68)
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    ids = toks["input_ids"][:, :n_prompt].clone()
+    ctx_id = toks["img_context_token_id"]
+    for b in range(B):
+        ids[b, (ids[b] == ctx_id).nonzero()[-1]] = 7
+    pv = synth.synthetic_frames(B * T, 224, seed=68)
+    model.img_context_token_id = ctx_id
+    dev = model.device
+    n = B * nb
+    t1 = torch.tensor([11, 12, 13, 14, 15, 16], dtype=torch.long, device=dev)
+    t2 = torch.tensor([21, 22, 23, 24, 25, 26], dtype=torch.long, device=dev)
+    parent = [2, 5, 4, 5, 0, 1]          # sequences keep their prompt (i % B == parent % B): a 3-cycle, a 2-cycle and a duplicated parent
+
+    def run(first_tokens, reorder):
+        ids_p, cu, _ = model._pack(ids.to(dev), None)
+        slot = torch.full_like(ids_p, -1, dtype=torch.int32)
+        vit = model.extract_feature(pv)
+        vis = vit.reshape(-1, vit.shape[-1]).contiguous()
+        sel = ids_p == ctx_id
+        slot[sel] = torch.arange(vis.shape[0], device=dev, dtype=torch.int32)
+        model._native(n_clips=n, out_rows=n)
+        model._prefill(ids_p, slot, cu, vis, vis.shape[0], None, None, [cu[i + 1] - 1 for i in range(B)], keep_kv=True, kv_cap=n_prompt + 8)
+        c = model._ctx
+        native.check(lib.aigv_kv_fork(c, nb, native.stream_ptr()), c)
+        out = torch.empty(n, dtype=torch.long, device=dev)
+        native.check(lib.aigv_decode_step(c, first_tokens.data_ptr(), out.data_ptr(), native.stream_ptr()), c)
+        if reorder:
+            lens = [n_prompt + 1] * n
+            native.check(lib.aigv_kv_reorder(c, native.i32_array(parent), native.i32_array(lens), n, native.stream_ptr()), c)
+        native.check(lib.aigv_decode_step(c, t2.data_ptr(), out.data_ptr(), native.stream_ptr()), c)
+        return model._row_logits(n).clone(), out.clone()
+
+    la, ta = run(t1, True)
+    lb, tb = run(t1[torch.tensor(parent, device=dev)], False)       # every sequence is fed its parent's token directly
+    assert torch.equal(la, lb) and torch.equal(ta, tb)
+    lc, _ = run(t1, False)
+    assert not torch.equal(la, lc)                                   # (the reorder did change what was cached)
+    # argument checks are loud
+    c = model._ctx
+    bad = native.i32_array([0, 1, 2, 3, 4, 9])
+    assert lib.aigv_kv_reorder(c, bad, native.i32_array([n_prompt] * n), n, native.stream_ptr()) != 0
+    assert lib.aigv_kv_reorder(c, native.i32_array(parent), native.i32_array([n_prompt] * n), n - 1, native.stream_ptr()) != 0

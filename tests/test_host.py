@@ -447,11 +447,16 @@ def test_generation_logits_processors_match_transformers():
             ours = InternVLChatModel._no_repeat_ngram(n)(hist, logits.clone())
             theirs = NoRepeatNGramLogitsProcessor(n)(hist, logits.clone())
             assert torch.equal(ours, theirs), (cur, n)
-    mx, eos, pad, sampler, procs = InternVLChatModel._gen_args(dict(max_new_tokens=7, eos_token_id=[5, 9], repetition_penalty=1.2, no_repeat_ngram_size=2), {})
+    mx, eos, pad, sampler, procs, beams = InternVLChatModel._gen_args(dict(max_new_tokens=7, eos_token_id=[5, 9], repetition_penalty=1.2, no_repeat_ngram_size=2), {})
     assert (mx, eos, pad, sampler, len(procs)) == (7, [5, 9], None, None, 2)
     assert InternVLChatModel._gen_args(None, dict(repetition_penalty=1.0, no_repeat_ngram_size=0))[4] == []
+    assert beams is None
+    assert InternVLChatModel._gen_args(dict(num_beams=3, length_penalty=0.5, early_stopping=True), {})[5] == dict(num_beams=3, length_penalty=0.5, early_stopping=True)
+    assert InternVLChatModel._gen_args(dict(num_beams=2), {})[5] == dict(num_beams=2, length_penalty=1.0, early_stopping=False)
     with pytest.raises(NotImplementedError):
-        InternVLChatModel._gen_args(dict(num_beams=2), {})
+        InternVLChatModel._gen_args(dict(num_beams=2, do_sample=True), {})
+    with pytest.raises(NotImplementedError):
+        InternVLChatModel._gen_args(dict(num_beams=2, num_return_sequences=2), {})
 
 
 def test_full_size_round3_fixture_is_plain_data(golden_dir):
@@ -473,3 +478,73 @@ def test_full_size_round3_fixture_is_plain_data(golden_dir):
     # the older fixture loads as plain data too
     g2 = torch.load(os.path.join(golden_dir, "e2e_8b_full.pt"), weights_only=True)
     assert "planted/201" in g2["cases"]
+
+
+def _tiny_hf_lm(vocab: int, seed: int):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(seed)
+    cfg = LlamaConfig(vocab_size=vocab, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=64, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    m = LlamaForCausalLM(cfg).double().eval()
+    with torch.no_grad():                      # sharper than the init's near-uniform logits, so that hypotheses differ in score
+        m.lm_head.weight.mul_(12.0)
+    return m
+
+
+@pytest.mark.parametrize("num_beams,eos,length_penalty,early_stopping,max_new,procs", [
+    (2, [], 1.0, False, 6, {}),
+    (3, [2], 1.0, False, 8, {}),
+    (4, [2, 5], 1.0, False, 7, {}),
+    (3, [2], 2.0, False, 8, {}),
+    (3, [2], 0.0, "never", 8, {}),
+    (3, [2], 1.0, True, 8, {}),
+    (4, [2], 0.6, True, 9, {}),
+    (3, [2], 1.0, False, 8, {"repetition_penalty": 1.3}),
+    (3, [2], 1.0, False, 8, {"no_repeat_ngram_size": 2}),
+])
+def test_beam_search_follows_transformers(num_beams, eos, length_penalty, early_stopping, max_new, procs):
+    """beam.beam_search against transformers' own generate(num_beams > 1) on a small random causal LM, driven - as the reference drives its
+    language model (modeling_internvl_chat.py:798-809) - through inputs_embeds, over several prompts, seeds and search settings: the same
+    sequences, token for token.  The model is only a source of logits here (fp64, so that HF's cached forward and this test's re-computed
+    one round to the same fp32 numbers)."""
+    from aigv_assessor_amd import beam
+    V, P, B = 11, 5, 3
+    checked = 0
+    for seed in range(4):
+        lm = _tiny_hf_lm(V, seed)
+        g = torch.Generator().manual_seed(100 + seed)
+        prompt = torch.randint(3, V, (B, P), generator=g)
+        emb = lm.get_input_embeddings()(prompt)
+        kw = dict(max_new_tokens=max_new, num_beams=num_beams, do_sample=False, length_penalty=length_penalty, early_stopping=early_stopping,
+                  eos_token_id=(eos if eos else None), pad_token_id=0, **procs)
+        with torch.no_grad():
+            want = lm.generate(inputs_embeds=emb, attention_mask=torch.ones(B, P, dtype=torch.long), **kw)
+        # the same search over a re-computing step function: histories reordered instead of a KV cache
+        hist = {"tok": torch.zeros((B, num_beams, 0), dtype=torch.long)}
+
+        def logits_of(tok_hist):   # [B, nb, t] -> fp32 [B, nb, V]
+            t = tok_hist.shape[2]
+            e = emb[:, None].expand(B, num_beams, P, emb.shape[-1]).reshape(B * num_beams, P, -1)
+            if t:
+                e = torch.cat((e, lm.get_input_embeddings()(tok_hist.reshape(B * num_beams, t))), dim=1)
+            with torch.no_grad():
+                return lm(inputs_embeds=e).logits[:, -1, :].float().view(B, num_beams, V)
+
+        def reorder(parent):
+            hist["tok"] = torch.gather(hist["tok"], 1, parent[:, :, None].expand(-1, -1, hist["tok"].shape[2]))
+
+        def step(tok):
+            hist["tok"] = torch.cat((hist["tok"], tok[:, :, None]), dim=2)
+            return logits_of(hist["tok"])
+
+        processors = []
+        if "repetition_penalty" in procs:
+            processors.append(InternVLChatModel._repetition_penalty(procs["repetition_penalty"]))
+        if "no_repeat_ngram_size" in procs:
+            processors.append(InternVLChatModel._no_repeat_ngram(procs["no_repeat_ngram_size"]))
+        first = logits_of(hist["tok"])[:, 0, :]
+        got = beam.beam_search(first, step, reorder, num_beams, max_new, eos_ids=eos, pad_id=0, length_penalty=length_penalty,
+                               early_stopping=early_stopping, processors=processors)
+        assert got.shape == want.shape and torch.equal(got, want), (seed, got.tolist(), want.tolist())
+        checked += 1
+    assert checked == 4
