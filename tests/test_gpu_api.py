@@ -422,12 +422,25 @@ def test_beam_search_generate_matches_the_oracle_driven_search(rig, num_beams, e
     assert got.shape == want.shape and torch.equal(got, want), (got.tolist(), want.tolist())
 
 
-def test_kv_reorder_is_a_gather_of_the_parents_caches(rig):
+@pytest.mark.parametrize("size", ["tiny", "8b-widths"])
+def test_kv_reorder_is_a_gather_of_the_parents_caches(rig, size):
     """aigv_kv_reorder: after it, sequence i decodes exactly as sequence parent[i] would have - bit for bit - and the gather is not in
-    place (a permutation with a cycle and a duplicated parent)."""
-    import ctypes as C
+    place (a permutation with a cycle and a duplicated parent).  Also at the 8B widths (8 kv heads x 128, ~600-token prompts, two
+    decoder layers), where the decode step takes its width-specific forms."""
     from aigv_assessor_amd import native
-    model, cfg, sd, tok = rig
+    if size == "tiny":
+        model, cfg, sd, tok = rig
+        px = 224
+    else:
+        from aigv_assessor_amd.modeling import InternVLChatModel
+        cfg = pkg.internvl2_8b()
+        cfg.vision_config.num_hidden_layers = 1
+        cfg.llm_config.num_hidden_layers = 2
+        cfg.llm_config.vocab_size = 4096
+        model = InternVLChatModel(cfg)
+        model.load_state_dict(synth.make_state_dict(cfg, seed=69, rich=True))
+        model.eval().cuda()
+        px = 448
     lib = native.load()
     B, T, nb = 2, 2, 3
     toks = synth.canonical_tokens(cfg, B, T, seed=68)
@@ -436,7 +449,7 @@ def test_kv_reorder_is_a_gather_of_the_parents_caches(rig):
     ctx_id = toks["img_context_token_id"]
     for b in range(B):
         ids[b, (ids[b] == ctx_id).nonzero()[-1]] = 7
-    pv = synth.synthetic_frames(B * T, 224, seed=68)
+    pv = synth.synthetic_frames(B * T, px, seed=68)
     model.img_context_token_id = ctx_id
     dev = model.device
     n = B * nb
