@@ -316,6 +316,7 @@ def main():
     ap.add_argument("--attn-kernel", type=int, default=0, choices=[0, 4, 8],
                     help="A/B: force one form of the prefill-attention kernel (aigv_tune_attention): 4 / 8 waves per workgroup; 0 = default")
     ap.add_argument("--tune-gemm", type=int, default=0, help="A/B: aigv_tune_gemm mode word (kernel choice + 16 * (1 + 256-kernel schedule variant))")
+    ap.add_argument("--serial-motion", action="store_true", help="A/B: run the SlowFast branch on the launch stream in front of the ViT instead of on a side stream beside it")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
     ap.add_argument("--no-parity", action="store_true", help="skip the score / level comparison with the reference's recorded outputs (tests/golden/e2e_8b_r3.pt; ~1.5 min of CPU weight generation)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on gloo / CPU with a stand-in model (no measurement)")
@@ -392,6 +393,8 @@ def main():
     if args.motion == "slowfast" and not dry:
         from aigv_assessor_amd.slowfast import SlowFastR50
         model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=0))
+        if args.serial_motion:
+            model.overlap_motion_branch = False
     flags = torch.ones(B * T, 1, dtype=torch.long)
     ids, labels, am = toks["input_ids"], toks["labels"], toks["attention_mask"]
     frames_u8 = None
