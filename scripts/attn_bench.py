@@ -25,9 +25,9 @@ def run(name, d, causal, h, hk, lens, iters=60, uniform=True):
     print(f"{name}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s", flush=True)
 import os
 for rep in range(2):
-  for nw in ((int(os.environ["ATTN_ONLY"]),) if os.environ.get("ATTN_ONLY") else (0,) if not os.environ.get("AB_WAVES") else (4, 8, 43, 83, 0)):
+  for nw in ((int(os.environ["ATTN_ONLY"]),) if os.environ.get("ATTN_ONLY") else (0,) if not os.environ.get("AB_WAVES") else (4, 8, 0)):
     native.check(lib.aigv_tune_attention(nw))
-    print(f"-- kernel choice: {({0: 'default', 4: '4 waves x 32 rows, two-deep ring', 8: '8 waves', 43: '4 waves, three-deep ring', 83: '8 waves, three-deep ring'})[nw]}")
+    print(f"-- kernel choice: {({0: 'default', 4: '4 waves x 32 rows', 8: '8 waves'})[nw]}")
     run("vit  d64  32x1025 h16", 64, False, 16, 16, [1025] * 32)
     run("vit  d64  32x1024 h16", 64, False, 16, 16, [1024] * 32)
     run("llm  d128 4x2177 h32/8", 128, True, 32, 8, [2177] * 4)

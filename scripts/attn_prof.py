@@ -5,7 +5,7 @@ from aigv_assessor_amd import native
 from aigv_assessor_amd.native import ptr
 import os
 lib = native.load()
-native.check(lib.aigv_tune_attention(int(os.environ.get("ATTN_KERNEL", "0"))))   # 0 default, 4 / 8 waves, 43 / 83 three-deep ring
+native.check(lib.aigv_tune_attention(int(os.environ.get("ATTN_KERNEL", "0"))))   # 0 default, 4 / 8 waves per workgroup
 BF = torch.bfloat16
 def run(d, causal, h, hk, lens, iters=6):
     T = sum(lens); g = h // hk
