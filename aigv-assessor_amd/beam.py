@@ -3,9 +3,9 @@
 The reference decodes through HF's ``language_model.generate(inputs_embeds=...)`` (modeling_internvl_chat.py:798-809), so ``num_beams > 1`` in a
 generation config means transformers' beam search.  This module restates that published algorithm (transformers/generation/utils.py,
 ``GenerationMixin._beam_search`` and its helpers ``_get_top_k_continuations`` / ``_get_running_beams_for_next_iteration`` /
-``_update_finished_beams`` / ``_check_early_stop_heuristic`` - the vectorised form of transformers >= 4.50, which keeps the hypotheses of
-the ``BeamSearchScorer`` the reference's pinned 4.37 used) and is pinned against the installed transformers on a small causal LM in
-tests/test_host.py.  With ``inputs_embeds`` HF's ``input_ids`` start empty, so the decoder prompt length is 0 here and every length below
+``_update_finished_beams`` / ``_check_early_stop_heuristic`` - the vectorised form of transformers >= 4.50; the ``BeamSearchScorer`` of
+the 4.37 the reference was written against runs the same search with the same scores, top-2k candidate rule and length penalty) and is
+pinned token for token against the INSTALLED transformers' ``generate`` on a small causal LM in tests/test_host.py.  With ``inputs_embeds`` HF's ``input_ids`` start empty, so the decoder prompt length is 0 here and every length below
 counts GENERATED tokens.
 
     first_logits  fp32 [B, V]: next-token logits behind the prompt (all beams of an item start from the same state)
