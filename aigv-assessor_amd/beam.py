@@ -5,8 +5,8 @@ generation config means transformers' beam search.  This module restates that pu
 ``GenerationMixin._beam_search`` and its helpers ``_get_top_k_continuations`` / ``_get_running_beams_for_next_iteration`` /
 ``_update_finished_beams`` / ``_check_early_stop_heuristic`` - the vectorised form of transformers >= 4.50; the ``BeamSearchScorer`` of
 the 4.37 the reference was written against runs the same search with the same scores, top-2k candidate rule and length penalty) and is
-pinned token for token against the INSTALLED transformers' ``generate`` on a small causal LM in tests/test_host.py.  With ``inputs_embeds`` HF's ``input_ids`` start empty, so the decoder prompt length is 0 here and every length below
-counts GENERATED tokens.
+pinned token for token against the INSTALLED transformers' ``generate`` on a small causal LM in tests/test_host.py.  With ``inputs_embeds``
+HF's ``input_ids`` start empty, so the decoder prompt length is 0 here and every length below counts GENERATED tokens.
 
     first_logits  fp32 [B, V]: next-token logits behind the prompt (all beams of an item start from the same state)
     step(tok)     tok long [B, nb]: the token each running beam just took (after ``reorder``) -> fp32 logits [B, nb, V]
