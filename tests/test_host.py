@@ -478,6 +478,11 @@ def test_full_size_round3_fixture_is_plain_data(golden_dir):
     # the older fixture loads as plain data too
     g2 = torch.load(os.path.join(golden_dir, "e2e_8b_full.pt"), weights_only=True)
     assert "planted/201" in g2["cases"]
+    # the second batch of the benched shape (make_golden_8b_r3b.py): same weights, inputs of seed 1
+    g3 = torch.load(os.path.join(golden_dir, "e2e_8b_r3b.pt"), weights_only=True)
+    assert g3["w_seed"] == g["w_seed"] and g3["overrides"] == g["overrides"]
+    b3 = g3["cases"]["batch4/bf16"]
+    assert (b3["B"], b3["T"], b3["seed"]) == (4, 8, 1) and b3["logit"].numel() == 40 and not torch.equal(b3["score1"], b4["score1"])
 
 
 def _tiny_hf_lm(vocab: int, seed: int):
