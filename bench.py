@@ -317,6 +317,7 @@ def main():
                     help="A/B: force one form of the prefill-attention kernel (aigv_tune_attention): 4 / 8 waves per workgroup; 0 = default")
     ap.add_argument("--tune-gemm", type=int, default=0, help="A/B: aigv_tune_gemm mode word (kernel choice + 16 * (1 + 256-kernel schedule variant))")
     ap.add_argument("--serial-motion", action="store_true", help="A/B: run the SlowFast branch on the launch stream in front of the ViT instead of on a side stream beside it")
+    ap.add_argument("--no-settle", action="store_true", help="skip the untimed settling batches in front of the timed region")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
     ap.add_argument("--no-parity", action="store_true", help="skip the score / level comparison with the reference's recorded outputs (tests/golden/e2e_8b_r3.pt; ~1.5 min of CPU weight generation)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on gloo / CPU with a stand-in model (no measurement)")
@@ -425,6 +426,30 @@ def main():
     gc.collect()
     gc.freeze()   # no generation-2 sweep over the (large, static) module graph inside the timed region
 
+    # ---- settling (untimed, reported): some boxes of the pool run their first 10-20 s of GPU work at less than half speed with every kernel at its
+    # usual duration (three of ~50 calls of round 3; it decays by itself and the next process is normal).  Batches of 5 more untimed
+    # steps until two consecutive batches agree within 3 %, at most 30 s; on a healthy box this is two batches.  The timed region below is untouched:
+    # exactly K steps, fenced on both sides; `settle_ms_per_step` lists what the batches read so that nothing is hidden.
+    settle = []
+    if not args.no_settle:
+        t_settle = time.perf_counter()
+        while True:
+            fence()
+            tb = time.perf_counter()
+            for _ in range(5):
+                out = step()
+            fence()
+            bt = torch.tensor([(time.perf_counter() - tb) / 5 * 1e3], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(bt, op=dist.ReduceOp.MAX)      # every rank takes the same decision
+            settle.append(float(bt.item()))
+            stop = torch.tensor([1.0 if (len(settle) >= 2 and abs(settle[-1] - settle[-2]) <= 0.03 * settle[-1]) or time.perf_counter() - t_settle > 30.0 else 0.0],
+                                dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+            if stop.item() > 0:
+                break
+
     # ---- the timed region: exactly K steps, barrier + synchronize on both sides, no instrumentation ----
     fence()
     t0 = time.perf_counter()
@@ -492,6 +517,7 @@ def main():
             "algorithmic_tflop_per_clip": fl["total"] / 1e12,
             "executed_tflop_per_clip": (fl["total"] if args.all_rows else fl["executed"]) / 1e12,
             "host_enqueue_ms_per_step": host_enqueue_ms,
+            "settle_ms_per_step": settle,
             "achieved_tflops_whole_step_per_gpu": (fl["total"] if args.all_rows else fl["executed"]) * B / dt / 1e12 / world * args.steps,
         }
         if prof:
