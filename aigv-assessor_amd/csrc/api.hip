@@ -44,6 +44,21 @@ struct ProfRec {
   double flops, bytes;
 };
 
+// Row plan of one pass (round 4): how the rows of the activation matrices divide into INDEPENDENT sequences (InternViT frames,
+// InternLM2 clips) and, from that alone, which kernel form every row runs in - so that a row's bits never depend on its batch mates:
+//   body: rows [0, 256 * floor(L / 256)) of every sequence -> full-K 256x256 kernel, whole tiles addressed through the half-tile table;
+//   tail: the remaining < 256 rows of every sequence      -> one or two (ragged) half tiles; run with a split-K factor that is a
+//                                                            function of the GEMM's (N, K) only (1 = inside the body's launch);
+//   tiny: tails of <= TINY_TAIL rows (InternViT: 1025 = 4 * 256 + 1) -> the weight-streaming skinny kernel in its fixed 4-slice form.
+struct RowPlan {
+  struct Tiny { int row0, stride_rows, count; };   // rows row0 + i * stride_rows, i < count
+  std::vector<int32_t> key;     // the cu_seqlens the plan was made from (cache key)
+  std::vector<Tiny> tiny;
+  int rows = 0, body_halves = 0, tail_halves = 0, tail_rows = 0;
+  int32_t* d_tab = nullptr;     // device: (base row, valid rows) per half, body halves first
+  int cap_halves = 0;
+};
+
 }  // namespace
 
 struct aigv_ctx {
@@ -79,11 +94,14 @@ struct aigv_ctx {
   std::vector<LlmLayerFp8> llm8;
   uint8_t* q8 = nullptr;       // [max_tokens, max(H, I)] e4m3 activations of the GEMM about to run
   float* q8_scale = nullptr;   // [max_tokens]
+  RowPlan rp_vit, rp_llm;           // row plans of the InternViT frames (cached per chunk size) and of the current prefill's clips
+  const RowPlan* cur_rp = nullptr;  // plan the InternLM2 layer helpers run under (null: batch-level dispatch, aigv_llm_extend)
   bool trim_last_layer = true;
   int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2
   size_t splitk_floats = 0;
   float* splitk_ws = nullptr;  // fp32 slabs of the split-K row bands: owned by the context (one launch stream per context at a time)
-  bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 3 (attention out, hidden, normed) + [64, I]
+  bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 2 (attention out, normed) + [64, I], reused per 64 consumed rows
+  bf16_t* l_trim_h = nullptr; // ... and the consumed rows' hidden states [max_out_rows + max_seqs + 64, H]
   bf16_t* l_score_ws = nullptr;
   bf16_t *kc = nullptr, *vc = nullptr;   // [layer][seq][kv head][cap][D]
   bf16_t *kc_alt = nullptr, *vc_alt = nullptr;   // second cache of the same size, made by the first aigv_kv_reorder (beam search gathers into it, then the two swap)
@@ -182,6 +200,12 @@ struct ProfScope {
     hipEventRecord(r.b, s);
     c->recs.push_back(r);
   }
+};
+
+struct RowPlanScope {   // the InternLM2 layer helpers run under `rp` inside the scope
+  aigv_ctx* c;
+  RowPlanScope(aigv_ctx* c_, const RowPlan* rp) : c(c_) { c->cur_rp = rp; }
+  ~RowPlanScope() { c->cur_rp = nullptr; }
 };
 
 struct GemmClassScope {   // GEMM launches inside the scope are booked under `cls` (per-class roofline entries of bench.py)
@@ -390,7 +414,7 @@ int resolved_gemm_mode(const aigv_ctx* c) { return (c && c->gemm_mode >= 0) ? c-
 
 int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
-  const int mode = resolved_gemm_mode(c);
+  const int mode = resolved_gemm_mode(c) == 3 ? 0 : resolved_gemm_mode(c);
   if (const int right = split_columns(a.M, a.N, a.K, epi, mode)) {
     TRY(run_gemm(c, col_slice(a, 0, a.N - right), epi, s));
     return launch_one(c, col_slice(a, a.N - right, right), epi, false, s);
@@ -420,6 +444,133 @@ int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
     return launch_one(c, bot, epi, false, s);
   }
   return 0;
+}
+
+// ---- per-sequence row plans (struct RowPlan above) ------------------------------------------------------------------------------------
+constexpr int TINY_TAIL = 4;
+
+// cu[0..n_seq]: row offsets of the sequences inside the activation matrices.  Builds the plan and uploads its table (kernel-argument
+// writes on `s`: no host synchronisation); a plan made from the same cu is reused as it is.
+int build_row_plan(aigv_ctx* c, RowPlan& rp, const int32_t* cu, int n_seq, hipStream_t s) {
+  if ((int)rp.key.size() == n_seq + 1 && std::equal(rp.key.begin(), rp.key.end(), cu)) return 0;
+  rp.key.clear();
+  rp.tiny.clear();
+  std::vector<int32_t> body, tail;
+  bool uniform = true;
+  for (int b = 1; b < n_seq; ++b) uniform = uniform && (cu[b + 1] - cu[b] == cu[1] - cu[0]);
+  rp.tail_rows = 0;
+  for (int b = 0; b < n_seq; ++b) {
+    const int L = cu[b + 1] - cu[b], nb = L / 256, rem = L % 256, r0 = cu[b] + nb * 256;
+    for (int j = 0; j < 2 * nb; ++j) { body.push_back(cu[b] + j * 128); body.push_back(128); }
+    if (rem == 0) continue;
+    if (rem <= TINY_TAIL) {
+      if (!uniform) rp.tiny.push_back({r0, 1, rem});
+      else if (b == 0)
+        for (int j = 0; j < rem; ++j) rp.tiny.push_back({r0 + j, L, n_seq});
+      continue;
+    }
+    tail.push_back(r0); tail.push_back(std::min(rem, 128));
+    if (rem > 128) { tail.push_back(r0 + 128); tail.push_back(rem - 128); }
+    rp.tail_rows += rem;
+  }
+  rp.body_halves = (int)body.size() / 2;
+  rp.tail_halves = (int)tail.size() / 2;
+  rp.rows = cu[n_seq];
+  if (rp.body_halves + rp.tail_halves > rp.cap_halves)
+    return fail(c, AIGV_ERR_STATE, "row plan: %d half tiles exceed the table's %d", rp.body_halves + rp.tail_halves, rp.cap_halves);
+  body.insert(body.end(), tail.begin(), tail.end());
+  if (!body.empty()) HIPCHK(c, aigv_launch_write_ints(body.data(), (int)body.size(), rp.d_tab, s));
+  rp.key.assign(cu, cu + n_seq + 1);
+  return 0;
+}
+
+// Split-K factor of the TAIL half tiles of a GEMM: a function of (N, K) only - never of the batch - sized so that two tail row tiles
+// (four clips' 128-row remainders, the benched batch) come to about one round of 256 workgroups.  1 = the tail rides in the body's launch.
+int tail_slices(int N, int K) {
+  static const char* env = getenv("AIGV_TAIL_SLICES");   // A/B knob: one factor for every shape it divides
+  const int tn = N / 256, nk = K / 64;
+  int best = 1;
+  for (int S : {2, 4, 8})
+    if (nk % S == 0 && nk / S >= 8 && 2 * tn * S <= 256) best = S;
+  if (env) { const int v = atoi(env); if (v == 1 || (v > 1 && nk % v == 0 && nk / v >= 4)) best = v; }
+  return best;
+}
+
+int launch_tab(aigv_ctx* c, const GemmArgs& a, int epi, const int32_t* tab, int halves, int rows, int S, hipStream_t s) {
+  if (halves <= 0) return 0;
+  GemmArgs b = a;
+  b.row_tab = tab; b.tab_halves = halves;
+  GemmArgs pf = a; pf.M = rows;            // the rows this launch really computes (profile records only)
+  GEMM_PROF(c, pf, s);
+  if (S <= 1) {
+    HIPCHK(c, aigv_launch_gemm256(b, epi, s));
+    return 0;
+  }
+  float* ws = nullptr;
+  TRY(splitk_scratch(c, (size_t)S * ((halves + 1) / 2) * 256 * a.N, &ws));
+  HIPCHK(c, aigv_launch_gemm_splitk(b, epi, S, ws, s, true));
+  return 0;
+}
+
+// A GEMM whose rows follow the row plan `rp` (mode 0); modes 1 / 2 run every row on one tile kernel in full K (also batch-invariant).
+int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hipStream_t s) {
+  if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
+  if (a.M != rp.rows) return fail(c, AIGV_ERR_STATE, "row plan covers %d rows, the GEMM has %d", rp.rows, a.M);
+  const int mode = resolved_gemm_mode(c);
+  if (mode == 3) return run_gemm(c, a, epi, s);   // rounds 1-3: batch-level cost-model dispatch (A/B only: not batch-invariant)
+  if (mode == 1 || a.N < 256) return launch_one(c, a, epi, false, s);
+  if (mode == 2 && a.N % 256 == 0) return launch_one(c, a, epi, true, s);
+  if (a.N % 256) {   // N = 256 j + 128 (InternViT-6B: 3200, 9600): the last 128 columns of every row on the 128 kernel, full K
+    if (epi == EPI_SWIGLU) return launch_one(c, a, epi, false, s);
+    TRY(run_gemm_rows(c, col_slice(a, 0, a.N - 128), epi, rp, s));
+    return launch_one(c, col_slice(a, a.N - 128, 128), epi, false, s);
+  }
+  const int S = tail_slices(a.N, a.K);
+  if (rp.tail_halves == 0 || S == 1) {
+    TRY(launch_tab(c, a, epi, rp.d_tab, rp.body_halves + rp.tail_halves, rp.body_halves * 128 + rp.tail_rows, 1, s));
+  } else {
+    TRY(launch_tab(c, a, epi, rp.d_tab, rp.body_halves, rp.body_halves * 128, 1, s));
+    const size_t per_pair = (size_t)S * 256 * a.N;
+    const size_t cap = c ? c->splitk_floats : SPLITK_MAX_FLOATS;
+    const int max_halves = (int)std::min<size_t>(cap / per_pair, 4096) * 2;
+    if (max_halves < 2) return fail(c, AIGV_ERR_STATE, "split-K scratch too small for one tail tile (N=%d, %d slices)", a.N, S);
+    for (int h0 = 0; h0 < rp.tail_halves; h0 += max_halves) {
+      const int nh = std::min(max_halves, rp.tail_halves - h0);
+      TRY(launch_tab(c, a, epi, rp.d_tab + 2 * (rp.body_halves + h0), nh, nh * 128, S, s));   // (profile: ragged halves counted as full)
+    }
+  }
+  const int sk = skinny_epi(epi);
+  for (const RowPlan::Tiny& t : rp.tiny) {
+    if (sk < 0 || a.K % 128) return fail(c, AIGV_ERR_STATE, "no skinny form for epilogue %d / K=%d (tiny sequence tails)", epi, a.K);
+    const size_t ldx = (size_t)t.stride_rows * a.lda, ldo = (size_t)t.stride_rows * a.ldc, ldr = (size_t)t.stride_rows * a.ldr;
+    if (ldx > 0x7fffffffu || ldo > 0x7fffffffu || ldr > 0x7fffffffu) return fail(c, AIGV_ERR_STATE, "tiny-tail row stride overflows");
+    for (int i0 = 0; i0 < t.count; i0 += 64) {
+      const int R = std::min(64, t.count - i0);
+      const size_t r0 = (size_t)t.row0 + (size_t)i0 * t.stride_rows;
+      ProfScope ps(c, c ? c->gemm_cls : AIGV_PROF_GEMM, 2.0 * R * (double)a.N * a.K, 2.0 * (double)a.N * a.K, s);
+      hipError_t e = aigv_launch_skinny_gemm(a.A + r0 * a.lda, (int)ldx, R, a.W, a.ldw, a.N, a.K, a.bias, a.resid ? a.resid + r0 * a.ldr : nullptr,
+                                            (int)ldr, a.C + r0 * a.ldc, (int)ldo, sk, s, a.ls, 0);
+      if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "skinny tiny tails (R=%d N=%d K=%d): %s", R, a.N, a.K, hipGetErrorString(e));
+    }
+  }
+  return 0;
+}
+
+// every row in full K on one tile kernel (the 256 kernel where its shape rules allow): batch-invariant for any row layout
+int run_gemm_full(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
+  if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
+  const int mode = resolved_gemm_mode(c);
+  if (mode == 1 || a.N < 256 || (a.N % 256 && epi == EPI_SWIGLU)) return launch_one(c, a, epi, false, s);
+  if (a.N % 256) {
+    TRY(launch_one(c, col_slice(a, 0, a.N - 128), epi, true, s));
+    return launch_one(c, col_slice(a, a.N - 128, 128), epi, false, s);
+  }
+  return launch_one(c, a, epi, true, s);
+}
+
+// InternLM2 linears: under the current pass's row plan (aigv_llm_prefill), else the batch-level dispatch (aigv_llm_extend)
+int run_llm_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
+  return c->cur_rp ? run_gemm_rows(c, a, epi, *c->cur_rp, s) : run_gemm(c, a, epi, s);
 }
 
 GemmArgs gemm_args(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* C, int ldc, int M, int N, int K) {
@@ -488,9 +639,8 @@ int g_skinny_p = 0;   // aigv_tune_skinny: sub-slab form forced on the op-level 
 int run_skinny(aigv_ctx* c, const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
                const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi, hipStream_t s, int p = 1) {
   ProfScope ps(c, AIGV_PROF_SKINNY, 2.0 * R * (double)N * K, 2.0 * (double)N * K, s);
-  // mode 1 (batch-invariant bits): one fixed plan per shape - the K split of a skinny GEMM must not depend on the row count either.
-  // The mode is resolved exactly as run_gemm resolves it (context setting, else the process default of aigv_tune_gemm).
-  if (resolved_gemm_mode(c) == 1 && p == 1) p = 0;
+  // p = 0 (the scoring pass: last-layer consumed rows, motion_mlp, tiny sequence tails): the fixed 4-slice form whatever the row count, so
+  // that a row's bits do not depend on its batch; p = 1 / 2 / 4 are the decode step's forms (decode_forms).
   hipError_t e = aigv_launch_skinny_gemm(x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, epi, s, nullptr, p);
   if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP,
                                    "skinny gemm (R=%d N=%d K=%d epi=%d): %s", R, N, K, epi, hipGetErrorString(e));
@@ -557,8 +707,14 @@ static int alloc_workspaces(aigv_ctx* c) {
     if ((rc = dalloc(c, &c->l_rowidx, (size_t)k.max_out_rows + k.max_seqs + 64))) break;
     if ((rc = dalloc(c, &c->l_kvlen, (size_t)k.max_seqs))) break;
     if ((rc = dalloc(c, &c->l_packed, (size_t)64))) break;
-    if ((rc = dalloc(c, &c->l_trim, (size_t)64 * (3 * k.llm_hidden + k.llm_inter)))) break;
+    if ((rc = dalloc(c, &c->l_trim, (size_t)64 * (2 * k.llm_hidden + k.llm_inter)))) break;
+    if ((rc = dalloc(c, &c->l_trim_h, (size_t)(k.max_out_rows + k.max_seqs + 64) * k.llm_hidden))) break;
     if ((rc = dalloc(c, &c->l_neg1, (size_t)k.max_tokens))) break;
+    c->rp_vit = RowPlan(); c->rp_llm = RowPlan(); c->cur_rp = nullptr;
+    c->rp_vit.cap_halves = (int)(vr / 128) + 2 * k.vit_chunk + 2;
+    c->rp_llm.cap_halves = (int)(T / 128) + 2 * k.max_seqs + 2;
+    if ((rc = dalloc(c, &c->rp_vit.d_tab, (size_t)2 * c->rp_vit.cap_halves))) break;
+    if ((rc = dalloc(c, &c->rp_llm.d_tab, (size_t)2 * c->rp_llm.cap_halves))) break;
     {   // split-K slabs: the planner's cap, or less when no GEMM of this context can reach it (8 slices x most rows x widest N)
       const size_t widest = (size_t)std::max(std::max(std::max(2 * k.llm_inter, c->qkv_out), std::max(k.vit_inter, 3 * k.vit_hidden)), k.llm_hidden);
       const size_t rows = std::max((size_t)k.max_tokens, (size_t)k.vit_chunk * c->S);
@@ -908,13 +1064,20 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
     const int F = std::min(k.vit_chunk, n_frames - f0);
     const int rows = F * c->S;
     const bf16_t* fr = (const bf16_t*)frames + (size_t)f0 * frame_elems;
+    {   // every frame is a sequence of S rows (cached per chunk size)
+      std::vector<int32_t> cu(F + 1);
+      for (int i = 0; i <= F; ++i) cu[i] = i * c->S;
+      TRY(build_row_plan(c, c->rp_vit, cu.data(), F, s));
+    }
+    const RowPlan& rp = c->rp_vit;
     // patch embed: im2col + GEMM with the bias / position / row-remap epilogue (modeling_intern_vit.py:95-107)
     HIPCHK(c, aigv_launch_im2col(fr, F, k.num_channels, k.image_size, k.patch_size, c->Kp, c->v_col, s));
     HIPCHK(c, aigv_launch_cls_rows(c->cls_pos, c->v_x, F, c->S, Hv, s));
     {
       GemmArgs a = gemm_args(c->v_col, c->Kp, c->patch_w, c->Kp, c->v_x, Hv, F * c->np, Hv, c->Kp);
       a.bias = c->patch_b; a.pos = c->pos; a.np = c->np;
-      TRY(run_gemm(c, a, EPI_PATCH, s));
+      // (every row in full K on ONE tile kernel chosen by the shape of a frame: batch-invariant)
+      TRY(launch_one(c, a, EPI_PATCH, Hv % 256 == 0 && resolved_gemm_mode(c) != 1, s));
     }
     for (int li = 0; li < n_layers; ++li) {
       const VitLayer& L = c->vit[li];
@@ -922,7 +1085,7 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
       {
         GemmArgs a = gemm_args(c->v_t, Hv, L.qkv_w, Hv, c->v_qkv, 3 * Hv, rows, 3 * Hv, Hv);
         a.bias = L.qkv_b;
-        TRY(run_gemm(c, a, EPI_STORE, s));
+        TRY(run_gemm_rows(c, a, EPI_STORE, rp, s));
       }
       if (k.vit_qk_norm) {  // full-width RMSNorm of q and k, in place (modeling_intern_vit.py:148-151)
         HIPCHK(c, aigv_launch_rmsnorm(c->v_qkv, 3 * Hv, L.qn, c->v_qkv, 3 * Hv, rows, Hv, k.vit_eps, nullptr, s));
@@ -945,18 +1108,18 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
       {
         GemmArgs a = gemm_args(c->v_ao, Hv, L.proj_w, Hv, c->v_x, Hv, rows, Hv, Hv);
         a.bias = L.proj_b; a.ls = L.ls1; a.resid = c->v_x; a.ldr = Hv;
-        TRY(run_gemm(c, a, EPI_LS_RESID, s));
+        TRY(run_gemm_rows(c, a, EPI_LS_RESID, rp, s));
       }
       TRY(vit_norm(c, c->v_x, L.n2w, L.n2b, c->v_t, rows, s));
       {
         GemmArgs a = gemm_args(c->v_t, Hv, L.fc1_w, Hv, c->v_h, Iv, rows, Iv, Hv);
         a.bias = L.fc1_b;
-        TRY(run_gemm(c, a, EPI_GELU, s));
+        TRY(run_gemm_rows(c, a, EPI_GELU, rp, s));
       }
       {
         GemmArgs a = gemm_args(c->v_h, Iv, L.fc2_w, Iv, c->v_x, Hv, rows, Hv, Iv);
         a.bias = L.fc2_b; a.ls = L.ls2; a.resid = c->v_x; a.ldr = Hv;
-        TRY(run_gemm(c, a, EPI_LS_RESID, s));
+        TRY(run_gemm_rows(c, a, EPI_LS_RESID, rp, s));
       }
     }
     HIPCHK(c, aigv_launch_pixel_shuffle(c->v_x, c->grid, Hv, (bf16_t*)out_tokens + (size_t)f0 * c->ntok * c->proj_in, F, s));
@@ -981,12 +1144,12 @@ int aigv_project(aigv_ctx* c, const void* tokens, int rows, void* out, void* str
     {
       GemmArgs a = gemm_args(c->p_t, Pin, c->p_w1[0], Pin, c->p_mid, H, R, H, Pin);
       a.bias = c->p_b1[0];
-      TRY(run_gemm(c, a, EPI_GELU, s));
+      TRY(run_gemm_full(c, a, EPI_GELU, s));
     }
     {
       GemmArgs a = gemm_args(c->p_mid, H, c->p_w2[0], H, (bf16_t*)out + (size_t)r0 * H, H, R, H, H);
       a.bias = c->p_b2[0];
-      TRY(run_gemm(c, a, EPI_STORE, s));
+      TRY(run_gemm_full(c, a, EPI_STORE, s));
     }
   }
   return 0;
@@ -1007,9 +1170,9 @@ int aigv_motion_project(aigv_ctx* c, const void* motion_feature, int n_clips, vo
   for (int r0 = 0; r0 < n_clips; r0 += 64) {
     const int R = std::min(64, n_clips - r0);
     TRY(run_skinny(c, c->p_t + (size_t)r0 * Md, Md, R, c->p_w1[1], Md, H, Md, c->p_b1[1], nullptr, 0,
-                   c->p_mid + (size_t)r0 * H, H, 3 /*gelu*/, s));
+                   c->p_mid + (size_t)r0 * H, H, 3 /*gelu*/, s, 0));
     TRY(run_skinny(c, c->p_mid + (size_t)r0 * H, H, R, c->p_w2[1], H, H, H, c->p_b2[1], nullptr, 0,
-                   (bf16_t*)out + (size_t)r0 * H, H, 0 /*store*/, s));
+                   (bf16_t*)out + (size_t)r0 * H, H, 0 /*store*/, s, 0));
   }
   return 0;
 }
@@ -1067,7 +1230,7 @@ static int llm_layer_qkv(aigv_ctx* c, int li, int T, hipStream_t s) {
     TRY(run_gemm_fp8(c, nullptr, H, H, c->llm8[li].wqkv, c->llm8[li].s_wqkv, c->l_qkv, c->qkv_out, T, c->qkv_out, EPI_STORE, nullptr, 0, s));
   } else {
     HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.an, c->l_t, H, T, H, k.rms_eps, nullptr, s));
-    TRY(run_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
+    TRY(run_llm_gemm(c, gemm_args(c->l_t, H, L.wqkv, H, c->l_qkv, c->qkv_out, T, c->qkv_out, H), EPI_STORE, s));
   }
   HIPCHK(c, aigv_launch_rope(c->l_qkv, c->qkv_out, c->l_pos, c->rope_cos, c->rope_sin, T, 1, g + 2, nkv, D, s, g));
   return 0;
@@ -1089,13 +1252,13 @@ static int llm_layer_post(aigv_ctx* c, int li, int T, hipStream_t s) {
   {
     GemmArgs a = gemm_args(c->l_ao, H, L.wo, H, c->l_h, H, T, H, H);
     a.resid = c->l_h; a.ldr = H;
-    TRY(run_gemm(c, a, EPI_RESID, s));
+    TRY(run_llm_gemm(c, a, EPI_RESID, s));
   }
   HIPCHK(c, aigv_launch_rmsnorm(c->l_h, H, L.fn, c->l_t, H, T, H, k.rms_eps, nullptr, s));
-  TRY(run_gemm(c, gemm_args(c->l_t, H, L.w13, H, c->l_ffn, I, T, 2 * I, H), EPI_SWIGLU, s));
+  TRY(run_llm_gemm(c, gemm_args(c->l_t, H, L.w13, H, c->l_ffn, I, T, 2 * I, H), EPI_SWIGLU, s));
   GemmArgs a = gemm_args(c->l_ffn, I, L.w2, I, c->l_h, H, T, H, I);
   a.resid = c->l_h; a.ldr = H;
-  TRY(run_gemm(c, a, EPI_RESID, s));
+  TRY(run_llm_gemm(c, a, EPI_RESID, s));
   return 0;
 }
 
@@ -1127,6 +1290,9 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
   if (B + 1 > AIGV_SMALL_INTS / 2) return fail(c, AIGV_ERR_ARG, "at most %d clips per prefill call", AIGV_SMALL_INTS / 2 - 1);
   // positions / sequence ids / cu_seqlens are produced on the device from cu passed as a kernel argument
   HIPCHK(c, aigv_launch_seqpos(cu, B, c->l_pos, c->l_seq, c->l_cu, T, s));
+  // every clip is a sequence: the kernel form of a row follows from its place in its own clip (struct RowPlan)
+  TRY(build_row_plan(c, c->rp_llm, cu, B, s));
+  RowPlanScope rps(c, c->fp8_llm ? nullptr : &c->rp_llm);
 
   HIPCHK(c, aigv_launch_embed(ids, slot, c->tok_emb, (const bf16_t*)vis, (const bf16_t*)motion, n_vis, c->l_h, T, H, s));
   TRY(upload_out_rows(c, score_rows, score != nullptr, B, logit_rows, R, T, s));
@@ -1141,7 +1307,8 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
     while (cu[b + 1] <= v) ++b;
     q_tail = std::max(q_tail, cu[b + 1] - v);
   }
-  const bool trim = c->trim_last_layer && n_out > 0 && n_out <= 64 && H % 128 == 0 && I % 128 == 0;
+  // (the rule is per clip - at most 16 consumed rows per clip on average - so a clip takes the same path whatever its batch)
+  const bool trim = c->trim_last_layer && n_out > 0 && n_out <= 16 * B && H % 128 == 0 && I % 128 == 0;
   double attn_flops = 0;
   for (int b = 0; b < B; ++b) { const double L = cu[b + 1] - cu[b]; attn_flops += 4.0 * (L * (L + 1) / 2) * D * k.llm_heads; }
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
@@ -1170,13 +1337,19 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       HIPCHK(c, aigv_launch_attention(a, D, s));
     }
     if (trim && li == k.llm_layers - 1) {
-      bf16_t *t_ao = c->l_trim, *t_h = t_ao + (size_t)64 * H, *t_n = t_h + (size_t)64 * H, *t_ffn = t_n + (size_t)64 * H;
-      HIPCHK(c, aigv_launch_gather_rows(c->l_ao, H, c->l_rowidx, n_out, t_ao, H, s));
-      HIPCHK(c, aigv_launch_gather_rows(c->l_h, H, c->l_rowidx, n_out, t_h, H, s));
-      TRY(run_skinny(c, t_ao, H, n_out, L.wo, H, H, H, nullptr, t_h, H, t_h, H, 1, s));
-      HIPCHK(c, aigv_launch_rmsnorm(t_h, H, L.fn, t_n, H, n_out, H, k.rms_eps, nullptr, s));
-      TRY(run_skinny(c, t_n, H, n_out, L.w13, H, 2 * I, H, nullptr, nullptr, 0, t_ffn, I, 2, s));
-      TRY(run_skinny(c, t_ffn, I, n_out, L.w2, I, H, I, nullptr, t_h, H, t_h, H, 1, s));
+      // 64 rows at a time through the weight-streaming kernel in its fixed 4-slice form (p = 0: the same bits whatever the row count);
+      // the finished rows collect in l_trim_h, in l_rowidx order
+      bf16_t *t_ao = c->l_trim, *t_n = t_ao + (size_t)64 * H, *t_ffn = t_n + (size_t)64 * H, *t_h = c->l_trim_h;
+      for (int r0 = 0; r0 < n_out; r0 += 64) {
+        const int nr = std::min(64, n_out - r0);
+        bf16_t* h = t_h + (size_t)r0 * H;
+        HIPCHK(c, aigv_launch_gather_rows(c->l_ao, H, c->l_rowidx + r0, nr, t_ao, H, s));
+        HIPCHK(c, aigv_launch_gather_rows(c->l_h, H, c->l_rowidx + r0, nr, h, H, s));
+        TRY(run_skinny(c, t_ao, H, nr, L.wo, H, H, H, nullptr, h, H, h, H, 1, s, 0));
+        HIPCHK(c, aigv_launch_rmsnorm(h, H, L.fn, t_n, H, nr, H, k.rms_eps, nullptr, s));
+        TRY(run_skinny(c, t_n, H, nr, L.w13, H, 2 * I, H, nullptr, nullptr, 0, t_ffn, I, 2, s, 0));
+        TRY(run_skinny(c, t_ffn, I, nr, L.w2, I, H, I, nullptr, h, H, h, H, 1, s, 0));
+      }
       TRY(final_rows(c, score, B, R, argmax, t_h, true, s));
       break;
     }
@@ -1384,7 +1557,7 @@ int aigv_set_row_trimming(aigv_ctx* c, int on) {
 
 int aigv_set_gemm_mode(aigv_ctx* c, int mode) {
   if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_gemm_mode: null context");
-  if (mode < -1 || mode > 2) return fail(c, AIGV_ERR_ARG, "aigv_set_gemm_mode: mode must be -1 (process default), 0 (auto), 1 (128 tile) or 2 (256 tile)");
+  if (mode < -1 || mode > 3) return fail(c, AIGV_ERR_ARG, "aigv_set_gemm_mode: mode must be -1 (process default), 0 (row plans), 1 (128 tile), 2 (256 tile) or 3 (batch-level dispatch)");
   c->gemm_mode = mode;
   return 0;
 }
@@ -1569,6 +1742,27 @@ int aigv_op_gemm(const void* A, int lda, const void* W_, int ldw, void* C, int l
   a.bias = (const bf16_t*)bias; a.ls = (const bf16_t*)ls; a.resid = (const bf16_t*)resid; a.ldr = ldr;
   a.pos = (const bf16_t*)pos; a.np = np;
   return run_gemm(nullptr, a, epi, (hipStream_t)stream);
+}
+
+// aigv_op_gemm with the rows divided into independent sequences (cu_host[0..n_seq], cu[0] = 0, cu[n_seq] = M): the dispatch the scoring
+// pass uses (struct RowPlan).  Test entry point: allocates the plan's table per call and synchronises the stream before freeing it.
+int aigv_op_gemm_rows(const void* A, int lda, const void* W_, int ldw, void* C, int ldc, const void* bias, const void* ls,
+                      const void* resid, int ldr, const int32_t* cu_host, int n_seq, int N, int K, int epi, void* stream) {
+  if (!cu_host || n_seq < 1 || cu_host[0] != 0) return fail(nullptr, AIGV_ERR_ARG, "aigv_op_gemm_rows: bad cu_seqlens");
+  for (int b = 0; b < n_seq; ++b)
+    if (cu_host[b + 1] <= cu_host[b]) return fail(nullptr, AIGV_ERR_ARG, "aigv_op_gemm_rows: empty sequence %d", b);
+  if (epi == EPI_PATCH) return fail(nullptr, AIGV_ERR_ARG, "aigv_op_gemm_rows: no patch epilogue");
+  const int M = cu_host[n_seq];
+  GemmArgs a = gemm_args((const bf16_t*)A, lda, (const bf16_t*)W_, ldw, (bf16_t*)C, ldc, M, N, K);
+  a.bias = (const bf16_t*)bias; a.ls = (const bf16_t*)ls; a.resid = (const bf16_t*)resid; a.ldr = ldr;
+  RowPlan rp;
+  rp.cap_halves = M / 128 + 2 * n_seq + 2;
+  HIPCHK(nullptr, hipMalloc((void**)&rp.d_tab, (size_t)2 * rp.cap_halves * sizeof(int32_t)));
+  int rc = build_row_plan(nullptr, rp, cu_host, n_seq, (hipStream_t)stream);
+  if (!rc) rc = run_gemm_rows(nullptr, a, epi, rp, (hipStream_t)stream);
+  hipStreamSynchronize((hipStream_t)stream);
+  hipFree(rp.d_tab);
+  return rc;
 }
 
 int aigv_op_gemm_splitk(const void* A, int lda, const void* W_, int ldw, void* C, int ldc, const void* bias, const void* ls,
@@ -1756,8 +1950,8 @@ int aigv_tune_gemm(int mode, double rate256) {
   mode &= 1023;
   const int vsel = mode >> 4;
   mode &= 15;
-  if (mode < 0 || mode > 2 || vsel < 0 || vsel > 4)
-    return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_gemm: mode must be 0 (auto), 1 (128 tile) or 2 (256 tile)");
+  if (mode < 0 || mode > 3 || vsel < 0 || vsel > 4)
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_gemm: mode must be 0 (auto), 1 (128 tile), 2 (256 tile) or 3 (batch-level dispatch in the scoring pass)");
   if (vsel > 0) g_gemm256_variant = vsel - 1;
   g_gemm_mode = mode;
   if (rate256 > 0) g_rate256 = rate256;

@@ -199,12 +199,20 @@ hipError_t launch(const GemmArgs& a, hipStream_t s) {
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs p, const float* __restrict__ part, int S) {
   const int nq = p.N / 4;                       // float4 groups per row
-  const size_t total = (size_t)p.M * nq, slab = (size_t)p.M * p.N;
+  // slab rows: the output rows themselves, or (GemmArgs::row_tab, the 256 kernel's half-tile table) compact rows half * 128 + r
+  const size_t srows = p.row_tab ? (size_t)((p.tab_halves + 1) / 2) * 256 : (size_t)p.M;
+  const size_t total = (p.row_tab ? (size_t)p.tab_halves * 128 : (size_t)p.M) * nq, slab = srows * p.N;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int m = (int)(i / nq), n = (int)(i - (size_t)m * nq) * 4;
-    f32x4 a = *(const f32x4*)(part + (size_t)m * p.N + n);
+    const int sm = (int)(i / nq), n = (int)(i - (size_t)sm * nq) * 4;
+    int m = sm;
+    if (p.row_tab) {
+      const int h = sm >> 7, r = sm & 127;
+      if (r >= p.row_tab[2 * h + 1]) continue;
+      m = p.row_tab[2 * h] + r;
+    }
+    f32x4 a = *(const f32x4*)(part + (size_t)sm * p.N + n);
     for (int sidx = 1; sidx < S; ++sidx) {
-      const f32x4 b = *(const f32x4*)(part + sidx * slab + (size_t)m * p.N + n);
+      const f32x4 b = *(const f32x4*)(part + sidx * slab + (size_t)sm * p.N + n);
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] += b[e];
     }
@@ -212,9 +220,9 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs p, co
       // 16-row interleave: columns [32b, 32b+16) gate, [32b+16, 32b+32) up -> output column 16b + (n % 16)
       const int blk = n >> 5, within = n & 31;
       if (within >= 16) continue;               // the gate thread also reads its up partner
-      f32x4 u = *(const f32x4*)(part + (size_t)m * p.N + n + 16);
+      f32x4 u = *(const f32x4*)(part + (size_t)sm * p.N + n + 16);
       for (int sidx = 1; sidx < S; ++sidx) {
-        const f32x4 b = *(const f32x4*)(part + sidx * slab + (size_t)m * p.N + n + 16);
+        const f32x4 b = *(const f32x4*)(part + sidx * slab + (size_t)sm * p.N + n + 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] += b[e];
       }
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs p, co
 
 template <int EPI>
 void launch_finalize(const GemmArgs& a, const float* part, int S, hipStream_t s) {
-  const size_t total = (size_t)a.M * (a.N / 4);
+  const size_t total = (a.row_tab ? (size_t)a.tab_halves * 128 : (size_t)a.M) * (a.N / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(gemm_finalize_kernel<EPI>, dim3(blocks), dim3(256), 0, s, a, part, S);
 }

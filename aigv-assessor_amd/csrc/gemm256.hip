@@ -43,6 +43,8 @@ constexpr int STAGE_ROWP = 144;            // residual epilogue: 16 staged rows 
 constexpr int STAGE_BYTES = 16 * STAGE_ROWP;
 constexpr int LDS_BYTES = 2 * BUF + 8 * STAGE_BYTES;   // 128 KB ring + 18 KB
 constexpr int GROUP_M256 = 4;
+// row tiles of a launch: from the half-tile table when there is one (GemmArgs::row_tab), else from M
+inline int row_tiles(const GemmArgs& a) { return a.row_tab ? (a.tab_halves + 1) / 2 : (a.M + TM - 1) / TM; }
 }
 int g_gemm256_order = -1;   // tile order of the plain launches (GemmArgs::order): -1 = by weight size; 0 = row groups, g > 0 = groups of g column tiles (aigv_tune_gemm bits 10..13)
 namespace {
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   GSTAMP(gs_begin);
 
   // ---- tile mapping: XCD-aware bijective remap, then groups of GROUP_M256 row-tiles sweep the column tiles ----
-  const int nbm = (p.M + TM - 1) / TM, nbn = p.N / TN;
+  const int nbm = p.row_tab ? (p.tab_halves + 1) / 2 : (p.M + TM - 1) / TM, nbn = p.N / TN;
   const int nwg = nbm * nbn;
   int wg;
   {
@@ -108,7 +110,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     const int in_g = wg - grp * per_group;
     tn = first_n + in_g % gsz; tm = in_g / gsz;
   }
-  const int m0 = tm * TM, n0 = tn * TN;
+  const int n0 = tn * TN;
+  // The 128-row HALF of the tile this wave group works on (group g loads, multiplies and stores rows g*128 .. g*128+127 only): base
+  // row `hb` and valid rows `hv`, wave-uniform.  Without a table the halves are rows tm*256 + g*128 of A; with GemmArgs::row_tab
+  // every half is an independent (base row, valid rows) entry, so ONE launch covers whole tiles of many sequences whose rows start
+  // anywhere (rows are independent: a row's bits do not depend on where in a tile it sits).
+  int hb, hv;
+  if (p.row_tab) {
+    const int h = 2 * tm + g;
+    hb = 0; hv = 0;
+    if (h < p.tab_halves) { hb = p.row_tab[2 * h]; hv = p.row_tab[2 * h + 1]; }
+  } else {
+    hb = tm * TM + g * 128; hv = min(p.M - hb, 128);
+    if (hv <= 0) { hb = p.M - 1; hv = 0; }
+  }
+  hb = __builtin_amdgcn_readfirstlane(hb);
+  hv = __builtin_amdgcn_readfirstlane(hv);
+  const int hend = hb + hv;                                     // first row past the half: rows m >= hend are never stored
+  auto relc = [&](int r) { return max(min(r, hv - 1), 0); };   // row inside the half, clamped to a readable one (rows >= hv are never stored)
 
   // ---- LDS-DMA source pointers: this wave fills unit rows 16*wave .. 16*wave+15 (two 8-row wave-instructions) ----
   // unit row r -> tile row:  V0: (r>>6)*128 + (r&63)   V1: +64   V2: (r>>5)*64 + (r&31)   V3: +32
@@ -117,15 +136,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // split-K (EPI_PARTIAL): blockIdx.y picks the K slice
   const int nk = (EPI == EPI_PARTIAL) ? p.K / TK / p.k_slices : p.K / TK;
   const size_t kbase = (EPI == EPI_PARTIAL) ? (size_t)blockIdx.y * nk * TK : 0;
-  const char* tileA = (const char*)(p.A + (size_t)m0 * p.lda + kbase);
+  const char* tileA = (const char*)(p.A + (size_t)hb * p.lda + kbase);
   const char* tileW = (const char*)(p.W + (size_t)n0 * p.ldw + kbase);
   unsigned off[4][2];   // [unit][instr], at k = 0
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = wave * 16 + i * 8 + lr;
-    const int ra0 = (r >> 6) * 128 + (r & 63), rb0 = (r >> 5) * 64 + (r & 31);
-    off[0][i] = (unsigned)(min(m0 + ra0, p.M - 1) - m0) * (unsigned)p.lda * 2u + lc * 16;
-    off[1][i] = (unsigned)(min(m0 + ra0 + 64, p.M - 1) - m0) * (unsigned)p.lda * 2u + lc * 16;
+    const int ra0 = r & 63, rb0 = (r >> 5) * 64 + (r & 31);     // (r >> 6 == g: a wave fills A rows of its own half only)
+    off[0][i] = (unsigned)relc(ra0) * (unsigned)p.lda * 2u + lc * 16;
+    off[1][i] = (unsigned)relc(ra0 + 64) * (unsigned)p.lda * 2u + lc * 16;
     off[2][i] = (unsigned)rb0 * (unsigned)p.ldw * 2u + lc * 16;
     off[3][i] = (unsigned)(rb0 + 32) * (unsigned)p.ldw * 2u + lc * 16;
   }
@@ -151,14 +170,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // buffer once the K loop has drained.  The HBM latency of the residual is then hidden behind MFMA work / the first half.
   // (the fp8 form adds its residual in stage 2 of the staged epilogue instead: the prefetching path has no registers left for the scales)
   constexpr bool RESID_PF = ((VAR & 4) != 0) && (EPI == EPI_RESID || EPI == EPI_LS_RESID) && !FP8;
-  const char* rtile = RESID_PF ? (const char*)(p.resid + (size_t)m0 * p.ldr + n0 + wc * 64) : nullptr;
+  const char* rtile = RESID_PF ? (const char*)(p.resid + (size_t)hb * p.ldr + n0 + wc * 64) : nullptr;
   auto resid_dma = [&](int mh, int i0, int cnt) {   // instructions i0 .. i0+cnt-1 of half mh (8 rows each)
     const int buf = (mh == 0) ? ((nk - 1) & 1) ^ 1 : ((nk - 1) & 1);
     const unsigned dst = (unsigned)(size_t)(LDS_AS char*)smem + buf * BUF + wave * 8192;
 #pragma unroll
     for (int i = i0; i < i0 + cnt; ++i) {
       const int r = i * 8 + lr;                                            // row inside the half
-      const int row = min(m0 + g * 128 + mh * 64 + r, p.M - 1) - m0;       // clamp: rows past M are never stored
+      const int row = relc(mh * 64 + r);                                   // clamp: rows past the half's valid count are never stored
       glds16_saddr(rtile, (unsigned)row * (unsigned)p.ldr * 2u + (unsigned)(((lane & 7) ^ (r & 7)) * 16), dst + i * 1024);
     }
   };
@@ -341,9 +360,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + g * 128 + mh * 64 + mt * 16 + fr;
-        if (m >= p.M) continue;
-        float* row = p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n0 + wc * 64 + fq * 4;
+        const int m = hb + mh * 64 + mt * 16 + fr;
+        if (m >= hend) continue;
+        // slab rows: the output row itself, or (table form) the compact row (half index) * 128 + row inside the half
+        const size_t srow = p.row_tab ? (size_t)((2 * tm + g) * 128 - hb) + m : (size_t)m;
+        const size_t slab_rows = p.row_tab ? (size_t)nbm * TM : (size_t)p.M;
+        float* row = p.part + ((size_t)blockIdx.y * slab_rows + srow) * p.N + n0 + wc * 64 + fq * 4;
         // fp8: the slabs hold SCALED partial sums ((acc * row scale) * column scale is linear in acc), so the finalize pass is the bf16 one
         const float rs = FP8 ? p.row_scale[m] : 1.f;
 #pragma unroll
@@ -414,9 +436,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int r = i * 8 + (lane >> 3), ch = lane & 7;
-          const int m = m0 + g * 128 + mh * 64 + mt * 16 + r;
+          const int m = hb + mh * 64 + mt * 16 + r;
           const u16x8 val = *(const u16x8*)(st + r * STAGE_ROWP + ch * 16);
-          if (m < p.M) *(u16x8*)(p.C + (size_t)m * p.ldc + n0 + wc * 64 + ch * 8) = val;
+          if (m < hend) *(u16x8*)(p.C + (size_t)m * p.ldc + n0 + wc * 64 + ch * 8) = val;
         }
       }
     }
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
               f32x2 gt = f32x2{acc[mh][mt][nh][0][2 * h], acc[mh][mt][nh][0][2 * h + 1]};
               f32x2 up = f32x2{acc[mh][mt][nh][1][2 * h], acc[mh][mt][nh][1][2 * h + 1]};
               if constexpr (FP8) {
-                const float rs = p.row_scale[min(m0 + g * 128 + mh * 64 + mt * 16 + fr, p.M - 1)];
+                const float rs = p.row_scale[hb + relc(mh * 64 + mt * 16 + fr)];
                 gt = (gt * rs) * f32x2{wsc[nh][0][2 * h], wsc[nh][0][2 * h + 1]};
                 up = (up * rs) * f32x2{wsc[nh][1][2 * h], wsc[nh][1][2 * h + 1]};
               }
@@ -497,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
               for (int h = 0; h < 2; ++h) {
                 f32x2 v = f32x2{acc[mh][mt][nh][nt][2 * h], acc[mh][mt][nh][nt][2 * h + 1]};
                 if constexpr (FP8) {   // (acc * row scale) * column scale, fp32
-                  const float rs = p.row_scale[min(m0 + g * 128 + mh * 64 + mt * 16 + fr, p.M - 1)];
+                  const float rs = p.row_scale[hb + relc(mh * 64 + mt * 16 + fr)];
                   v = (v * rs) * f32x2{wsc[nh][nt][2 * h], wsc[nh][nt][2 * h + 1]};
                 }
                 if (p.bias) v += unpack_bf2(bcol[nh][nt][h]);   // wave-uniform branch
@@ -514,9 +536,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 64 / RPI; ++i) {
         const int r = i * RPI + lane / CPR, ch = lane % CPR;
-        const int m = m0 + g * 128 + mh * 64 + r;
+        const int m = hb + mh * 64 + r;
         u16x8 val = *(const u16x8*)(st + r * ROWP + ch * 16);
-        if (m < p.M) {
+        if (m < hend) {
           const int n = (EPI == EPI_SWIGLU ? (n0 + wc * 64) / 2 : n0 + wc * 64) + ch * 8;
           size_t orow = (size_t)m;
           if constexpr (EPI == EPI_PATCH) {
@@ -543,8 +565,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + g * 128 + mh * 64 + mt * 16 + fr;
-      if (m >= p.M) continue;
+      const int m = hb + mh * 64 + mt * 16 + fr;
+      if (m >= hend) continue;
       if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
@@ -613,7 +635,7 @@ template <int EPI, int VAR>
 hipError_t launch256(const GemmArgs& a, hipStream_t s) {
   static LdsAttrOnce lds_attr;
   if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI, VAR>, LDS_BYTES); e != hipSuccess) return e;
-  const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
+  const int nbm = row_tiles(a), nbn = a.N / TN;
   GemmArgs b = a;
   // Tile order.  The XCD-aware remap hands each XCD a contiguous run of tiles; WHICH operand an XCD then owns decides what is fetched
   // eight times over.  Row groups (order 0): an XCD owns 4 row tiles and sweeps all of W - right when W is small (InternViT: 2-8 MB).
@@ -622,7 +644,7 @@ hipError_t launch256(const GemmArgs& a, hipStream_t s) {
   // 235 MB, w2 117 MB): w2 718 -> 694 us, w1|w3 1398 -> 1380 us isolated, 101.5-101.9 -> 100.4 ms of GEMM time per step
   // (profiles/r2_gemm_tile_order.txt; the L2<->fabric byte count is the same either way - what changes is how much of it reaches HBM).
   // (measured at M = 8704; with M = 4281 - one 16-frame clip at the 26B widths - the row order was 0.3 % ahead, so short problems keep it)
-  b.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)a.N * (size_t)a.K >= ((size_t)32 << 20) && a.M >= 8192 ? 4 : 0);
+  b.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)a.N * (size_t)a.K >= ((size_t)32 << 20) && nbm >= 32 ? 4 : 0);
   hipLaunchKernelGGL((gemm256_kernel<EPI, VAR>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, b);
   return hipGetLastError();
 }
@@ -666,7 +688,7 @@ extern "C" int aigv_debug_gemm_stamps(unsigned long long* out /*[8][2][8]*/, int
 
 int g_gemm256_variant = 1;   // balanced reads + no s_setprio + LDS-staged epilogue: fastest in interleaved A/B (profiles/r1_gemm_variants.txt)
 
-bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0 && a.M >= 1; }
+bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0 && a.M >= 1 && (!a.row_tab || a.tab_halves >= 1); }
 
 // split-K slices of the 256 kernel: grid.y = a.k_slices workgroups per tile, each writes fp32 partial sums of its K range into
 // a.part[slice][M][N] (summed in slice order by gemm_finalize_kernel, gemm.hip)
@@ -675,9 +697,9 @@ template <int EPI>
 hipError_t launch256_fp8(const GemmArgs& b, hipStream_t s) {
   static LdsAttrOnce lds_attr;
   if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI, 7, true>, LDS_BYTES); e != hipSuccess) return e;
-  const int nbm = (b.M + TM - 1) / TM, nbn = b.N / TN;
+  const int nbm = row_tiles(b), nbn = b.N / TN;
   GemmArgs c = b;   // same tile-order rule as the bf16 launches (b.K counts byte pairs here: N x K x 2 = the weight bytes)
-  c.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)b.N * (size_t)b.K * 2 >= ((size_t)64 << 20) && b.M >= 8192 ? 4 : 0);
+  c.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)b.N * (size_t)b.K * 2 >= ((size_t)64 << 20) && nbm >= 32 ? 4 : 0);
   hipLaunchKernelGGL((gemm256_kernel<EPI, 7, true>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, c);
   return hipGetLastError();
 }
@@ -709,7 +731,7 @@ hipError_t aigv_launch_gemm256_fp8_partial(const GemmArgs& a, hipStream_t s) {
   if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI_PARTIAL, 7, true>, LDS_BYTES); e != hipSuccess) return e;
   GemmArgs b = a;
   b.K = a.K / 2; b.lda = a.lda / 2; b.ldw = a.ldw / 2;
-  const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
+  const int nbm = row_tiles(a), nbn = a.N / TN;
   hipLaunchKernelGGL((gemm256_kernel<EPI_PARTIAL, 7, true>), dim3(nbm * nbn, a.k_slices), dim3(512), LDS_BYTES, s, b);
   return hipGetLastError();
 }
@@ -718,7 +740,7 @@ hipError_t aigv_launch_gemm256_partial(const GemmArgs& a, hipStream_t s) {
   if (!aigv_gemm256_supported(a) || a.k_slices < 1 || (a.K / TK) % a.k_slices || !a.part) return hipErrorInvalidValue;
   static LdsAttrOnce lds_attr;
   if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI_PARTIAL, 7>, LDS_BYTES); e != hipSuccess) return e;
-  const int nbm = (a.M + TM - 1) / TM, nbn = a.N / TN;
+  const int nbm = row_tiles(a), nbn = a.N / TN;
   hipLaunchKernelGGL((gemm256_kernel<EPI_PARTIAL, 7>), dim3(nbm * nbn, a.k_slices), dim3(512), LDS_BYTES, s, a);
   return hipGetLastError();
 }

@@ -33,6 +33,9 @@ struct GemmArgs {
   // same 128-byte K-tiles), C = bf16(acc * row_scale[m] * col_scale[n] + bias)
   const float* row_scale;
   const float* col_scale;
+  // gemm256 only: the rows of a launch as a table of 128-row HALF tiles, (base row, valid rows 0..128) int32 pairs on the device; row
+  // tile i = halves 2i, 2i+1.  M is then only the row count of the buffers (slabs of the split-K form are [k_slices][tiles*256][N]).
+  const int32_t* row_tab; int tab_halves;
   int order;                    // gemm256 tile order: 0 = groups of 4 ROW tiles sweep the column tiles (an XCD owns rows), g > 0 = groups of g COLUMN tiles sweep the rows (an XCD owns a slice of W)
 };
 

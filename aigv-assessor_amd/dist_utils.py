@@ -80,36 +80,63 @@ def even_split(n: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
+class GatheredRows:
+    """Result of an all-gather along dim 0 with per-rank row counts: ONE buffer [world * max(counts), ...] filled by a single
+    ``all_gather_into_tensor`` (rank k's rows at block k, padding behind them when the counts are ragged).  ``rows(lo, hi)`` returns global
+    rows [lo, hi) - a VIEW of the buffer when they lie inside one rank's block (always, when the counts are equal), else the
+    concatenation of the pieces: only the rows a consumer asks for are ever copied."""
+
+    def __init__(self, buf: torch.Tensor, counts: List[int]):
+        self.buf, self.counts, self.m = buf, list(counts), max(counts) if counts else 0
+        self.starts = [0]
+        for c in counts:
+            self.starts.append(self.starts[-1] + c)
+
+    def __len__(self):
+        return self.starts[-1]
+
+    def rows(self, lo: int, hi: int) -> torch.Tensor:
+        if len(set(self.counts)) == 1:
+            return self.buf[lo:hi]
+        pieces = []
+        for k, c in enumerate(self.counts):
+            a, b = max(lo, self.starts[k]), min(hi, self.starts[k] + c)
+            if a < b:
+                pieces.append(self.buf[k * self.m + a - self.starts[k]: k * self.m + b - self.starts[k]])
+        if not pieces:
+            return self.buf[:0]
+        return pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=0)
+
+    def all(self) -> torch.Tensor:
+        return self.rows(0, len(self))
+
+
 def all_gather_rows_begin(local: torch.Tensor, counts: List[int], group=None):
-    """Start an all-gather along dim 0 with per-rank row counts (equal counts take the single-buffer fast path) and return a
-    function that completes it.  Between the two calls the collective runs on RCCL's own stream: work enqueued on the compute
-    stream in the meantime overlaps with it (the completion only makes the compute stream wait, the host does not block)."""
+    """Start an all-gather along dim 0 with per-rank row counts and return a function that completes it and hands back a
+    ``GatheredRows``.  Equal or ragged counts, it is ONE ``all_gather_into_tensor`` on a (padded) buffer - no tensor lists, no
+    re-assembly pass.  Between the two calls the collective runs on RCCL's own stream: work enqueued on the compute stream in the
+    meantime overlaps with it (the completion only makes the compute stream wait, the host does not block)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1 and not (force_single_rank_collectives and dist.is_initialized()):
-        return lambda: local
+        return lambda: GatheredRows(local, [local.shape[0]])
     tail = tuple(local.shape[1:])
-    if len(set(counts)) == 1:
-        out = torch.empty((sum(counts),) + tail, dtype=local.dtype, device=local.device)
-        work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=True)
-
-        def finish_equal():
-            work.wait()
-            return out
-        return finish_equal
     m = max(counts)
-    pad = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    work = dist.all_gather(bufs, pad, group=group, async_op=True)
+    send = local.contiguous()
+    if send.shape[0] != m:                      # ragged: this rank's block is padded to the longest
+        pad = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
+        pad[: send.shape[0]] = send
+        send = pad
+    out = torch.empty((world * m,) + tail, dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, send, group=group, async_op=True)
 
-    def finish_ragged():
+    def finish():
         work.wait()
-        return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
-    return finish_ragged
+        return GatheredRows(out, counts)
+    return finish
 
 
 def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
-    return all_gather_rows_begin(local, counts, group)()
+    return all_gather_rows_begin(local, counts, group)().all()
 
 
 def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
@@ -159,7 +186,7 @@ def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, a
     own = chi > clo and lo <= clo * fpc and chi * fpc <= hi and not prefer_gathered
     tokens = None if own else finish_tokens()
     if chi > clo:
-        vis = local[clo * fpc - lo: chi * fpc - lo] if own else tokens[fl]
+        vis = local[clo * fpc - lo: chi * fpc - lo] if own else tokens.rows(fl.start, fl.stop)
         out = model(mos=None if mos is None else mos[sl], pixel_values=None, input_ids=input_ids[sl],
                     attention_mask=None if attention_mask is None else attention_mask[sl],
                     image_flags=None if image_flags is None else image_flags[fl], labels=labels[sl],

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "aigv_out_row_hidden": (_I, [_P, _I, _I, _P, _I, _P]),
     "aigv_decode_eos": (_I, [_P, _P, _P, _I64P, _I, C.c_int64, _P]),
     "aigv_op_gemm": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "aigv_op_gemm_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, C.POINTER(C.c_int32), _I, _I, _I, _I, _P]),
     "aigv_op_gemm_splitk": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "aigv_op_gemm_splitk256": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "aigv_slowfast_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_P)]),

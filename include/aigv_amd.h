@@ -151,14 +151,16 @@ int aigv_kv_reorder(aigv_ctx* ctx, const int32_t* parent, const int32_t* len, in
  * score head, ViT weights) keeps the copies and the mode. */
 enum aigv_precision { AIGV_PRECISION_BF16 = 0, AIGV_PRECISION_FP8_LLM = 1 };
 int aigv_set_precision(aigv_ctx* ctx, int mode);
-/* Last-layer row trimming in aigv_llm_prefill (default on): when at most 64 rows are consumed (score rows + logit rows), the
+/* Last-layer row trimming in aigv_llm_prefill (default on): when at most 16 rows per clip are consumed (score rows + logit rows), the
  * last decoder layer computes attention only for the query blocks holding them and finishes wo / MLP / final norm on a compact
  * copy of those rows.  Rows are independent after attention, so the outputs are those of the untrimmed pass (up to the fp32
  * summation order of the kernel that runs the few rows); off = every row through every layer, as the reference does. */
 int aigv_set_row_trimming(aigv_ctx* ctx, int on);
 /* GEMM tile choice of THIS context: -1 = follow the process default set by aigv_tune_gemm (the state after aigv_ctx_create),
- * 0 = the cost-model dispatch, 1 = every row on the 128x128 kernel (per-row arithmetic then independent of the batch: bit-identical
- * batch-of-N vs one-by-one results), 2 = the 256x256 kernel wherever its shape rules allow.  Split-K scratch is per context too. */
+ * 0 = the per-sequence row plan (aigv_op_gemm_rows: the default; a clip's / frame's bits do not depend on its batch mates),
+ * 1 = every row on the 128x128 kernel, 2 = every row on the 256x256 kernel wherever its shape rules allow (both in full K, so
+ * batch-invariant too, but slower: test aliases).  Split-K scratch is per context too.  aigv_llm_extend (continuations of a kept
+ * prefix) still uses the batch-level cost-model dispatch of aigv_op_gemm. */
 int aigv_set_gemm_mode(aigv_ctx* ctx, int mode);
 
 /* One greedy decode step for every clip of the last keep_kv prefill (generate(): modeling_internvl_chat.py:769-811,
@@ -187,6 +189,13 @@ int aigv_decode_eos(aigv_ctx* ctx, int64_t* tokens, int32_t* state, const int64_
 /* C = epilogue(A[M,K] . W[N,K]^T); epi: 0 store, 1 gelu, 2 layerscale+residual, 3 residual, 4 swiglu, 5 patch */
 int aigv_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
                  const void* resid, int ldr, const void* pos, int np, int M, int N, int K, int epi, void* stream);
+/* The same GEMM with its M = cu_host[n_seq] rows divided into n_seq independent sequences (HOST int32 cu_host[0..n_seq], cu[0] = 0; epi
+ * 0..4): the dispatch of the scoring pass.  Every sequence's rows [0, 256 * floor(L / 256)) run on the full-K 256x256 kernel as whole
+ * tiles addressed through a half-tile table, its remaining rows as (ragged) half tiles with a split-K factor that depends on (N, K)
+ * only, remainders of <= 4 rows on the weight-streaming kernel in its fixed form - a row's result depends on its own sequence alone,
+ * never on the other sequences of the call.  Synchronises the stream (test entry point). */
+int aigv_op_gemm_rows(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
+                      const void* resid, int ldr, const int32_t* cu_host, int n_seq, int N, int K, int epi, void* stream);
 /* the split-K form used for latency-bound row tails: k_slices x tiles write fp32 slabs into ws_f32 (k_slices*M*N floats),
  * one pass sums them in slice order and applies the epilogue (epi 0..4) */
 int aigv_op_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,

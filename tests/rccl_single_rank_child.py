@@ -33,7 +33,7 @@ def main():
     x = torch.arange(6 * 5 * 8, dtype=torch.float32, device=dev).reshape(6, 5, 8).to(torch.bfloat16)
     finish = dist_utils.all_gather_rows_begin(x, [6])
     y = (x.float() * 2).to(torch.bfloat16)            # work enqueued between begin and finish overlaps with the collective
-    g = finish()
+    g = finish().all()
     assert g.data_ptr() != x.data_ptr() and torch.equal(g, x) and torch.equal(y.float(), x.float() * 2)
     # 2. the scorer through it
     cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)

@@ -139,3 +139,70 @@ def test_bench_multi_process_control_flow_dry_run():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["dry_run"] is True
     assert out["config"]["global_batch_clips"] == 4 and out["scaling"] == "weak" and out["value"] > 0
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2 --dry-run-cpu` as a PLAIN command (no torch.distributed.run, no RANK / WORLD_SIZE in the environment;
+    VERDICT r3 item 2): the process starts its two rank processes itself and rank 0 prints ONE json line with n_gpus 2, the time of every
+    rank and the process group's own world size.  A failing rank makes the whole command fail."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu", "--clips-per-gpu", "2",
+           "--frames", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["config"]["global_batch_clips"] == 4
+    assert len(out["ms_per_step_by_rank"]) == 2 and all(t > 0 for t in out["ms_per_step_by_rank"])
+    assert out["process_group"] == {"backend": "gloo", "world_size": 2}
+    assert abs(out["ms_per_step"] - max(out["ms_per_step_by_rank"])) < 1e-6          # the headline time is the MAX over the ranks
+    # a rank that dies takes the command down with a non-zero exit code (an option the ranks reject)
+    bad = subprocess.run(cmd + ["--precision", "nonsense"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert bad.returncode != 0
+
+
+def _gather_worker(rank, world, port, q, counts):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist_utils.init_dist("pytorch", backend="gloo")
+    lo = sum(counts[:rank])
+    local = (torch.arange(lo, lo + counts[rank], dtype=torch.float32)[:, None] * 10 + torch.arange(3, dtype=torch.float32)[None, :])
+    g = dist_utils.all_gather_rows_begin(local, counts)()
+    n = sum(counts)
+    whole = g.all()
+    inside = g.rows(lo, lo + counts[rank]) if counts[rank] else None
+    q.put((rank, whole.tolist(), g.buf.shape[0], len(g), g.rows(1, n - 1).tolist(),
+           None if inside is None else inside.untyped_storage().data_ptr() == g.buf.untyped_storage().data_ptr()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [[3, 3], [3, 2], [2, 0], [4, 4, 3, 3]])
+def test_ragged_all_gather_is_one_padded_collective(counts):
+    """all_gather_rows_begin: equal or ragged per-rank row counts through ONE all_gather_into_tensor on a padded buffer (VERDICT r3 item 2);
+    rows inside one rank's block come back as views of that buffer."""
+    world = len(counts)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q, counts)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = sum(counts)
+    want = (torch.arange(n, dtype=torch.float32)[:, None] * 10 + torch.arange(3, dtype=torch.float32)[None, :])
+    for rank, whole, buf_rows, length, mid, is_view in res:
+        assert whole == want.tolist() and length == n and buf_rows == world * max(counts)
+        assert mid == want[1:n - 1].tolist()
+        assert is_view in (None, True)

@@ -324,10 +324,11 @@ def test_repetition_processors_in_generate(rig):
         assert not torch.equal(pen, greedy) or len(set(pen[0].tolist())) == len(set(greedy[0].tolist()))
 
 
-def test_process_default_gemm_mode_1_is_batch_invariant(rig):
-    """aigv_tune_gemm(1) as the PROCESS default with the context left at -1: every GEMM form - tile kernels, the skinny
-    GEMMs of the trimmed last layer and of the decode step - must then be independent of the batch: a clip scored or decoded alone
-    gives the bits it gives inside a batch."""
+@pytest.mark.parametrize("process_mode", [0, 1, 2])
+def test_scores_and_decode_are_batch_invariant(rig, process_mode):
+    """A clip scored or decoded alone gives the bits it gives inside a batch - in the DEFAULT dispatch (mode 0: per-clip / per-frame row
+    plans, round 4) and under aigv_tune_gemm(1 / 2) as the PROCESS default with the context left at -1: every GEMM form - tile
+    kernels, the skinny GEMMs of the trimmed last layer and of the decode step - is independent of the batch."""
     from aigv_assessor_amd import native
     model, cfg, sd, tok = rig
     lib = native.load()
@@ -351,7 +352,7 @@ def test_process_default_gemm_mode_1_is_batch_invariant(rig):
         out = model.generate(pixel_values=pv[sl_f], input_ids=gids[sl_c], attention_mask=torch.ones_like(gids[sl_c]), max_new_tokens=4, do_sample=False).cpu()
         return out, model._row_logits(out.shape[0]).cpu()            # the last decode step's lm-head logits, bit for bit
     assert getattr(model, "_gemm_mode", -1) == -1
-    native.check(lib.aigv_tune_gemm(1, 0.0))
+    native.check(lib.aigv_tune_gemm(process_mode, 0.0))
     try:
         both = score(slice(0, B), slice(0, B * T))
         tok_all, log_all = decode(slice(0, B), slice(0, B * T))

@@ -114,6 +114,76 @@ def test_gemm_epilogues(lib, M, N, K, epi):
               atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
+def _gemm_rows_case(g, lens, N, K, epi):
+    M = sum(lens)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(BF)
+    W = (torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K))).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF) if epi in (0, 1, 2) else None
+    ls = (torch.rand(N, generator=g) + 0.5).to(BF) if epi == 2 else None
+    nout = N // 2 if epi == 4 else N
+    resid = torch.randn(M, nout, generator=g).to(BF) if epi in (2, 3) else None
+    return A, W, bias, ls, resid, nout
+
+
+def _run_gemm_rows(lib, A, W, bias, ls, resid, nout, lens, epi):
+    import ctypes
+    from aigv_assessor_amd.native import ptr
+    M, K, N = A.shape[0], A.shape[1], W.shape[0]
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    dA, dW = dev(A), dev(W)
+    dC = torch.full((M, nout), float("nan"), dtype=BF, device="cuda")
+    db, dl, dr = (dev(t) if t is not None else None for t in (bias, ls, resid))
+    sync(lib.aigv_op_gemm_rows(ptr(dA), K, ptr(dW), K, ptr(dC), nout, ptr(db), ptr(dl), ptr(dr), nout, (ctypes.c_int32 * len(cu))(*cu), len(lens),
+                               N, K, epi, None), lib)
+    return dC.cpu()
+
+
+# sequences: whole tiles only; the benched clip (2176 = 8 x 256 + 128); ragged tails of one and two halves; InternViT frames (1025 =
+# 4 x 256 + 1: tiny tails on the skinny kernel, uniform and not); sequences shorter than a half tile; N = 256 j + 128 (column split)
+@pytest.mark.parametrize("lens,N,K", [([512, 256], 256, 128), ([2176, 2176, 2176], 512, 1024), ([300, 77, 1000, 129, 511], 768, 512),
+                                      ([1025] * 5, 512, 1024), ([1025, 1027, 258, 3], 256, 256), ([40, 5, 130], 384, 192),
+                                      ([2176] * 4, 1024, 3584)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_row_plan_epilogues(lib, lens, N, K, epi):
+    """aigv_op_gemm_rows - the scoring pass's dispatch: per-sequence body tiles through the half-tile table, (ragged) tail halves as
+    K slices with a factor fixed by (N, K), tiny tails on the skinny kernel - against the rounded fp32 reference."""
+    g = torch.Generator().manual_seed(sum(lens) * 7 + N + K + epi)
+    A, W, bias, ls, resid, nout = _gemm_rows_case(g, lens, N, K, epi)
+    want = gemm_ref(A, W, epi, bias, ls, resid)
+    got = _run_gemm_rows(lib, A, W, bias, ls, resid, nout, lens, epi)
+    ulp_check(got, want, frac=0.03 if epi in (1, 4) else 0.02, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
+
+
+@pytest.mark.parametrize("N,K", [(512, 1024), (1024, 3584), (384, 256)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_row_plan_is_batch_invariant(lib, N, K, epi):
+    """A sequence's rows give the same BITS whatever the other sequences of the call are: every sequence of a mixed
+    batch alone == inside the batch, for body rows, split-K tail halves (one and two, ragged) and tiny tails."""
+    lens = [2176, 1025, 300, 2176, 131, 1025, 2]
+    g = torch.Generator().manual_seed(N + K + epi)
+    A, W, bias, ls, resid, nout = _gemm_rows_case(g, lens, N, K, epi)
+    both = _run_gemm_rows(lib, A, W, bias, ls, resid, nout, lens, epi)
+    assert torch.isfinite(both.float()).all()
+    r0 = 0
+    for n in lens:
+        sl = slice(r0, r0 + n)
+        one = _run_gemm_rows(lib, A[sl], W, bias, ls, None if resid is None else resid[sl], nout, [n], epi)
+        assert torch.equal(one.view(torch.int16), both[sl].view(torch.int16)), f"sequence of {n} rows at {r0}"
+        r0 += n
+    # and as a uniform batch of the same sequence (the tiny tails then share one strided skinny launch)
+    for n in (1025, 2176):
+        start = sum(lens[:lens.index(n)])
+        sl = slice(start, start + n)
+        rep = 3
+        A3 = A[sl].repeat(rep, 1)
+        r3 = None if resid is None else resid[sl].repeat(rep, 1)
+        got = _run_gemm_rows(lib, A3, W, bias, ls, r3, nout, [n] * rep, epi)
+        for i in range(rep):
+            assert torch.equal(got[i * n:(i + 1) * n].view(torch.int16), both[sl].view(torch.int16))
+
+
 @pytest.mark.parametrize("mode", [1, 2 + 16, 2 + 32, 2 + 64, 0])
 @pytest.mark.parametrize("M,N,K,epi", [(1100, 512, 448, 0), (777, 256, 64, 1), (515, 768, 1024, 2), (300, 256, 192, 3),
                                         (1029, 1024, 512, 4), (256, 256, 128, 0),
