@@ -365,6 +365,34 @@ def spawn_ranks(n):
     return rc
 
 
+def reference_loop_metric(model, cfg, toks, dev, T, n_clips=6):
+    """The reference's OWN eval-loop shape (stage2_eval.py:908-941: DataLoader batch_size = 1, `.to(device)` per clip, one
+    `score1.item()` host synchronisation and the answer-token slice per clip): for every clip, T decoded uint8 720p frames in pinned host
+    memory -> H2D -> Pillow-exact resize + normalise on the GPU -> one forward at batch 1 (SlowFast branch inside when the model carries it)
+    -> score to the host.  A second, separately labelled number: never the headline `value`."""
+    from aigv_assessor_amd import eval_utils
+    g8 = torch.Generator().manual_seed(6)
+    clips = [torch.randint(0, 256, (T, 720, 1280, 3), dtype=torch.uint8, generator=g8).pin_memory() for _ in range(2)]
+    ids, labels, am = toks["input_ids"][:1], toks["labels"][:1], toks["attention_mask"][:1]
+    flags = torch.ones(T, 1, dtype=torch.long)
+    motion = None if model.slowfast_model is not None else torch.zeros(1, cfg.motion_dim, dtype=torch.bfloat16, device=dev)
+    times, scores = [], []
+    for i in range(n_clips + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pv = model.ingest_frames(clips[i % 2].to(dev, non_blocking=True))
+        out = model(mos=None, pixel_values=pv, input_ids=ids, attention_mask=am, image_flags=flags, labels=labels, motion_feature=motion)
+        score = out["score1"].item()
+        pred = eval_utils.answer_ids(labels[0], out["logit"].cpu())
+        times.append((time.perf_counter() - t0) * 1e3)
+        scores.append((score, int(pred.numel())))
+    times = sorted(times[2:])
+    ms = times[len(times) // 2]
+    return {"latency_ms_per_clip": ms, "clips_per_s": 1e3 / ms, "clips_timed": n_clips, "ms_min_max": [times[0], times[-1]],
+            "shape": (f"the reference's eval loop (stage2_eval.py:908-941): batch 1, per clip {T} uint8 720p frames from pinned host memory -> H2D -> BICUBIC "
+                      "resize + normalise -> forward -> score1.item() + answer-token slice on the host; median of the timed clips after two warm-up clips")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -665,6 +693,8 @@ def main():
                 line["roofline_by_class"]["decode"] = {"kernels": "generate(): q_len = 1 GEMVs + split-KV attention, batch 1", "bound": "hbm",
                                                        "achieved": dm["decode_hbm_tb_per_s"] * 1e3, "peak": 8000.0, "unit": "GB/s",
                                                        "frac": dm["decode_hbm_frac_of_8tbps"], "ms_per_token": dm["decode_ms_per_token"]}
+        if world == 1 and not dry and not args.no_decode and not args.ingest:
+            line["reference_loop_shape"] = reference_loop_metric(model, cfg, toks, dev, T)
         if (world == 1 and not dry and not args.no_parity and args.model == "8b" and args.precision == "bf16" and T == 8 and Bl == 4
                 and not args.all_rows and not args.tune_gemm and not args.attn_kernel):
             par = parity_vs_reference(model, cfg, dev)      # (replaces the model's weights: after every measurement)

@@ -487,3 +487,43 @@ def test_kv_reorder_is_a_gather_of_the_parents_caches(rig, size):
     bad = native.i32_array([0, 1, 2, 3, 4, 9])
     assert lib.aigv_kv_reorder(c, bad, native.i32_array([n_prompt] * n), n, native.stream_ptr()) != 0
     assert lib.aigv_kv_reorder(c, native.i32_array(parent), native.i32_array([n_prompt] * n), n - 1, native.stream_ptr()) != 0
+
+
+def test_reference_eval_loop_shape_batch_1_with_ingest(rig):
+    """The reference's own eval loop (stage2_eval.py:908-941: DataLoader batch_size = 1, frames copied to the device per clip,
+    ``score1.item()`` and the answer-token slice per clip), driven through this package's pieces for three clips: decoded uint8 frames in
+    pinned host memory -> ingest_frames (H2D + Pillow-exact resize + normalise) -> prompts.build_inputs -> forward -> eval_utils.  Every
+    clip must score exactly as the oracle does on the frames the oracle's own resize produces."""
+    from aigv_assessor_amd import eval_utils, prompts
+    from oracle import resize as OR
+    model, cfg, sd, tok = rig
+    T = 2
+    g = torch.Generator().manual_seed(77)
+    model.img_context_token_id = tok.convert_tokens_to_ids("<IMG_CONTEXT>")
+    im_end = tok.convert_tokens_to_ids("<|im_end|>")
+    qa = [("How would you rate the static quality of this video?", "The static quality of the video is good."),
+          ("How would you rate the temporal smoothness of this video?", "The temporal smoothness of the video is fair."),
+          ("How would you rate the overall quality of this video?", "The overall quality of the video is excellent.")]
+    rows = []
+    for i, (q, a) in enumerate(qa):
+        frames = torch.randint(0, 256, (T, 180 + 12 * i, 320, 3), dtype=torch.uint8, generator=g).pin_memory()
+        s = prompts.build_inputs(tok, q, a, T, num_image_token=model.num_image_token)
+        pv = model.ingest_frames(frames.to(model.device, non_blocking=True))
+        motion = synth.synthetic_motion(1, cfg.motion_dim, seed=80 + i)
+        out = model(mos=torch.tensor([0.5]), pixel_values=pv, input_ids=s["input_ids"][None], attention_mask=s["attention_mask"][None],
+                    image_flags=torch.ones(T, 1, dtype=torch.long), labels=s["labels"][None], motion_feature=motion)
+        score = out["score1"].item()                                         # the loop's per-clip host synchronisation (:938)
+        pred = eval_utils.answer_ids(s["labels"], out["logit"].cpu(), im_end_id=im_end)
+        # oracle: Pillow-exact resize + the eval transform on the CPU, then the reference path
+        import numpy as np
+        ref_pv = O.normalize_frames_u8(torch.from_numpy(np.stack([OR.resize_bicubic_u8(f.numpy(), cfg.image_size, cfg.image_size) for f in frames])))
+        assert torch.equal(pv.cpu(), ref_pv), f"clip {i}: ingest differs from the oracle's resize + normalise"
+        ref = O.forward_eval(sd, cfg, ref_pv, s["input_ids"][None], s["attention_mask"][None], torch.ones(T, 1, dtype=torch.long), s["labels"][None],
+                             motion, model.img_context_token_id, mos=torch.full((1,), 0.5, dtype=BF), stage=2)
+        want = eval_utils.answer_ids(s["labels"], ref["logit"], im_end_id=im_end)
+        assert pred.tolist() == want.tolist(), (i, pred.tolist(), want.tolist())
+        assert abs(score - ref["score1"].float().item()) <= max(1e-3, 2.0 ** -8 * abs(ref["score1"].float().item())), (i, score, ref["score1"])
+        text = tok.decode(pred, skip_special_tokens=True)
+        rows.append((f"clip{i}", a, text, 50.0 + i, score, eval_utils.parse_level(text)))
+    stats = eval_utils.save_and_evaluate(rows)
+    assert len(rows) == 3 and 0.0 <= stats["acc"] <= 1.0
