@@ -6,6 +6,7 @@ reference's conversation template renders (pinned in tests/test_host.py against 
 tokenizer.
 """
 import json
+import math
 import os
 import sys
 
@@ -519,9 +520,19 @@ def test_reference_eval_loop_shape_batch_1_with_ingest(rig):
         ref_pv = O.normalize_frames_u8(torch.from_numpy(np.stack([OR.resize_bicubic_u8(f.numpy(), cfg.image_size, cfg.image_size) for f in frames])))
         assert torch.equal(pv.cpu(), ref_pv), f"clip {i}: ingest differs from the oracle's resize + normalise"
         ref = O.forward_eval(sd, cfg, ref_pv, s["input_ids"][None], s["attention_mask"][None], torch.ones(T, 1, dtype=torch.long), s["labels"][None],
-                             motion, model.img_context_token_id, mos=torch.full((1,), 0.5, dtype=BF), stage=2)
+                             motion, model.img_context_token_id, mos=torch.full((1,), 0.5, dtype=BF), stage=2, return_intermediates=True)
         want = eval_utils.answer_ids(s["labels"], ref["logit"], im_end_id=im_end)
-        assert pred.tolist() == want.tolist(), (i, pred.tolist(), want.tolist())
+        # identical tokens, up to rows where the oracle's own two candidate logits are within 2 bf16 ulps (random-weight near-ties; the
+        # rule of tests/test_gpu_e2e.py::assert_levels)
+        rows = eval_utils.answer_ids(s["labels"], torch.arange(ref["logit"].numel()), im_end_id=im_end)
+        n_tie = 0
+        for j, (a, b) in enumerate(zip(pred.tolist(), want.tolist())):
+            if a != b:
+                lg = ref["logits"][0, int(rows[j])].float()
+                ulp = 2.0 ** (math.floor(math.log2(max(abs(lg[b].item()), 1e-30))) - 7)
+                assert abs(lg[a].item() - lg[b].item()) <= 2 * ulp, (i, j, a, b)
+                n_tie += 1
+        assert n_tie <= max(1, len(want) // 10), (i, pred.tolist(), want.tolist())
         assert abs(score - ref["score1"].float().item()) <= max(1e-3, 2.0 ** -8 * abs(ref["score1"].float().item())), (i, score, ref["score1"])
         text = tok.decode(pred, skip_special_tokens=True)
         rows.append((f"clip{i}", a, text, 50.0 + i, score, eval_utils.parse_level(text)))
