@@ -97,6 +97,7 @@ struct aigv_ctx {
   RowPlan rp_vit, rp_llm;           // row plans of the InternViT frames (cached per chunk size) and of the current prefill's clips
   const RowPlan* cur_rp = nullptr;  // plan the InternLM2 layer helpers run under (null: batch-level dispatch, aigv_llm_extend)
   bool trim_last_layer = true;
+  int attn_round_scores = 1;   // prefill attention: the reference's bf16 rounding points of the score matrix (aigv_set_attention_numerics)
   int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2
   size_t splitk_floats = 0;
   float* splitk_ws = nullptr;  // fp32 slabs of the split-K row bands: owned by the context (one launch stream per context at a time)
@@ -1100,6 +1101,7 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
         a.n_heads = a.n_kv_heads = k.vit_heads;
         a.q_group_stride = a.kv_head_stride = c->vit_head_dim;
         a.causal = 0; a.post_div = 1.0f; a.q_prescale = 1.0f / sqrtf((float)c->vit_head_dim);
+        a.round_scores = c->attn_round_scores;
         a.uniform_len = 1;
         if (const char* m = aigv_attn_check(a, c->vit_head_dim)) return fail(c, AIGV_ERR_ARG, "%s", m);
         ProfScope ps(c, AIGV_PROF_ATTN_VIT, 4.0 * F * (double)c->S * c->S * Hv, 2.0 * 4 * rows * (double)Hv, s);
@@ -1329,6 +1331,7 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       a.n_heads = k.llm_heads; a.n_kv_heads = nkv;
       a.q_group_stride = a.kv_head_stride = (g + 2) * D;
       a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
+      a.round_scores = c->attn_round_scores;
       a.rope_pos = c->l_pos; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       const bool last_trim = trim && li == k.llm_layers - 1;
       a.q_tail = last_trim ? q_tail : 0;
@@ -1426,6 +1429,7 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
       a.n_heads = k.llm_heads; a.n_kv_heads = nkv;
       a.q_group_stride = (g + 2) * D;
       a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
+      a.round_scores = c->attn_round_scores;
       a.rope_pos = c->l_pos; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
       ProfScope ps(c, AIGV_PROF_ATTN_LLM, attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
@@ -1552,6 +1556,13 @@ int aigv_set_precision(aigv_ctx* c, int mode) {
 int aigv_set_row_trimming(aigv_ctx* c, int on) {
   if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_row_trimming: null context");
   c->trim_last_layer = on != 0;
+  return 0;
+}
+
+int aigv_set_attention_numerics(aigv_ctx* c, int mode) {
+  if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_attention_numerics: null context");
+  if (mode != 0 && mode != 1) return fail(c, AIGV_ERR_ARG, "aigv_set_attention_numerics: 0 (fp32 scores) or 1 (the reference's bf16 score matrix)");
+  c->attn_round_scores = mode;
   return 0;
 }
 
@@ -1855,6 +1866,7 @@ int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void
   a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
   a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
   a.causal = causal & 1; a.uniform_len = (causal >> 1) & 1; a.post_div = post_div; a.q_prescale = q_prescale;
+  a.round_scores = (causal >> 2) & 1;
   if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));
   return 0;
@@ -1869,6 +1881,7 @@ int aigv_op_attention_rope(const void* q, int ldq, const void* k, int ldk, const
   a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
   a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
   a.causal = causal & 1; a.uniform_len = (causal >> 1) & 1; a.post_div = post_div; a.q_prescale = q_prescale;
+  a.round_scores = (causal >> 2) & 1;
   a.rope_pos = pos; a.rope_cos = (const bf16_t*)cos; a.rope_sin = (const bf16_t*)sin;
   if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));

@@ -49,7 +49,9 @@ __device__ unsigned long long g_attn_stamp[2][STAMP_REPL][16];
 // NW = waves per workgroup (32 query rows each).  More waves share one K/V tile: the LDS-DMA issue cost per wave and tile
 // (the dominant overhead next to the MFMAs) halves going from 4 to 8 waves.
 // NB = K/V ring depth: tile t is multiplied while tiles t+1 .. t+NB-2 are in flight behind a counted vmcnt.
-template <int D, bool CAUSAL, int NW, int NB>
+// RS = the reference's rounding points of the SCORE matrix (AttnArgs::round_scores): s1 = bf16(q k^T) and, where the division that
+// follows is not a power of two (InternLM2: / sqrt(128)), s2 = bf16(s1 / post_div); the softmax then runs in fp32 on those values.
+template <int D, bool CAUSAL, int NW, int NB, bool RS>
 __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int QB = NW * 32;                // query rows per workgroup
   constexpr int ROWB = Lay<D>::ROWB;
@@ -208,7 +210,10 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float sc = 1.4426950408889634f / p.post_div;   // scores stay fp32: exp2(s*sc - m*sc) = exp((s - m)/post_div)
+  // exp2(s*sc - m*sc) = exp((s - m)/post_div).  RS with a rounded division (round_div): the scores the softmax sees are already divided.
+  const bool round_div = RS && p.round_scores == 2;
+  const float inv_div = 1.0f / p.post_div;
+  const float sc = round_div ? 1.4426950408889634f : 1.4426950408889634f / p.post_div;
 
   // transposed-read lane constants: 16-lane group gi = lane>>4 -> d columns 16*(gi&1).., key rows 4*(gi>>1)..
   const int li = lane & 15, gi = lane >> 4;
@@ -303,6 +308,26 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
     // ---- online softmax on the fp32 scores (one FMA + one exp2 per element) ---------------------------------
     // p = exp2(s * c - m * c), c = log2(e) / post_div.  The mask is only evaluated on tiles that need it (the
     // causal diagonal / the ragged last tile); the O rescale is skipped when no row maximum moved (wave-uniform).
+    if constexpr (RS) {
+      // the reference's score matrix is a bf16 tensor (modeling_internlm2.py:417: matmul -> bf16, / sqrt(d) -> bf16;
+      // modeling_intern_vit.py:153: (q * scale) @ k^T -> bf16): the same two roundings here, pairwise (one v_cvt_pk_bf16_f32 + two
+      // unpacks per pair and rounding; scalar multiplies: packed fp32 math does not overlap with the matrix pipe).  Measured on the
+      // benched batch at full depth (tests/manual/attention_numerics_study.py): WITHOUT these roundings a correct evaluation sits 4 bf16
+      // ulps (mean) from the reference's scores, with them 1.5 - the reference's own spread between host thread counts.
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          uint32_t pk = pack_bf2(f32x2{sacc[st][e], sacc[st][e + 1]});
+          float a = __uint_as_float(pk << 16), b = __uint_as_float(pk & 0xffff0000u);
+          if (round_div) {
+            a *= inv_div; b *= inv_div;
+            pk = pack_bf2(f32x2{a, b});
+            a = __uint_as_float(pk << 16); b = __uint_as_float(pk & 0xffff0000u);
+          }
+          sacc[st][e] = a; sacc[st][e + 1] = b;
+        }
+    }
     const int qpos = qw + c + kv_off;   // index of the last key this query may see (causal)
     const bool need_mask = (key0 + KT > kv_len) || (CAUSAL && key0 + KT - 1 > qw + kv_off);
     float tmax = -INFINITY;
@@ -684,14 +709,18 @@ int g_attn_waves = 0;   // 0 = default (4 waves per workgroup); forced for A/B e
 
 // NB = 2: deeper rings (3, 4 buffers) measured 5-15 % slower on the ViT shape - they cost resident workgroups (LDS), and
 // with four workgroups per CU the wait for the next tile is already covered by the others' work
-template <int D, bool CAUSAL, int NW, int NB = 2>
-static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
+template <int D, bool CAUSAL, int NW, bool RS, int NB = 2>
+static hipError_t launch_attn_rs(const AttnArgs& a, hipStream_t s) {
   constexpr int LDS = NB * 2 * KT * (D * 2);
   static LdsAttrOnce lds_attr;
-  if (hipError_t e = lds_attr.ensure((const void*)attn_fwd_kernel<D, CAUSAL, NW, NB>, LDS); e != hipSuccess) return e;
+  if (hipError_t e = lds_attr.ensure((const void*)attn_fwd_kernel<D, CAUSAL, NW, NB, RS>, LDS); e != hipSuccess) return e;
   const int nqb = (a.max_len + NW * 32 - 1) / (NW * 32) - a.q_begin / (NW * 32);
-  hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, NW, NB>), dim3(nqb * a.n_heads * a.n_seq), dim3(NW * 64), LDS, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, NW, NB, RS>), dim3(nqb * a.n_heads * a.n_seq), dim3(NW * 64), LDS, s, a);
   return hipGetLastError();
+}
+template <int D, bool CAUSAL, int NW>
+static hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
+  return a.round_scores ? launch_attn_rs<D, CAUSAL, NW, true>(a, s) : launch_attn_rs<D, CAUSAL, NW, false>(a, s);
 }
 
 static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_t s) {
@@ -721,6 +750,11 @@ hipError_t aigv_launch_attention(const AttnArgs& a_in, int head_dim, hipStream_t
     if (a.q_prescale > 0.f && a.q_prescale != 1.0f && frexpf(a.q_prescale, &ex) == 0.5f && ex > -60 && ex < 60) {
       a.post_div = a.post_div / a.q_prescale;
       a.q_prescale = 1.0f;
+    }
+    // round_scores: 1 = the score matrix rounds to bf16 once (a power-of-two division commutes with the rounding and stays folded into
+    // the exp2 scale), 2 = and again after the division (InternLM2: sqrt(128) is no power of two)
+    if (a.round_scores) {
+      a.round_scores = (a.post_div > 0.f && frexpf(a.post_div, &ex) == 0.5f) ? 1 : 2;
     }
   }
   return launch_attention32(a, head_dim, s);

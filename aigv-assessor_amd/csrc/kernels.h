@@ -79,6 +79,7 @@ struct AttnArgs {
                                 // s * kv_seq_stride elements (a KV cache [seq][kv head][capacity][D]: ldk = D, kv_head_stride = cap * D)
   int causal;
   float post_div;               // score = bf16(bf16(q.k) / post_div)  (LLM: sqrt(d); ViT: 1, q is pre-scaled)
+  int round_scores;             // != 0: the two bf16 roundings of the line above are applied, as the reference's eager path does; 0: scores stay fp32
   float q_prescale;             // q <- bf16(q * q_prescale)           (ViT: d^-1/2; LLM: 1)
   // RoPE applied to the QUERY rows as they are loaded (same three bf16 roundings as rope_kernel); K must already be rotated.
   // null = queries are used as stored.  rope_pos: position of every packed query row; tables [max_pos, D/2] bf16.

@@ -415,6 +415,7 @@ class InternVLChatModel(nn.Module):
         # per-context switches survive a re-created context
         native.check(lib.aigv_set_gemm_mode(ctx, int(getattr(self, "_gemm_mode", -1))), ctx)
         native.check(lib.aigv_set_row_trimming(ctx, int(getattr(self, "_row_trim", True))), ctx)
+        native.check(lib.aigv_set_attention_numerics(ctx, int(getattr(self, "_attn_numerics", 1))), ctx)
         self._dirty = False
 
     def __del__(self):
@@ -1127,9 +1128,20 @@ class InternVLChatModel(nn.Module):
         if self._ctx is not None and not self._dirty:
             native.check(native.load().aigv_set_precision(self._ctx, 1 if mode == "fp8" else 0), self._ctx)
 
+    def set_attention_numerics(self, mode: str = "reference"):
+        """Prefill attention: "reference" (default) rounds the score matrix to bf16 exactly where the reference's eager path does
+        (modeling_internlm2.py:417, modeling_intern_vit.py:153); "fp32" keeps the scores in fp32 (rounds 1-3; ~4 % faster, but 4 instead
+        of 1.5 bf16 ulps from the reference's scores at full depth)."""
+        if mode not in ("reference", "fp32"):
+            raise ValueError("attention numerics must be 'reference' or 'fp32'")
+        self._attn_numerics = 1 if mode == "reference" else 0
+        lib, ctx = self._native()
+        native.check(lib.aigv_set_attention_numerics(ctx, self._attn_numerics), ctx)
+
     def set_gemm_mode(self, mode: int = -1):
-        """GEMM tile choice of this model's context (aigv_set_gemm_mode): -1 process default, 0 cost-model dispatch, 1 every row
-        on the 128x128 kernel (batch-invariant bits), 2 the 256x256 kernel wherever it applies."""
+        """GEMM tile choice of this model's context (aigv_set_gemm_mode): -1 process default, 0 per-clip / per-frame row plans (the
+        default: batch-invariant bits), 1 every row on the 128x128 kernel, 2 the 256x256 kernel wherever it applies (both full K: test
+        aliases), 3 the batch-level cost-model dispatch of rounds 1-3 (A/B only)."""
         self._gemm_mode = int(mode)
         lib, ctx = self._native()
         native.check(lib.aigv_set_gemm_mode(ctx, int(mode)), ctx)

@@ -416,6 +416,8 @@ def main():
                     help="A/B: force one form of the prefill-attention kernel (aigv_tune_attention): 4 / 8 waves per workgroup; 0 = default")
     ap.add_argument("--tune-gemm", type=int, default=0, help="A/B: aigv_tune_gemm mode word (kernel choice + 16 * (1 + 256-kernel schedule variant))")
     ap.add_argument("--serial-motion", action="store_true", help="A/B: run the SlowFast branch on the launch stream in front of the ViT instead of on a side stream beside it")
+    ap.add_argument("--attn-numerics", default="reference", choices=["reference", "fp32"],
+                    help="prefill attention: 'reference' rounds the score matrix to bf16 where the reference's eager path does (default); 'fp32' keeps fp32 scores (A/B)")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settling batches in front of the timed region")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
     ap.add_argument("--no-parity", action="store_true", help="skip the score / level comparison with the reference's recorded outputs (tests/golden/e2e_8b_r3.pt; ~1.5 min of CPU weight generation)")
@@ -480,6 +482,8 @@ def main():
             model.set_row_trimming(False)
         if args.precision == "fp8":
             model.set_precision("fp8")
+        if args.attn_numerics != "reference":
+            model.set_attention_numerics(args.attn_numerics)
         if args.attn_kernel:
             from aigv_assessor_amd import native
             native.check(native.load().aigv_tune_attention(args.attn_kernel))
@@ -622,6 +626,7 @@ def main():
                        "motion_branch": "SlowFast-R50 on the frames, inside the step" if args.motion == "slowfast" else "synthetic motion_feature input",
                        "inputs": ("bf16 NCHW frames resident in HBM before the timed region: no H2D copy, no resize / normalise inside the step"
                                   if frames_u8 is None else "pinned uint8 720p frames: H2D copy + BICUBIC resize + normalise INSIDE the step (--ingest variant)"),
+                       "attention_numerics": args.attn_numerics,
                        "global_batch_clips": B, "frames_per_clip": T, "tokens_per_clip": N,
                        "parallelism": f"frame/clip-dp{world}" + (" + RCCL all-gather of visual tokens" if world > 1 or args.force_dp else "")},
             "slowfast_tflop_per_clip": (model.slowfast_model.flops_per_clip() / 1e12 if args.motion == "slowfast" and not dry else 0.0),   # not in the figures below
@@ -696,7 +701,7 @@ def main():
         if world == 1 and not dry and not args.no_decode and not args.ingest:
             line["reference_loop_shape"] = reference_loop_metric(model, cfg, toks, dev, T)
         if (world == 1 and not dry and not args.no_parity and args.model == "8b" and args.precision == "bf16" and T == 8 and Bl == 4
-                and not args.all_rows and not args.tune_gemm and not args.attn_kernel):
+                and not args.all_rows and not args.tune_gemm and not args.attn_kernel and args.attn_numerics == "reference"):
             par = parity_vs_reference(model, cfg, dev)      # (replaces the model's weights: after every measurement)
             if par:
                 line.update(par)

@@ -156,6 +156,11 @@ int aigv_set_precision(aigv_ctx* ctx, int mode);
  * copy of those rows.  Rows are independent after attention, so the outputs are those of the untrimmed pass (up to the fp32
  * summation order of the kernel that runs the few rows); off = every row through every layer, as the reference does. */
 int aigv_set_row_trimming(aigv_ctx* ctx, int on);
+/* Numerics of the prefill attention (InternViT and InternLM2): 1 (default) = the score matrix carries the reference's rounding points -
+ * s = bf16(q k^T), InternLM2 also bf16(s / sqrt(d)) (modeling_internlm2.py:417, modeling_intern_vit.py:153) - before the fp32 softmax;
+ * 0 = scores stay fp32 (rounds 1-3: closer to an fp32 evaluation, but 4 instead of 1.5 bf16 ulps (mean) from the reference's scores at
+ * full depth: tests/manual/attention_numerics_study.py; ~4 % faster).  P is rounded un-normalised in both modes (no measurable effect). */
+int aigv_set_attention_numerics(aigv_ctx* ctx, int mode);
 /* GEMM tile choice of THIS context: -1 = follow the process default set by aigv_tune_gemm (the state after aigv_ctx_create),
  * 0 = the per-sequence row plan (aigv_op_gemm_rows: the default; a clip's / frame's bits do not depend on its batch mates),
  * 1 = every row on the 128x128 kernel, 2 = every row on the 256x256 kernel wherever its shape rules allow (both in full K, so
@@ -233,7 +238,8 @@ int aigv_op_rmsnorm(const void* x, int ldx, const void* w, void* y, int ldy, int
 int aigv_op_rope(void* qkv, int ld, const int32_t* pos, const void* cos, const void* sin, int tokens, int n_rot,
                  int slots, int n_groups, int head_dim, void* stream);
 /* q/k/v as in kernels.h AttnArgs; cu is a DEVICE int32[n_seq+1].  causal: bit 0 = causal mask; bit 1 = "every sequence has
- * exactly max_len rows" (InternViT frames), which lets the dispatcher give a short left-over query block to the key-split kernel. */
+ * exactly max_len rows" (InternViT frames), which lets the dispatcher give a short left-over query block to the key-split kernel;
+ * bit 2 = the score matrix rounds to bf16 as in the reference's eager path (aigv_set_attention_numerics mode 1). */
 int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
                       const int32_t* cu, int n_seq, int max_len, int n_heads, int n_kv_heads, int q_group_stride,
                       int kv_head_stride, int head_dim, int causal, float post_div, float q_prescale, void* stream);

@@ -89,7 +89,7 @@ def main():
     model = model.to(torch.bfloat16)                                             # exact: every value is a bf16 number already
     print(f"reference model with the seeded weights ready in {time.time() - t0:.0f} s", flush=True)
     out = dict(llm_config=llm, vision_config=vis, w_seed=W_SEED, plant_scale=PLANT_SCALE, overrides=dict(OVERRIDES), cases={},
-               host=dict(torch=torch.__version__, cpus=os.cpu_count()))
+               host=dict(torch=str(torch.__version__), cpus=os.cpu_count()))
     cases = out["cases"]
     all4 = list(range(BENCH_B))
     for seed, fixture in ((0, "e2e_8b_r3.pt"), (1, "e2e_8b_r3b.pt")):

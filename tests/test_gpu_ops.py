@@ -449,7 +449,7 @@ def attn_truth(q, k, v, causal, scale_pre, post_div, dtype):
     return (p @ vv).transpose(0, 1)
 
 
-def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False):
+def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False, round_scores=False):
     from aigv_assessor_amd.native import ptr
     T, h, hk = q.shape[0], q.shape[1], k.shape[1]
     g = h // hk
@@ -464,7 +464,8 @@ def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False):
     out = torch.full((T, h * d), float("nan"), dtype=BF, device="cuda")
     base = dq.data_ptr()
     sync(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(dev(cu)),
-                               len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal) | (2 if uniform else 0), post, pre, None), lib)
+                               len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal) | (2 if uniform else 0) | (4 if round_scores else 0),
+                               post, pre, None), lib)
     return out.cpu().view(T, h, d)
 
 
@@ -482,15 +483,19 @@ def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False):
     (128, True, 8, 2, [2176]),                   # the canonical clip: 17 x 128 rows, 34 key tiles
     (128, False, 2, 2, [384, 129]),              # InternViT-6B head width, non-causal
 ])
-def test_attention_matches_eager_reference(lib, d, causal, h, hk, lens, kernel):
+@pytest.mark.parametrize("round_scores", [True, False])
+def test_attention_matches_eager_reference(lib, d, causal, h, hk, lens, kernel, round_scores):
+    """round_scores: the score matrix rounded to bf16 where the reference's eager path rounds it (the default of the scoring pass since
+    round 4) - the kernel must then sit much closer to the EAGER bf16 result than that result sits to fp64 truth (the rounding noise of
+    the scores is shared); False: fp32 scores (rounds 1-3), at least as accurate against fp64 truth as the eager path."""
     sync(lib.aigv_tune_attention(kernel), lib)
     try:
-        _attention_case(lib, d, causal, h, hk, lens, uniform=(kernel == 0 and len(set(lens)) == 1))
+        _attention_case(lib, d, causal, h, hk, lens, uniform=(kernel == 0 and len(set(lens)) == 1), round_scores=round_scores)
     finally:
         sync(lib.aigv_tune_attention(0), lib)
 
 
-def _attention_case(lib, d, causal, h, hk, lens, uniform):
+def _attention_case(lib, d, causal, h, hk, lens, uniform, round_scores=False):
     g = torch.Generator().manual_seed(sum(lens) + d)
     T = sum(lens)
     q = (torch.randn(T, h, d, generator=g) * 1.5).to(BF)
@@ -500,8 +505,9 @@ def _attention_case(lib, d, causal, h, hk, lens, uniform):
     k[lens[0] // 2] *= 6.0
     pre = d ** -0.5 if not causal else 1.0
     post = 1.0 if not causal else math.sqrt(d)
-    got = run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform).double()
+    got = run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform, round_scores).double()
     off = 0
+    near, far = 0.0, 0.0
     for n in lens:
         sl = slice(off, off + n)
         truth = attn_truth(q[sl], k[sl], v[sl], causal, pre, post, torch.float64)
@@ -511,7 +517,12 @@ def _attention_case(lib, d, causal, h, hk, lens, uniform):
         assert torch.isfinite(got[sl]).all()
         assert e_hip.mean() <= 1.5 * e_ref.mean() + 1e-4, (e_hip.mean().item(), e_ref.mean().item())
         assert e_hip.max() <= 2.0 * e_ref.max() + 2e-3, (e_hip.max().item(), e_ref.max().item())
+        near += (got[sl] - eager).abs().sum().item()
+        far += e_ref.sum().item()
         off += n
+    print(f"sum |hip - eager bf16| / sum |eager bf16 - fp64 truth| = {near / max(far, 1e-30):.3f} (round_scores={round_scores})")
+    if round_scores:       # what remains is the P rounding (un-normalised here, normalised there) and the output rounding
+        assert near <= 0.75 * far, (near, far)
 
 
 def test_attention_with_fused_query_rope_equals_rope_then_attention(lib):
