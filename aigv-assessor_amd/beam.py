@@ -3,9 +3,14 @@
 The reference decodes through HF's ``language_model.generate(inputs_embeds=...)`` (modeling_internvl_chat.py:798-809), so ``num_beams > 1`` in a
 generation config means transformers' beam search.  This module restates that published algorithm (transformers/generation/utils.py,
 ``GenerationMixin._beam_search`` and its helpers ``_get_top_k_continuations`` / ``_get_running_beams_for_next_iteration`` /
-``_update_finished_beams`` / ``_check_early_stop_heuristic`` - the vectorised form of transformers >= 4.50; the ``BeamSearchScorer`` of
-the 4.37 the reference was written against runs the same search with the same scores, top-2k candidate rule and length penalty) and is
-pinned token for token against the INSTALLED transformers' ``generate`` on a small causal LM in tests/test_host.py.  With ``inputs_embeds``
+``_update_finished_beams`` / ``_check_early_stop_heuristic`` - the vectorised form of transformers >= 4.50) and is pinned token for token
+against the INSTALLED transformers' ``generate`` (5.x here) on a small causal LM in tests/test_host.py.  The reference pins transformers
+4.37.2, whose ``BeamSearchScorer`` runs the same search (scores, top-2k candidate rule, length penalty) but differs in two corners that
+are NOT pinned here: with ``early_stopping=False`` its ``BeamHypotheses.is_done`` compares against the best of ALL 2k candidate scores
+(end-token candidates included) where the vectorised heuristic below uses the best RUNNING beam, so stop points can differ in edge
+cases; and it fills finished rows with ``pad_token_id`` even when that id is 0, where this code (like transformers 5.x) treats a pad id
+of 0 as unset and fills with the end token.  The reference's shipped generation configs are ``num_beams=1`` (no ``num_beams`` anywhere in
+its tree), so neither corner is reachable from its eval scripts.  With ``inputs_embeds``
 HF's ``input_ids`` start empty, so the decoder prompt length is 0 here and every length below counts GENERATED tokens.
 
     first_logits  fp32 [B, V]: next-token logits behind the prompt (all beams of an item start from the same state)

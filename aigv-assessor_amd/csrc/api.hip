@@ -98,7 +98,9 @@ struct aigv_ctx {
   const RowPlan* cur_rp = nullptr;  // plan the InternLM2 layer helpers run under (null: batch-level dispatch, aigv_llm_extend)
   bool trim_last_layer = true;
   int attn_round_scores = 1;   // prefill attention: the reference's bf16 rounding points of the score matrix (aigv_set_attention_numerics)
-  int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2
+  int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2 / 3
+  // the other experiment knobs of this context (aigv_ctx_tune): -1 = follow the process default (aigv_tune_*)
+  int t_order = -1, t_variant = -1, t_attn_waves = -1, t_skinny_p = -1;
   size_t splitk_floats = 0;
   float* splitk_ws = nullptr;  // fp32 slabs of the split-K row bands: owned by the context (one launch stream per context at a time)
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 2 (attention out, normed) + [64, I], reused per 64 consumed rows
@@ -217,8 +219,31 @@ struct GemmClassScope {   // GEMM launches inside the scope are booked under `cl
 };
 
 // ---- GEMM dispatch: split the rows over the tile kernels by a wave-quantisation cost model -----------------------
-// g_gemm_mode: 0 = auto, 1 = force the 128x128 kernel, 2 = force the 256x256 kernel (where its shape rules allow)
-int g_gemm_mode = 0;
+// Experiment knobs.  The kernel files hold no mutable state: every launch carries its selectors (GemmArgs::order_sel / variant_sel,
+// AttnArgs::waves), filled in here from the context's own setting (aigv_ctx_tune / aigv_set_gemm_mode) or, where the context leaves a
+// knob at -1 and for the context-free aigv_op_* entry points, from these process defaults (aigv_tune_*: tests and A/B scripts).
+// gemm_mode: 0 = row plans (scoring pass) / cost model (op level), 1 = the 128x128 kernel, 2 = the 256x256 kernel, 3 = batch-level cost model
+struct Tune { int gemm_mode = 0, order_sel = 0, variant_sel = 0, attn_waves = 0, skinny_p = 0; };
+Tune g_tune;
+// the knobs in force for a call: the context's own setting, else the process default
+int resolved_gemm_mode(const aigv_ctx* c) { return (c && c->gemm_mode >= 0) ? c->gemm_mode : g_tune.gemm_mode; }
+Tune tune_of(const aigv_ctx* c) {
+  Tune t = g_tune;
+  if (c) {
+    if (c->gemm_mode >= 0) t.gemm_mode = c->gemm_mode;
+    if (c->t_order >= 0) t.order_sel = c->t_order;
+    if (c->t_variant >= 0) t.variant_sel = c->t_variant;
+    if (c->t_attn_waves >= 0) t.attn_waves = c->t_attn_waves;
+    if (c->t_skinny_p >= 0) t.skinny_p = c->t_skinny_p;
+  }
+  return t;
+}
+GemmArgs tuned(const aigv_ctx* c, const GemmArgs& a) {
+  GemmArgs b = a;
+  const Tune t = tune_of(c);
+  b.order_sel = t.order_sel; b.variant_sel = t.variant_sel;
+  return b;
+}
 // Model constants, microseconds on one MI355X (scripts/gemm_overhead.py: time vs K at fixed M, N):
 //   a full round of the 256 kernel (256 tiles, one per CU) takes nk * kt256 + fix256; a full round of the 128 kernel
 //   (512 tiles, two co-resident workgroups per CU) nk * KT128 + FIX128, a last round of <= 256 tiles LONE128 of that.
@@ -314,7 +339,7 @@ double t_skinny(int rows, int N, int K) {
 
 int launch_one(aigv_ctx* c, const GemmArgs& a, int epi, bool use256, hipStream_t s) {
   GEMM_PROF(c, a, s);
-  HIPCHK(c, use256 ? aigv_launch_gemm256(a, epi, s) : aigv_launch_gemm(a, epi, s));
+  HIPCHK(c, use256 ? aigv_launch_gemm256(tuned(c, a), epi, s) : aigv_launch_gemm(a, epi, s));
   return 0;
 }
 
@@ -322,7 +347,7 @@ int launch_splitk(aigv_ctx* c, const GemmArgs& a, int epi, int S, bool tile256, 
   float* ws = nullptr;
   TRY(splitk_scratch(c, (size_t)S * a.M * a.N, &ws));
   GEMM_PROF(c, a, s);
-  HIPCHK(c, aigv_launch_gemm_splitk(a, epi, S, ws, s, tile256));
+  HIPCHK(c, aigv_launch_gemm_splitk(tuned(c, a), epi, S, ws, s, tile256));
   return 0;
 }
 
@@ -410,9 +435,6 @@ GemmArgs col_slice(const GemmArgs& a, int n0, int n) {
   return b;
 }
 
-// GEMM tile choice in force for a call: the context's own setting (aigv_set_gemm_mode), else the process default (aigv_tune_gemm)
-int resolved_gemm_mode(const aigv_ctx* c) { return (c && c->gemm_mode >= 0) ? c->gemm_mode : g_gemm_mode; }
-
 int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
   const int mode = resolved_gemm_mode(c) == 3 ? 0 : resolved_gemm_mode(c);
@@ -499,7 +521,7 @@ int tail_slices(int N, int K) {
 
 int launch_tab(aigv_ctx* c, const GemmArgs& a, int epi, const int32_t* tab, int halves, int rows, int S, hipStream_t s) {
   if (halves <= 0) return 0;
-  GemmArgs b = a;
+  GemmArgs b = tuned(c, a);
   b.row_tab = tab; b.tab_halves = halves;
   GemmArgs pf = a; pf.M = rows;            // the rows this launch really computes (profile records only)
   GEMM_PROF(c, pf, s);
@@ -589,7 +611,7 @@ int run_gemm_fp8(aigv_ctx* c, const bf16_t* A, int lda, int K, const uint8_t* W8
     e = aigv_launch_quant_fp8_rows(A, lda, T, K, c->q8, K, c->q8_scale, s);
     if (e != hipSuccess) return fail(c, AIGV_ERR_HIP, "fp8 activation quantisation (T=%d K=%d): %s", T, K, hipGetErrorString(e));
   }
-  GemmArgs a{};
+  GemmArgs a = tuned(c, GemmArgs{});
   a.A = (const bf16_t*)c->q8; a.lda = K; a.W = (const bf16_t*)W8; a.ldw = K; a.C = C; a.ldc = ldc; a.M = T; a.N = N; a.K = K;
   a.row_scale = c->q8_scale; a.col_scale = w_scale; a.resid = resid; a.ldr = ldr;
   ProfScope ps(c, AIGV_PROF_GEMM_FP8, 2.0 * T * (double)N * K, (double)T * K + (double)N * K + 2.0 * T * (epi == EPI_SWIGLU ? N / 2 : N), s);
@@ -635,7 +657,6 @@ int run_gemm_fp8(aigv_ctx* c, const bf16_t* A, int lda, int K, const uint8_t* W8
   return 0;
 }
 
-int g_skinny_p = 0;   // aigv_tune_skinny: sub-slab form forced on the op-level entry point / the decode step (0 = default)
 
 int run_skinny(aigv_ctx* c, const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, int N, int K, const bf16_t* bias,
                const bf16_t* resid, int ldr, bf16_t* out, int ldo, int epi, hipStream_t s, int p = 1) {
@@ -659,9 +680,6 @@ int need(aigv_ctx* c, const std::string& name, size_t elems, const bf16_t** out)
 
 }  // namespace
 
-extern int g_gemm256_variant;
-extern int g_gemm256_order;
-extern int g_attn_waves;
 
 void aigv_set_error(const char* msg) { g_err = msg ? msg : ""; }
 
@@ -1101,7 +1119,7 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
         a.n_heads = a.n_kv_heads = k.vit_heads;
         a.q_group_stride = a.kv_head_stride = c->vit_head_dim;
         a.causal = 0; a.post_div = 1.0f; a.q_prescale = 1.0f / sqrtf((float)c->vit_head_dim);
-        a.round_scores = c->attn_round_scores;
+        a.round_scores = c->attn_round_scores; a.waves = tune_of(c).attn_waves; a.waves = tune_of(c).attn_waves;
         a.uniform_len = 1;
         if (const char* m = aigv_attn_check(a, c->vit_head_dim)) return fail(c, AIGV_ERR_ARG, "%s", m);
         ProfScope ps(c, AIGV_PROF_ATTN_VIT, 4.0 * F * (double)c->S * c->S * Hv, 2.0 * 4 * rows * (double)Hv, s);
@@ -1331,7 +1349,7 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       a.n_heads = k.llm_heads; a.n_kv_heads = nkv;
       a.q_group_stride = a.kv_head_stride = (g + 2) * D;
       a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
-      a.round_scores = c->attn_round_scores;
+      a.round_scores = c->attn_round_scores; a.waves = tune_of(c).attn_waves;
       a.rope_pos = c->l_pos; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       const bool last_trim = trim && li == k.llm_layers - 1;
       a.q_tail = last_trim ? q_tail : 0;
@@ -1429,7 +1447,7 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
       a.n_heads = k.llm_heads; a.n_kv_heads = nkv;
       a.q_group_stride = (g + 2) * D;
       a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
-      a.round_scores = c->attn_round_scores;
+      a.round_scores = c->attn_round_scores; a.waves = tune_of(c).attn_waves;
       a.rope_pos = c->l_pos; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
       ProfScope ps(c, AIGV_PROF_ATTN_LLM, attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
@@ -1500,14 +1518,24 @@ int aigv_kv_reorder(aigv_ctx* c, const int32_t* parent, const int32_t* len, int 
   }
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
-  if (!c->kc_alt) {
+  if (!c->kc_alt || !c->vc_alt || !c->beam_ints) {
+    // The second cache is made on first use.  No memset: the gather below writes every position a later step reads, and a
+    // blocking null-stream memset would not be ordered against a gather on a non-blocking stream `s`.  All three or none: a partial
+    // failure frees what it got, so the next call starts over instead of finding one pointer set.
     const size_t per = (size_t)k.llm_layers * k.max_seqs * k.llm_kv_heads * k.kv_capacity * c->head_dim;
-    c->ws_phase = true;
-    int rc = dalloc(c, &c->kc_alt, per);
-    if (!rc) rc = dalloc(c, &c->vc_alt, per);
-    if (!rc) rc = dalloc(c, &c->beam_ints, (size_t)2 * k.max_seqs);
-    c->ws_phase = false;
-    if (rc) return rc;
+    void *a = nullptr, *b = nullptr, *i = nullptr;
+    const hipError_t e1 = hipMalloc(&a, per * sizeof(bf16_t));
+    const hipError_t e2 = e1 == hipSuccess ? hipMalloc(&b, per * sizeof(bf16_t)) : e1;
+    const hipError_t e3 = e2 == hipSuccess ? hipMalloc(&i, (size_t)2 * k.max_seqs * sizeof(int32_t)) : e2;
+    if (e3 != hipSuccess) {
+      if (a) hipFree(a);
+      if (b) hipFree(b);
+      if (i) hipFree(i);
+      c->kc_alt = c->vc_alt = nullptr; c->beam_ints = nullptr;
+      return fail(c, AIGV_ERR_ALLOC, "aigv_kv_reorder: second KV cache (2 x %zu bytes): %s", per * sizeof(bf16_t), hipGetErrorString(e3));
+    }
+    c->kc_alt = (bf16_t*)a; c->vc_alt = (bf16_t*)b; c->beam_ints = (int32_t*)i;
+    c->ws_allocs.push_back(a); c->ws_allocs.push_back(b); c->ws_allocs.push_back(i);
   }
   HIPCHK(c, aigv_launch_write_ints(parent, n, c->beam_ints, s));
   HIPCHK(c, aigv_launch_write_ints(len, n, c->beam_ints + k.max_seqs, s));
@@ -1559,6 +1587,27 @@ int aigv_set_row_trimming(aigv_ctx* c, int on) {
   return 0;
 }
 
+int aigv_ctx_tune(aigv_ctx* c, int knob, int value) {
+  if (!c) return fail(c, AIGV_ERR_ARG, "aigv_ctx_tune: null context");
+  switch (knob) {
+    case AIGV_TUNE_GEMM_MODE: return aigv_set_gemm_mode(c, value);
+    case AIGV_TUNE_GEMM256_ORDER:
+      if (value < -1 || value > 15) break;
+      c->t_order = value; return 0;
+    case AIGV_TUNE_GEMM256_VARIANT:
+      if (value < -1 || value > 4) break;
+      c->t_variant = value; return 0;
+    case AIGV_TUNE_ATTN_WAVES:
+      if (value != -1 && value != 0 && value != 4 && value != 8) break;
+      c->t_attn_waves = value; return 0;
+    case AIGV_TUNE_SKINNY_P:
+      if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4) break;
+      c->t_skinny_p = value; return 0;
+    default: return fail(c, AIGV_ERR_ARG, "aigv_ctx_tune: unknown knob %d", knob);
+  }
+  return fail(c, AIGV_ERR_ARG, "aigv_ctx_tune: value %d out of range for knob %d", value, knob);
+}
+
 int aigv_set_attention_numerics(aigv_ctx* c, int mode) {
   if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_attention_numerics: null context");
   if (mode != 0 && mode != 1) return fail(c, AIGV_ERR_ARG, "aigv_set_attention_numerics: 0 (fp32 scores) or 1 (the reference's bf16 score matrix)");
@@ -1596,7 +1645,7 @@ static void decode_forms(aigv_ctx* c, int B, int* pq, int* po, int* p13, int* p2
   }
   *pq = *po = *p13 = pick_form(max_p, k.llm_hidden);
   *p2 = pick_form(max_p, k.llm_inter);
-  if (g_skinny_p) *pq = *po = *p13 = *p2 = std::min(g_skinny_p, max_p);
+  if (const int sp = tune_of(c).skinny_p) *pq = *po = *p13 = *p2 = std::min(sp, max_p);
   static const char* env = getenv("AIGV_DECODE_P");
   if (env) {
     int v[4];
@@ -1824,7 +1873,7 @@ int aigv_op_gemm_fp8(const void* A_e4m3, int lda, const void* W_e4m3, int ldw, v
 int aigv_op_skinny_gemm(const void* x, int ldx, int R, const void* W_, int ldw, int N, int K, const void* bias,
                         const void* resid, int ldr, void* out, int ldo, int epi, void* stream) {
   return run_skinny(nullptr, (const bf16_t*)x, ldx, R, (const bf16_t*)W_, ldw, N, K, (const bf16_t*)bias,
-                    (const bf16_t*)resid, ldr, (bf16_t*)out, ldo, epi, (hipStream_t)stream, g_skinny_p ? g_skinny_p : 1);
+                    (const bf16_t*)resid, ldr, (bf16_t*)out, ldo, epi, (hipStream_t)stream, g_tune.skinny_p ? g_tune.skinny_p : 1);
 }
 
 int aigv_op_skinny_gemm_fp8(const void* x, int ldx, int R, const void* W_e4m3, int ldw, const float* w_scale, int N, int K, const void* resid,
@@ -1866,7 +1915,7 @@ int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void
   a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
   a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
   a.causal = causal & 1; a.uniform_len = (causal >> 1) & 1; a.post_div = post_div; a.q_prescale = q_prescale;
-  a.round_scores = (causal >> 2) & 1;
+  a.round_scores = (causal >> 2) & 1; a.waves = g_tune.attn_waves;
   if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));
   return 0;
@@ -1881,7 +1930,7 @@ int aigv_op_attention_rope(const void* q, int ldq, const void* k, int ldk, const
   a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
   a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
   a.causal = causal & 1; a.uniform_len = (causal >> 1) & 1; a.post_div = post_div; a.q_prescale = q_prescale;
-  a.round_scores = (causal >> 2) & 1;
+  a.round_scores = (causal >> 2) & 1; a.waves = g_tune.attn_waves;
   a.rope_pos = pos; a.rope_cos = (const bf16_t*)cos; a.rope_sin = (const bf16_t*)sin;
   if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));
@@ -1930,8 +1979,9 @@ int aigv_op_frame_resize_ingest(const void* hwc_u8, int n_frames, int in_h, int 
 int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us) {
   if (!plan || M <= 0 || N <= 0 || K <= 0 || N % 128 || K % 64 || epi < 0 || epi >= EPI_COUNT)
     return fail(nullptr, AIGV_ERR_ARG, "aigv_plan_gemm: bad problem M=%d N=%d K=%d epi=%d", M, N, K, epi);
-  const int right = split_columns(M, N, K, epi, g_gemm_mode);
-  const GemmPlan pl = plan_gemm(M, N - right, K, epi, g_gemm_mode);
+  const int pmode = g_tune.gemm_mode == 3 ? 0 : g_tune.gemm_mode;
+  const int right = split_columns(M, N, K, epi, pmode);
+  const GemmPlan pl = plan_gemm(M, N - right, K, epi, pmode);
   plan[6] = right;
   plan[0] = pl.top_tiles; plan[1] = pl.mid_tiles; plan[2] = pl.mid_slices; plan[3] = pl.last_rows; plan[4] = pl.last_kind;
   plan[5] = pl.last_slices;
@@ -1941,14 +1991,14 @@ int aigv_plan_gemm(int M, int N, int K, int epi, int* plan, double* est_us) {
 
 int aigv_tune_skinny(int p) {
   if (p != 0 && p != 1 && p != 2 && p != 4) return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_skinny: 0 (default), 1, 2 or 4, got %d", p);
-  g_skinny_p = p;
+  g_tune.skinny_p = p;
   return 0;
 }
 
 int aigv_tune_attention(int waves) {
   if (waves != 0 && waves != 4 && waves != 8)
     return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_attention: 0 (default), 4 or 8 waves per workgroup, got %d", waves);
-  g_attn_waves = waves;
+  g_tune.attn_waves = waves;
   return 0;
 }
 
@@ -1956,17 +2006,14 @@ int aigv_tune_gemm(int mode, double rate256) {
   // mode = kernel choice (0 auto, 1 128-tile, 2 256-tile) + 16 * (256-kernel schedule variant 0..3, experiments)
   // mode bits 4..6: 0 = keep the default schedule, 1 + v = select 256-kernel schedule variant v (0..3)
   // bits 10..13: tile order of the 256 kernel for every shape (default 0: by weight size, gemm256.hip): 1 = row groups, 1 + g = groups of g column tiles
-  {
-    const int f = (mode >> 10) & 15;
-    g_gemm256_order = f == 0 ? -1 : f - 1;
-  }
+  g_tune.order_sel = (mode >> 10) & 15;
   mode &= 1023;
   const int vsel = mode >> 4;
   mode &= 15;
   if (mode < 0 || mode > 3 || vsel < 0 || vsel > 4)
     return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_gemm: mode must be 0 (auto), 1 (128 tile), 2 (256 tile) or 3 (batch-level dispatch in the scoring pass)");
-  if (vsel > 0) g_gemm256_variant = vsel - 1;
-  g_gemm_mode = mode;
+  if (vsel > 0) g_tune.variant_sel = vsel;
+  g_tune.gemm_mode = mode;
   if (rate256 > 0) g_rate256 = rate256;
   return 0;
 }

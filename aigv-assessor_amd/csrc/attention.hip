@@ -705,7 +705,6 @@ const char* aigv_attn_check(const AttnArgs& a, int head_dim) {
   return nullptr;
 }
 
-int g_attn_waves = 0;   // 0 = default (4 waves per workgroup); forced for A/B experiments: 4 / 8 waves
 
 // NB = 2: deeper rings (3, 4 buffers) measured 5-15 % slower on the ViT shape - they cost resident workgroups (LDS), and
 // with four workgroups per CU the wait for the next tile is already covered by the others' work
@@ -727,7 +726,7 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
   // 4 waves (128 query rows) per workgroup.  With the XCD-aware block order the K/V stream of a head is shared in L2, and
   // 8-wave workgroups (half the K/V reads, half the resident workgroups) measured equal or slower on every headline shape
   // (scripts/attn_bench.py with AB_WAVES=1); the 8-wave form stays reachable through aigv_tune_attention for such A/Bs.
-  const int nw = g_attn_waves == 8 ? 8 : 4;
+  const int nw = a.waves == 8 ? 8 : 4;
   if (head_dim == 64) {
     if (a.causal) return nw == 8 ? launch_attn<64, true, 8>(a, s) : launch_attn<64, true, 4>(a, s);
     return nw == 8 ? launch_attn<64, false, 8>(a, s) : launch_attn<64, false, 4>(a, s);

@@ -46,7 +46,8 @@ constexpr int GROUP_M256 = 4;
 // row tiles of a launch: from the half-tile table when there is one (GemmArgs::row_tab), else from M
 inline int row_tiles(const GemmArgs& a) { return a.row_tab ? (a.tab_halves + 1) / 2 : (a.M + TM - 1) / TM; }
 }
-int g_gemm256_order = -1;   // tile order of the plain launches (GemmArgs::order): -1 = by weight size; 0 = row groups, g > 0 = groups of g column tiles (aigv_tune_gemm bits 10..13)
+// tile order of a plain launch: GemmArgs::order_sel 0 = by weight size, 1 = row groups, 1 + g = groups of g column tiles
+static inline int tile_order(const GemmArgs& a, bool big_w, int nbm) { return a.order_sel > 0 ? a.order_sel - 1 : (big_w && nbm >= 32 ? 4 : 0); }
 namespace {
 
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
@@ -644,7 +645,7 @@ hipError_t launch256(const GemmArgs& a, hipStream_t s) {
   // 235 MB, w2 117 MB): w2 718 -> 694 us, w1|w3 1398 -> 1380 us isolated, 101.5-101.9 -> 100.4 ms of GEMM time per step
   // (profiles/r2_gemm_tile_order.txt; the L2<->fabric byte count is the same either way - what changes is how much of it reaches HBM).
   // (measured at M = 8704; with M = 4281 - one 16-frame clip at the 26B widths - the row order was 0.3 % ahead, so short problems keep it)
-  b.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)a.N * (size_t)a.K >= ((size_t)32 << 20) && nbm >= 32 ? 4 : 0);
+  b.order = tile_order(a, (size_t)a.N * (size_t)a.K >= ((size_t)32 << 20), nbm);
   hipLaunchKernelGGL((gemm256_kernel<EPI, VAR>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, b);
   return hipGetLastError();
 }
@@ -686,7 +687,7 @@ extern "C" int aigv_debug_gemm_stamps(unsigned long long* out /*[8][2][8]*/, int
 }
 #endif
 
-int g_gemm256_variant = 1;   // balanced reads + no s_setprio + LDS-staged epilogue: fastest in interleaved A/B (profiles/r1_gemm_variants.txt)
+// (default schedule = variant 1: balanced reads + no s_setprio + LDS-staged epilogue, fastest in interleaved A/B: profiles/r1_gemm_variants.txt)
 
 bool aigv_gemm256_supported(const GemmArgs& a) { return a.N % TN == 0 && a.K % TK == 0 && a.M >= 1 && (!a.row_tab || a.tab_halves >= 1); }
 
@@ -699,7 +700,7 @@ hipError_t launch256_fp8(const GemmArgs& b, hipStream_t s) {
   if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI, 7, true>, LDS_BYTES); e != hipSuccess) return e;
   const int nbm = row_tiles(b), nbn = b.N / TN;
   GemmArgs c = b;   // same tile-order rule as the bf16 launches (b.K counts byte pairs here: N x K x 2 = the weight bytes)
-  c.order = g_gemm256_order >= 0 ? g_gemm256_order : ((size_t)b.N * (size_t)b.K * 2 >= ((size_t)64 << 20) && nbm >= 32 ? 4 : 0);
+  c.order = tile_order(b, (size_t)b.N * (size_t)b.K * 2 >= ((size_t)64 << 20), nbm);
   hipLaunchKernelGGL((gemm256_kernel<EPI, 7, true>), dim3(nbm * nbn), dim3(512), LDS_BYTES, s, c);
   return hipGetLastError();
 }
@@ -749,7 +750,7 @@ hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
   // schedule variants kept for in-process A/B (scripts/gemm_bench.py, profiles/r1_gemm_variants.txt):
   //   1 (default) balanced reads + no s_setprio + LDS-staged epilogue;  3: the same with the direct 8-B epilogue;
   //   0: first schedule (12/4/8/0 reads, s_setprio pairs, direct epilogue)
-  switch (g_gemm256_variant) {
+  switch (a.variant_sel > 0 ? a.variant_sel - 1 : 1) {
     case 0: return launch256v<0>(a, epi, s);
     case 3: return launch256v<3>(a, epi, s);
     default: return launch256v<7>(a, epi, s);

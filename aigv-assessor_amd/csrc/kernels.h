@@ -36,6 +36,10 @@ struct GemmArgs {
   // gemm256 only: the rows of a launch as a table of 128-row HALF tiles, (base row, valid rows 0..128) int32 pairs on the device; row
   // tile i = halves 2i, 2i+1.  M is then only the row count of the buffers (slabs of the split-K form are [k_slices][tiles*256][N]).
   const int32_t* row_tab; int tab_halves;
+  // per-launch tuning selectors (0 = the default; set from the context's / the process's knobs by the dispatcher in api.hip - the kernel files
+  // hold no mutable state): order_sel 1 = row groups, 1 + g = groups of g column tiles (0: by weight size); variant_sel 1 + v = schedule
+  // variant v of the 256 kernel (0: the shipped one)
+  int order_sel, variant_sel;
   int order;                    // gemm256 tile order: 0 = groups of 4 ROW tiles sweep the column tiles (an XCD owns rows), g > 0 = groups of g COLUMN tiles sweep the rows (an XCD owns a slice of W)
 };
 
@@ -87,6 +91,7 @@ struct AttnArgs {
   int q_tail;                   // > 0: only the last q_tail query rows of every sequence are computed (others left unwritten)
   int uniform_len;              // every sequence has max_len rows (InternViT frames): lets the dispatcher split the query rows between kernels
   // row range of ONE kernel launch (set by aigv_launch_attention when it splits the rows between the two kernels; 0 = no limit):
+  int waves;                    // 0 = default (4 waves per workgroup); 4 / 8 forced (A/B: aigv_tune_attention / aigv_ctx_tune)
   int q_begin;                  // the launch computes query rows >= q_begin (a multiple of the workgroup's 128 rows) only; 0 everywhere at present
 };
 const char* aigv_attn_check(const AttnArgs& a, int head_dim);

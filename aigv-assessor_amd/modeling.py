@@ -356,7 +356,7 @@ class InternVLChatModel(nn.Module):
                     self._ctx, self._dirty = None, True
                     raise native.NativeError(f"libaigv_amd error {rc}: {msg.decode() if msg else '?'}")
                 self._cap = want
-                if c.max_positions != self._n_pos:   # longer rotary tables: reload them (finalize + precision mode inside)
+                if c.max_positions != self._n_pos:   # longer rotary tables: reload them (aigv_finalize_weights inside; it keeps the precision mode)
                     self._n_pos = c.max_positions
                     self._upload_rope()
             else:
@@ -796,8 +796,6 @@ class InternVLChatModel(nn.Module):
             # the reference recomputes the dynamic-NTK base at every decode step past max_position_embeddings
             # (modeling_internlm2.py:227-235) while its cached keys keep the base they were rotated with
             raise NotImplementedError("decoding past max_position_embeddings with dynamic-NTK rope scaling is not implemented")
-        if len(eos_ids) > 8:
-            raise ValueError("at most 8 eos_token_id values")
         nb = beams["num_beams"] if beams else 1
         self._native(seq_len=longest, n_clips=b * nb, out_rows=b * nb)       # (beam search: room for every beam before the prompt pass)
         _, nxt = self._prefill(ids_packed, slot, cu, vis, n_vis, motion, None, last_rows, keep_kv=True,
@@ -807,7 +805,18 @@ class InternVLChatModel(nn.Module):
             return self._beam_decode(b, [cu[i + 1] - cu[i] for i in range(b)], max_new_tokens, eos_ids, pad_id, processors or [], **beams)
         eos_a = (C.c_int64 * max(len(eos_ids), 1))(*[int(e) for e in eos_ids]) if eos_ids else None
         state = torch.zeros(b + 1, dtype=torch.int32, device=self.device)     # finished flags + live-column count (aigv_amd.h)
+        # aigv_decode_eos takes at most 8 end ids (kernel-argument array): longer lists keep HF's bookkeeping in torch ops on the device -
+        # the same rule (next = next * unfinished + pad * (1 - unfinished); unfinished &= next not in eos), still without a per-token sync
+        host_eos = len(eos_ids) > 8
+        eos_t = torch.tensor([int(e) for e in eos_ids], dtype=torch.long, device=self.device) if host_eos else None
         outs: List[torch.Tensor] = []
+
+        def eos_step(tok):
+            live = state[:b] == 0
+            tok = torch.where(live, tok, torch.full_like(tok, int(pad_id)))
+            state[b] += live.any().to(torch.int32)
+            state[:b] |= (live & torch.isin(tok, eos_t)).to(torch.int32)
+            return tok
 
         def pick(greedy_tok):
             """The step's raw token: the fused argmax, or - with logits processors / sampling - a choice over the rows' lm-head logits."""
@@ -822,7 +831,9 @@ class InternVLChatModel(nn.Module):
 
         tok = pick(nxt).contiguous()
         for step in range(max_new_tokens):
-            if eos_ids:       # tok: raw -> emitted (pad for finished sequences); flags / live-column count advance on the device
+            if host_eos:
+                tok = eos_step(tok).contiguous()
+            elif eos_ids:     # tok: raw -> emitted (pad for finished sequences); flags / live-column count advance on the device
                 native.check(lib.aigv_decode_eos(ctx, tok.data_ptr(), state.data_ptr(), eos_a, len(eos_ids), int(pad_id), native.stream_ptr()), ctx)
             outs.append(tok)
             if step + 1 == max_new_tokens:
@@ -1145,6 +1156,13 @@ class InternVLChatModel(nn.Module):
         self._gemm_mode = int(mode)
         lib, ctx = self._native()
         native.check(lib.aigv_set_gemm_mode(ctx, int(mode)), ctx)
+
+    TUNE_KNOBS = {"gemm_mode": 0, "gemm256_order": 1, "gemm256_variant": 2, "attn_waves": 3, "skinny_p": 4}
+
+    def tune(self, knob: str, value: int = -1):
+        """Experiment knobs of THIS model's context (aigv_ctx_tune; -1 = follow the process default): tests and A/B runs only."""
+        lib, ctx = self._native()
+        native.check(lib.aigv_ctx_tune(ctx, self.TUNE_KNOBS[knob], int(value)), ctx)
 
     def set_row_trimming(self, on: bool = True):
         """Last-layer row trimming (default on): the last decoder layer finishes only the rows whose hidden state is

@@ -86,11 +86,11 @@ def weight_shapes(cfg: InternVLChatConfig) -> List[Tuple[str, Tuple[int, ...], s
     return out
 
 
-def make_state_dict(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16, device="cpu",
-                    rich: bool = False) -> Dict[str, torch.Tensor]:
+def make_state_dict_iter(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16, device="cpu", rich: bool = False):
+    """(name, tensor) in weight_shapes order from ONE seeded generator - make_state_dict's values, one tensor alive at a time (a
+    streaming consumer, tests/golden/make_golden_26b.py, walks 26 G parameters with a few hundred MB)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    sd: Dict[str, torch.Tensor] = {}
     n_score = len(cfg.score_dims)
 
     def randn(shape, std):
@@ -108,7 +108,7 @@ def make_state_dict(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16
                 for r in range(0, shape[0], step):
                     t[r:r + step] = (torch.randn((min(step, shape[0] - r), shape[1]), generator=g,
                                                  device=device, dtype=torch.float32) * 0.02).to(dtype)
-                sd[name] = t
+                yield name, t
                 continue
             t = randn(shape, 0.02)
         elif kind in ("cls", "pos"):
@@ -132,8 +132,12 @@ def make_state_dict(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16
                     t = torch.full(shape, 0.5, device=device)
         else:
             raise AssertionError(kind)
-        sd[name] = t.to(dtype)
-    return sd
+        yield name, t.to(dtype)
+
+
+def make_state_dict(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16, device="cpu",
+                    rich: bool = False) -> Dict[str, torch.Tensor]:
+    return dict(make_state_dict_iter(cfg, seed=seed, dtype=dtype, device=device, rich=rich))
 
 
 def canonical_tokens(cfg: InternVLChatConfig, n_clips: int, n_frames: int, seed: int = 0,

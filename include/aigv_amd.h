@@ -272,10 +272,20 @@ int aigv_op_frame_resize_ingest(const void* hwc_u8, int n_frames, int in_h, int 
                                 const float* stdv, void* tmp_u8, void* out_u8_hwc, void* out_nchw, void* stream);
 
 /* ---- tuning knobs: TESTS AND EXPERIMENTS ONLY ---------------------------------------------------------------------------------------
- * aigv_tune_gemm / aigv_tune_attention / aigv_tune_skinny set PROCESS-WIDE defaults (plain globals: not thread-safe, shared by every
- * context and every aigv_op_* call of the process); they exist for in-process A/B measurements and for tests that must force a kernel
- * form.  A deployment never calls them: what a context needs per instance is aigv_set_gemm_mode / aigv_set_precision /
- * aigv_set_row_trimming above. */
+ * Every knob lives in the CONTEXT (aigv_ctx_tune; value -1 = follow the process default): two contexts of one process can run different
+ * kernel forms side by side, and the kernel files hold no mutable state - each launch carries its selectors.  aigv_tune_gemm /
+ * aigv_tune_attention / aigv_tune_skinny set the PROCESS defaults, which apply to the context-free aigv_op_* entry points and to
+ * contexts that left a knob at -1 (not thread-safe: in-process A/B scripts and tests that must force a kernel form).  A deployment calls
+ * none of them: what a context needs per instance is aigv_set_gemm_mode / aigv_set_precision / aigv_set_row_trimming /
+ * aigv_set_attention_numerics above. */
+enum aigv_tune_knob {
+  AIGV_TUNE_GEMM_MODE = 0,       /* = aigv_set_gemm_mode */
+  AIGV_TUNE_GEMM256_ORDER = 1,   /* tile order of the 256 kernel: 0 by weight size, 1 row groups, 1 + g groups of g column tiles */
+  AIGV_TUNE_GEMM256_VARIANT = 2, /* 0 the shipped schedule, 1 + v schedule variant v (0..3) */
+  AIGV_TUNE_ATTN_WAVES = 3,      /* prefill attention: 0 default, 4 / 8 waves per workgroup */
+  AIGV_TUNE_SKINNY_P = 4         /* decode GEMV form: 0 per-shape default, 1 / 2 / 4 */
+};
+int aigv_ctx_tune(aigv_ctx* ctx, int knob, int value);
 /* GEMM tile-kernel selection: mode 0 = cost model (default), 1 = always the 128x128 kernel, 2 = always the 256x256
  * phase-interleaved kernel where N % 256 == 0; rate256 > 0 overrides the model's relative throughput of the 256 kernel. */
 /* mode bits 4..6: 1 + v selects schedule variant v of the 256 kernel (0 = keep); bits 10..13: tile order of the 256 kernel, 0 = by weight

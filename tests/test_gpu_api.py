@@ -297,6 +297,9 @@ def test_eos_bookkeeping_runs_on_the_device_and_follows_hf(rig):
     assert free.shape == (B, n_new)
     pad = 2
     cases = [[int(free[0, 3])], [int(free[1, 10])], [int(free[0, 3]), int(free[1, 10])], [int(free[0, 12]), int(free[1, 1])], [cfg.llm_config.vocab_size - 1]]
+    # more than 8 end ids (the device kernel's argument array holds 8): the same rule through torch ops on the device
+    unused = [t for t in range(3, 200) if t not in set(free.flatten().tolist())][:9]
+    cases.append(unused + [int(free[0, 5]), int(free[1, 8])])
     for eos in cases:
         want = free.clone()
         ends = []
@@ -535,11 +538,11 @@ def test_reference_eval_loop_shape_batch_1_with_ingest(rig):
         # rule of tests/test_gpu_e2e.py::assert_levels)
         arows = eval_utils.answer_ids(s["labels"], torch.arange(ref["logit"].numel()), im_end_id=im_end)
         n_tie = 0
-        for j, (a, b) in enumerate(zip(pred.tolist(), want.tolist())):
-            if a != b:
+        for j, (tg, tw) in enumerate(zip(pred.tolist(), want.tolist())):
+            if tg != tw:
                 lg = ref["logits"][0, int(arows[j])].float()
-                ulp = 2.0 ** (math.floor(math.log2(max(abs(lg[b].item()), 1e-30))) - 7)
-                assert abs(lg[a].item() - lg[b].item()) <= 2 * ulp, (i, j, a, b)
+                ulp = 2.0 ** (math.floor(math.log2(max(abs(lg[tw].item()), 1e-30))) - 7)
+                assert abs(lg[tg].item() - lg[tw].item()) <= 2 * ulp, (i, j, tg, tw)
                 n_tie += 1
         assert n_tie <= max(1, len(want) // 10), (i, pred.tolist(), want.tolist())
         assert abs(score - ref["score1"].float().item()) <= max(1e-3, 2.0 ** -8 * abs(ref["score1"].float().item())), (i, score, ref["score1"])
@@ -547,3 +550,39 @@ def test_reference_eval_loop_shape_batch_1_with_ingest(rig):
         rows.append((f"clip{i}", a, text, 50.0 + i, score, eval_utils.parse_level(text)))
     stats = eval_utils.save_and_evaluate(rows)
     assert len(rows) == 3 and 0.0 <= stats["acc"] <= 1.0
+
+
+def test_experiment_knobs_live_in_the_context(rig):
+    """aigv_ctx_tune: the kernel-form knobs are per context - a second model of the same process keeps its own forms -
+    and every form computes the same scores up to fp32 summation order (tiny configuration: identical level tokens, score within one
+    bf16 ulp).  Bad knobs / values are rejected."""
+    from aigv_assessor_amd import native
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    model, cfg, sd, tok = rig
+    other = InternVLChatModel(cfg)
+    other.load_state_dict(sd)
+    other.eval().cuda()
+    B, T = 2, 2
+    toks = synth.canonical_tokens(cfg, B, T, seed=91)
+    pv = synth.synthetic_frames(B * T, 224, seed=91)
+    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=91)
+
+    def score(m):
+        m.img_context_token_id = toks["img_context_token_id"]
+        return m(pixel_values=pv, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"], image_flags=torch.ones(B * T, 1, dtype=torch.long),
+                 labels=toks["labels"], motion_feature=motion)
+    base = score(model)
+    assert torch.equal(score(other)["score1"], base["score1"])
+    try:
+        for knob, value in (("attn_waves", 8), ("gemm256_order", 1), ("gemm256_order", 3), ("gemm256_variant", 4), ("gemm_mode", 2), ("skinny_p", 2)):
+            other.tune(knob, value)
+            got = score(other)
+            assert torch.equal(got["logit"], base["logit"]), (knob, value)
+            assert (got["score1"].float() - base["score1"].float()).abs().max() <= 2.0 ** -8, (knob, value)
+            assert torch.equal(score(model)["score1"], base["score1"])           # the first context never moved
+            other.tune(knob, -1)
+        assert torch.equal(score(other)["score1"], base["score1"])
+        lib, ctx = other._native()
+        assert lib.aigv_ctx_tune(ctx, 99, 0) != 0 and lib.aigv_ctx_tune(ctx, 3, 5) != 0 and lib.aigv_ctx_tune(None, 0, 0) != 0
+    finally:
+        del other
