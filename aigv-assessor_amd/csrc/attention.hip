@@ -79,6 +79,16 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
     v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   }
   int qb = v % nqb, grp = v / nqb;
+  if (CAUSAL && p.n_heads > p.n_kv_heads) {
+    // Causal GQA (InternLM2): work grows with the query block, and an XCD's run of workgroups is dispatched in order - with all blocks of
+    // one head in front of the next head's, the launch ends on the LAST heads' heaviest blocks (list-scheduling a clip's 16 heads x 17
+    // blocks on an XCD's 64 slots: 108 tile-times against 89 ideal).  Order inside the run: one GQA group at a time (its heads read the
+    // same K/V: the L2 sharing stays), the group's query blocks heaviest first, the group's heads side by side -> 93 tile-times.
+    const int gq = p.n_heads / p.n_kv_heads, per = nqb * gq;
+    const int t = v / per, r = v - t * per;
+    qb = r / gq;
+    grp = t * gq + (r - qb * gq);
+  }
   if (qb0 == 0 && !CAUSAL && (p.max_len % QB) != 0 && (p.max_len % QB) <= 32 && nqb > 1 && ((int)gridDim.x % (8 * nqb)) == 0) {
     // Non-causal with a nearly empty last query block per head (ViT: 1025 rows): each XCD runs its full blocks first and the
     // cheap ragged ones (key-split below) at the end, so the launch drains on short workgroups instead of on full ones.
@@ -314,19 +324,26 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
       // unpacks per pair and rounding; scalar multiplies: packed fp32 math does not overlap with the matrix pipe).  Measured on the
       // benched batch at full depth (tests/manual/attention_numerics_study.py): WITHOUT these roundings a correct evaluation sits 4 bf16
       // ulps (mean) from the reference's scores, with them 1.5 - the reference's own spread between host thread counts.
+      // (two straight-line forms: left inside the pair loop, the wave-uniform test becomes sixteen branches per tile)
+      if (round_div) {
 #pragma unroll
-      for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          uint32_t pk = pack_bf2(f32x2{sacc[st][e], sacc[st][e + 1]});
-          float a = __uint_as_float(pk << 16), b = __uint_as_float(pk & 0xffff0000u);
-          if (round_div) {
-            a *= inv_div; b *= inv_div;
+          for (int e = 0; e < 16; e += 2) {
+            uint32_t pk = pack_bf2(f32x2{sacc[st][e], sacc[st][e + 1]});
+            float a = __uint_as_float(pk << 16) * inv_div, b = __uint_as_float(pk & 0xffff0000u) * inv_div;
             pk = pack_bf2(f32x2{a, b});
-            a = __uint_as_float(pk << 16); b = __uint_as_float(pk & 0xffff0000u);
+            sacc[st][e] = __uint_as_float(pk << 16); sacc[st][e + 1] = __uint_as_float(pk & 0xffff0000u);
           }
-          sacc[st][e] = a; sacc[st][e + 1] = b;
-        }
+      } else {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const uint32_t pk = pack_bf2(f32x2{sacc[st][e], sacc[st][e + 1]});
+            sacc[st][e] = __uint_as_float(pk << 16); sacc[st][e + 1] = __uint_as_float(pk & 0xffff0000u);
+          }
+      }
     }
     const int qpos = qw + c + kv_off;   // index of the last key this query may see (causal)
     const bool need_mask = (key0 + KT > kv_len) || (CAUSAL && key0 + KT - 1 > qw + kv_off);

@@ -280,6 +280,24 @@ class InternVLChatModel(nn.Module):
         self._invalidate()
         return missing, unexpected
 
+    def load_state_dict_stream(self, named_tensors):
+        """load_state_dict from an iterable of (name, tensor) without ever holding the whole state dict on the host (InternVL2-26B: 51 GB):
+        every tensor is copied into its parameter as it arrives.  Names the model does not own raise; returns the names never seen."""
+        own = dict(self.named_parameters())
+        seen = set()
+        with torch.no_grad():
+            for k, v in named_tensors:
+                if self.stage == 1 and k.startswith("mlpscore."):
+                    continue
+                if k not in own:
+                    raise RuntimeError(f"load_state_dict_stream: unexpected tensor {k}")
+                if tuple(v.shape) != tuple(own[k].shape):
+                    raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(own[k].shape)}")
+                own[k].copy_(v.to(own[k].dtype))
+                seen.add(k)
+        self._invalidate()
+        return [k for k in own if k not in seen]
+
     def _apply(self, fn, *a, **k):  # .cuda() / .to(): weights move, the native copy must follow
         out = super()._apply(fn, *a, **k)
         self._invalidate()

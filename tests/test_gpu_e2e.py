@@ -568,6 +568,54 @@ def test_config4_26b_true_widths_stage1_16_frames():
     check_levels(out, ref)
 
 
+def test_config4_26b_full_depth_matches_the_oracle(golden_dir):
+    """BASELINE config 4 at its true widths AND full depth (round 4): InternViT-6B x 45 layers + InternLM2-20B x 48
+    layers, one 16-frame clip (N = 4281), stage-1 flavour - 26 G parameters, 51 GB of bf16 weights streamed from the seeded generator
+    straight into the model (load_state_dict_stream).  ORACLE-ONLY: the fixture (tests/golden/make_golden_26b.py -> e2e_26b_full.pt) holds
+    the oracle's bf16 and fp32 passes; the reference itself cannot be built at this width (its score head and motion projector hard-code
+    a 4096-wide LLM, modeling_internvl_chat.py:44,244-249).  Bars as for the 8B fixtures: level tokens identical to the bf16 oracle or a
+    near-tie of the oracle's own logits, agreement with the fp32 oracle no worse than the bf16 oracle's minus 4 rows, and the final hidden
+    state of the score row position hidden[:, -4] at most 1.25 x as far (relative L2) from the fp32 oracle as the bf16 oracle is."""
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    path = os.path.join(golden_dir, "e2e_26b_full.pt")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/e2e_26b_full.pt not generated")
+    g = torch.load(path, weights_only=True)
+    cfg = pkg.internvl2_26b()
+    assert (g["vit_layers"], g["llm_layers"]) == (cfg.vision_config.num_hidden_layers, cfg.llm_config.num_hidden_layers) == (45, 48)
+    T, N = g["T"], g["n_tokens"]
+    dev = torch.device("cuda", 0)
+    model = InternVLChatModel(cfg, device=dev, stage=1, max_clips=1, max_frames=T, max_tokens=N)
+    missing = model.load_state_dict_stream(synth.make_state_dict_iter(cfg, seed=g["w_seed"], rich=True))
+    assert not missing, missing[:5]
+    model.eval()
+    toks = synth.canonical_tokens(cfg, 1, T, seed=g["in_seed"])
+    assert toks["input_ids"].shape[1] == N == 4281
+    model.img_context_token_id = toks["img_context_token_id"]
+    out = model(pixel_values=synth.synthetic_frames(T, 448, seed=g["in_seed"]).to(dev), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+                image_flags=torch.ones(T, 1, dtype=torch.long), labels=toks["labels"], motion_feature=synth.synthetic_motion(1, cfg.motion_dim, seed=g["in_seed"]).to(dev))
+    torch.cuda.synchronize()
+    assert "score1" not in out
+    rows, r16, r32 = g["answer_rows"], g["cases"]["bf16"], g["cases"]["fp32"]
+    assert torch.equal(out["label"].cpu()[rows], g["label"])
+    got = out["logit"].cpu()[rows]
+    n_tie = _level_rows_ok(got, r16, "26B full depth")
+    agree_hip, agree_ref = int((got == r32["logit"]).sum()), int((r16["logit"] == r32["logit"]).sum())
+    # hidden[:, -4] is the 8th of the ten consumed (answer) rows: rows N-11 .. N-2 of the shifted sequence
+    assert int(rows[7]) == N - 4
+    hid = model.last_hidden_rows(len(rows)).float().cpu()[7:8]
+    h32 = r32["hidden_m4"].float()
+    e_hip = float((hid - h32).norm() / h32.norm())
+    e_ref = float((r16["hidden_m4"].float() - h32).norm() / h32.norm())
+    print(f"26B full depth (oracle-only): level tokens {len(rows) - n_tie}/{len(rows)} identical to the bf16 oracle ({n_tie} near-ties), agreement with the fp32 "
+          f"oracle: hip {agree_hip}, bf16 oracle {agree_ref}; hidden[:, -4] rel L2 vs fp32 oracle: hip {e_hip:.4f}, bf16 oracle {e_ref:.4f}")
+    assert n_tie <= len(rows) // 4 + 1
+    assert agree_hip >= agree_ref - 4
+    assert e_hip <= 1.25 * e_ref, (e_hip, e_ref)
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_config5_fp8_mode_at_8b_widths():
     """BASELINE config 5's arithmetic at the 8B WIDTHS (hidden 4096, 32 q / 8 kv heads, intermediate 14336; three decoder layers, one
     InternViT-300M layer, reduced vocabulary), two 8-frame clips: the e4m3 linears against oracle/fp8.py - the kernel form that
