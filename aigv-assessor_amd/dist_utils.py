@@ -126,6 +126,13 @@ def all_gather_rows_begin(local: torch.Tensor, counts: List[int], group=None):
         pad = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
         pad[: send.shape[0]] = send
         send = pad
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # REHEARSAL transport (tests/test_gpu_dist.py: several ranks on ONE card, where RCCL refuses duplicate devices): gloo has no
+        # device all-gather, so the shard goes through host memory.  Same partitioning, same result; never used with backend 'nccl'.
+        out_h = torch.empty((world * m,) + tail, dtype=local.dtype)
+        dist.all_gather_into_tensor(out_h, send.cpu(), group=group)
+        out = out_h.to(local.device)
+        return lambda: GatheredRows(out, counts)
     out = torch.empty((world * m,) + tail, dtype=local.dtype, device=local.device)
     work = dist.all_gather_into_tensor(out, send, group=group, async_op=True)
 

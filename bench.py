@@ -440,6 +440,8 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback (--dry-run-cpu rehearses the control flow only)")
+        if os.environ.get("AIGV_BENCH_SHARE_DEVICE"):   # rehearsal only: every rank on ONE card (a builder's box has a single MI355X); not a measurement
+            local_rank = int(os.environ["AIGV_BENCH_SHARE_DEVICE"])
         torch.cuda.set_device(local_rank)
         if args.force_dp and world == 1 and "RANK" not in os.environ:
             # `python bench.py --gpus 1 --force-dp`: a one-rank RCCL group of its own, and the collectives of score_clips_dp run although one
@@ -447,7 +449,10 @@ def main():
             import socket
             so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-        if world > 1 or (args.force_dp and "RANK" in os.environ):
+        if world > 1 and os.environ.get("AIGV_BENCH_SHARE_DEVICE"):
+            # rehearsal only (every rank on ONE card; RCCL refuses duplicate devices): the real model, the real control flow, collectives over gloo
+            dist.init_process_group("gloo")
+        elif world > 1 or (args.force_dp and "RANK" in os.environ):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             if args.force_dp and world == 1:
                 from aigv_assessor_amd import dist_utils as _du
@@ -517,6 +522,10 @@ def main():
                          motion_feature=motion)
         return score_clips_dp(model, x, ids, am, flags, labels, motion)
 
+    # scalars that cross ranks (settling decisions, rank times): device tensors over RCCL; host tensors over gloo (the dry run and the
+    # one-card rehearsal - gloo has no device all-gather, and its device all-reduce is not relied on)
+    cdev = torch.device("cpu") if (dry or (dist.is_initialized() and dist.get_backend() == "gloo")) else dev
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -549,12 +558,12 @@ def main():
             for _ in range(5):
                 out = step()
             fence()
-            bt = torch.tensor([(time.perf_counter() - tb) / 5 * 1e3], dtype=torch.float64, device=dev)
+            bt = torch.tensor([(time.perf_counter() - tb) / 5 * 1e3], dtype=torch.float64, device=cdev)
             if world > 1:
                 dist.all_reduce(bt, op=dist.ReduceOp.MAX)      # every rank takes the same decision
             settle.append(float(bt.item()))
             stop = torch.tensor([1.0 if (len(settle) >= 2 and abs(settle[-1] - settle[-2]) <= 0.03 * settle[-1]) or time.perf_counter() - t_settle > 30.0 else 0.0],
-                                dtype=torch.float64, device=dev)
+                                dtype=torch.float64, device=cdev)
             if world > 1:
                 dist.all_reduce(stop, op=dist.ReduceOp.MAX)
             if stop.item() > 0:
@@ -593,14 +602,18 @@ def main():
             out = step()
         fence()
         dt_prof = time.perf_counter() - t1
-    elif world > 1:
-        for _ in range(args.steps):   # keep the ranks in lock-step with rank 0's roofline pass
+    elif world > 1 and not args.no_prof and not dry:
+        # keep the ranks in lock-step with rank 0's roofline pass: the SAME sequence of collectives on every rank - fence, K steps, fence.
+        # (Until round 4 the other ranks skipped the first fence: rank 0's extra barrier then paired with their first token all-gather and
+        # the run hung at N > 1 - found by the one-card two-rank rehearsal, AIGV_BENCH_SHARE_DEVICE; no multi-GPU run had ever executed.)
+        fence()
+        for _ in range(args.steps):
             out = step()
         fence()
     rank_ms = [1e3 * dt / args.steps]
     if world > 1:
-        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
-        every = torch.zeros(world, dtype=torch.float64, device=dev)
+        mine = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        every = torch.zeros(world, dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(every, mine)
         rank_ms = [1e3 * float(t) / args.steps for t in every.tolist()]
         tmax = mine.clone()
@@ -628,13 +641,15 @@ def main():
                                   if frames_u8 is None else "pinned uint8 720p frames: H2D copy + BICUBIC resize + normalise INSIDE the step (--ingest variant)"),
                        "attention_numerics": args.attn_numerics,
                        "global_batch_clips": B, "frames_per_clip": T, "tokens_per_clip": N,
-                       "parallelism": f"frame/clip-dp{world}" + (" + RCCL all-gather of visual tokens" if world > 1 or args.force_dp else "")},
+                       "parallelism": f"frame/clip-dp{world}" + ((" + RCCL" if not dist.is_initialized() or dist.get_backend() == "nccl" else " + " + dist.get_backend() + " (rehearsal)")
+                                                                   + " all-gather of visual tokens" if world > 1 or args.force_dp else "")},
             "slowfast_tflop_per_clip": (model.slowfast_model.flops_per_clip() / 1e12 if args.motion == "slowfast" and not dry else 0.0),   # not in the figures below
             "algorithmic_tflop_per_clip": fl["total"] / 1e12,
             "executed_tflop_per_clip": (fl["total"] if args.all_rows else fl["executed"]) / 1e12,
             "host_enqueue_ms_per_step": host_enqueue_ms,
             "ms_per_step_by_rank": rank_ms,
             "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist.is_initialized() else None),
+            "ranks_share_one_device": bool(os.environ.get("AIGV_BENCH_SHARE_DEVICE")),
             "protocol": (f"{args.warmup} warmup steps; {min(5, args.steps)} untimed-but-reported steps (presettle_ms_per_step); "
                          + ("no settling; " if args.no_settle else "untimed settling batches of 5 steps until two agree within 3 %, at most 30 s (settle_ms_per_step); ")
                          + f"then EXACTLY {args.steps} timed steps between barrier + synchronize fences"),
