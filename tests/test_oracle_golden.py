@@ -253,3 +253,50 @@ def test_slowfast_restatement_regression_fixture():
     assert torch.allclose(f32, g["feature_fp32"], rtol=1e-4, atol=1e-4)          # conv algorithms may differ between hosts: not bitwise
     bf = osf.slowfast_features(sd, frames).float()
     assert (bf - g["feature_bf16"].float()).abs().mean() <= 0.01 * g["feature_fp32"].abs().mean()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 4 fixtures: the reference against itself, and the streamed 26B oracle pass
+# ---------------------------------------------------------------------------------------------------------
+def test_reference_self_consistency_fixture():
+    """tests/golden/e2e_8b_r4_self.pt (make_golden_8b_r4.py: the imported reference, full depth): what the GPU tests' score bars are read
+    from.  Structure, the two facts the bars rest on - alone vs in batch bit-identical, other thread counts not - and that the pass
+    reproduced the earlier rounds' recordings when it was made."""
+    import os
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_8b_r4_self.pt"), weights_only=True)
+    c = g["cases"]
+    for seed in (0, 1):
+        b = c[f"batch4/seed{seed}/t8"]
+        assert b["equals_earlier_fixture"] is True and b["threads"] == 8
+        alone = torch.cat([c[f"alone/seed{seed}/clip{i}/t8"]["score1"] for i in range(4)])
+        assert torch.equal(alone, b["score1"])
+        assert torch.equal(torch.cat([c[f"alone/seed{seed}/clip{i}/t8"]["logit"] for i in range(4)]), b["logit"])
+    d4 = (c["batch4/seed0/t4"]["score1"].float() - c["batch4/seed0/t8"]["score1"].float()).abs()
+    d1 = (c["alone/seed0/clip0/t1"]["score1"].float() - c["alone/seed0/clip0/t8"]["score1"].float()).abs()
+    assert float(d4.max()) >= 2.0 ** -8 and float(d1.max()) >= 2.0 ** -8      # the reference moves by >= 1 bf16 ulp against itself
+    assert float(d4.max()) <= 0.05                                             # ... and by no more than a few
+    old = torch.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_8b_r3.pt"), weights_only=True)["cases"]["batch4/bf16"]
+    assert torch.equal(old["score1"], c["batch4/seed0/t8"]["score1"]) and torch.equal(old["hidden_m4"], c["batch4/seed0/t8"]["hidden_m4"])
+
+
+def test_26b_fixture_structure_and_streamed_weights():
+    """tests/golden/e2e_26b_full.pt (make_golden_26b.py: ORACLE-only, streamed): structure, consistency with the canonical inputs, and the
+    streaming generator itself - make_state_dict_iter yields exactly make_state_dict's tensors (same generator walk)."""
+    import os
+    import aigv_assessor_amd as pkg
+    from aigv_assessor_amd import synth
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_26b_full.pt"), weights_only=True)
+    cfg = pkg.internvl2_26b()
+    assert (g["vit_layers"], g["llm_layers"], g["T"], g["n_tokens"]) == (45, 48, 16, synth.canonical_len(cfg, 16)) == (45, 48, 16, 4281)
+    toks = synth.canonical_tokens(cfg, 1, g["T"], seed=g["in_seed"])
+    rows = g["answer_rows"]
+    assert torch.equal(toks["labels"][0, 1:][rows], g["label"]) and rows.numel() == 10 and int(rows[7]) == g["n_tokens"] - 4
+    for tag in ("bf16", "fp32"):
+        r = g["cases"][tag]
+        assert r["hidden_m4"].shape == (1, cfg.llm_config.hidden_size) and torch.equal(r["top_ids"][:, 0], r["logit"])
+    h16, h32 = g["cases"]["bf16"]["hidden_m4"].float(), g["cases"]["fp32"]["hidden_m4"].float()
+    assert 0.01 < float((h16 - h32).norm() / h32.norm()) < 0.15
+    small = pkg.tiny(image_size=224)
+    a = synth.make_state_dict(small, seed=11, rich=True)
+    b = dict(synth.make_state_dict_iter(small, seed=11, rich=True))
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
