@@ -1351,6 +1351,7 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
       a.round_scores = c->attn_round_scores; a.waves = tune_of(c).attn_waves;
       a.rope_pos = c->l_pos; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
+      a.rope_pos_is_row = 1;   // l_pos[t] = t - cu[seq] (+ the cached length): aigv_launch_seqpos
       const bool last_trim = trim && li == k.llm_layers - 1;
       a.q_tail = last_trim ? q_tail : 0;
       if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
@@ -1449,6 +1450,7 @@ int aigv_llm_extend(aigv_ctx* c, const int64_t* ids, const int32_t* cu, int B, c
       a.causal = 1; a.post_div = sqrtf((float)D); a.q_prescale = 1.0f;
       a.round_scores = c->attn_round_scores; a.waves = tune_of(c).attn_waves;
       a.rope_pos = c->l_pos; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
+      a.rope_pos_is_row = 1;   // l_pos[t] = t - cu[seq] (+ the cached length): aigv_launch_seqpos
       if (const char* m = aigv_attn_check(a, D)) return fail(c, AIGV_ERR_ARG, "%s", m);
       ProfScope ps(c, AIGV_PROF_ATTN_LLM, attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
       HIPCHK(c, aigv_launch_attention(a, D, s));

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
     for (int ks = 0; ks < NKS; ++ks) raw[ks] = *(const u16x8*)(qp + 16 * ks + 8 * h);
     if (p.rope_cos) {
       // rotate_half pairs dimension i with i + D/2: k-steps ks and ks + NKS/2 of the same lane (modeling_internlm2.py:247-261)
-      const size_t tb = (size_t)p.rope_pos[row0 + (q_ok ? qr0 : 0)] * (D / 2);
+      const int kv0 = p.kv_off ? p.kv_off[seq] : p.kv_len_offset;
+      const size_t tb = (size_t)(p.rope_pos_is_row ? kv0 + (q_ok ? qr0 : 0) : p.rope_pos[row0 + (q_ok ? qr0 : 0)]) * (D / 2);
 #pragma unroll
       for (int ks = 0; ks < NKS / 2; ++ks) {
         rco[ks] = *(const u16x8*)(p.rope_cos + tb + 16 * ks + 8 * h);

@@ -88,6 +88,8 @@ struct AttnArgs {
   // RoPE applied to the QUERY rows as they are loaded (same three bf16 roundings as rope_kernel); K must already be rotated.
   // null = queries are used as stored.  rope_pos: position of every packed query row; tables [max_pos, D/2] bf16.
   const int32_t* rope_pos; const bf16_t* rope_cos; const bf16_t* rope_sin;
+  int rope_pos_is_row;          // != 0: the position of query row r of a sequence IS kv offset + r (plain prefill / continuation): the kernel computes it
+                                // instead of loading rope_pos (one dependent global load fewer in front of the cos / sin rows in every workgroup's prologue)
   int q_tail;                   // > 0: only the last q_tail query rows of every sequence are computed (others left unwritten)
   int uniform_len;              // every sequence has max_len rows (InternViT frames): lets the dispatcher split the query rows between kernels
   // row range of ONE kernel launch (set by aigv_launch_attention when it splits the rows between the two kernels; 0 = no limit):
