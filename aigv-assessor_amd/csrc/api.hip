@@ -100,7 +100,7 @@ struct aigv_ctx {
   int attn_round_scores = 1;   // prefill attention: the reference's bf16 rounding points of the score matrix (aigv_set_attention_numerics)
   int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2 / 3
   // the other experiment knobs of this context (aigv_ctx_tune): -1 = follow the process default (aigv_tune_*)
-  int t_order = -1, t_variant = -1, t_attn_waves = -1, t_skinny_p = -1;
+  int t_order = -1, t_variant = -1, t_attn_waves = -1, t_skinny_p = -1, t_body_tile = -1;
   size_t splitk_floats = 0;
   float* splitk_ws = nullptr;  // fp32 slabs of the split-K row bands: owned by the context (one launch stream per context at a time)
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 2 (attention out, normed) + [64, I], reused per 64 consumed rows
@@ -223,7 +223,7 @@ struct GemmClassScope {   // GEMM launches inside the scope are booked under `cl
 // AttnArgs::waves), filled in here from the context's own setting (aigv_ctx_tune / aigv_set_gemm_mode) or, where the context leaves a
 // knob at -1 and for the context-free aigv_op_* entry points, from these process defaults (aigv_tune_*: tests and A/B scripts).
 // gemm_mode: 0 = row plans (scoring pass) / cost model (op level), 1 = the 128x128 kernel, 2 = the 256x256 kernel, 3 = batch-level cost model
-struct Tune { int gemm_mode = 0, order_sel = 0, variant_sel = 0, attn_waves = 0, skinny_p = 0; };
+struct Tune { int gemm_mode = 0, order_sel = 0, variant_sel = 0, attn_waves = 0, skinny_p = 0, body_tile = 0; };
 Tune g_tune;
 // the knobs in force for a call: the context's own setting, else the process default
 int resolved_gemm_mode(const aigv_ctx* c) { return (c && c->gemm_mode >= 0) ? c->gemm_mode : g_tune.gemm_mode; }
@@ -235,6 +235,7 @@ Tune tune_of(const aigv_ctx* c) {
     if (c->t_variant >= 0) t.variant_sel = c->t_variant;
     if (c->t_attn_waves >= 0) t.attn_waves = c->t_attn_waves;
     if (c->t_skinny_p >= 0) t.skinny_p = c->t_skinny_p;
+    if (c->t_body_tile >= 0) t.body_tile = c->t_body_tile;
   }
   return t;
 }
@@ -549,10 +550,27 @@ int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hi
     return launch_one(c, col_slice(a, a.N - 128, 128), epi, false, s);
   }
   const int S = tail_slices(a.N, a.K);
-  if (rp.tail_halves == 0 || S == 1) {
+  // The body rows may run on either tile kernel: both sum every output element over the full K in the same order, so not one bit moves
+  // (tests/test_gpu_ops.py pins that).  Shipped: always the 256 tiles - for one clip, whose wo / w2 / ViT proj / fc2 bodies are only 128
+  // tiles, the 128 kernel (512 tiles, two per CU) was expected to win by the cost model and measured 1-3 % slower per clip
+  // (profiles/r4_negatives.txt, 6); body_tile = 2 keeps the 128 form reachable for tests.
+  const bool body128 = rp.body_halves > 0 && tune_of(c).body_tile == 2;
+  const bool tails_apart = rp.tail_halves > 0 && S > 1;
+  if (body128) {
+    {
+      GemmArgs b = a;
+      b.row_tab = rp.d_tab; b.tab_halves = rp.body_halves;
+      GemmArgs pf = a; pf.M = rp.body_halves * 128;
+      GEMM_PROF(c, pf, s);
+      HIPCHK(c, aigv_launch_gemm(b, epi, s));
+    }
+    if (rp.tail_halves > 0 && !tails_apart) TRY(launch_tab(c, a, epi, rp.d_tab + 2 * rp.body_halves, rp.tail_halves, rp.tail_rows, 1, s));
+  } else if (!tails_apart) {
     TRY(launch_tab(c, a, epi, rp.d_tab, rp.body_halves + rp.tail_halves, rp.body_halves * 128 + rp.tail_rows, 1, s));
   } else {
     TRY(launch_tab(c, a, epi, rp.d_tab, rp.body_halves, rp.body_halves * 128, 1, s));
+  }
+  if (tails_apart) {
     const size_t per_pair = (size_t)S * 256 * a.N;
     const size_t cap = c ? c->splitk_floats : SPLITK_MAX_FLOATS;
     const int max_halves = (int)std::min<size_t>(cap / per_pair, 4096) * 2;
@@ -1605,6 +1623,9 @@ int aigv_ctx_tune(aigv_ctx* c, int knob, int value) {
     case AIGV_TUNE_SKINNY_P:
       if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4) break;
       c->t_skinny_p = value; return 0;
+    case AIGV_TUNE_BODY_TILE:
+      if (value < -1 || value > 2) break;
+      c->t_body_tile = value; return 0;
     default: return fail(c, AIGV_ERR_ARG, "aigv_ctx_tune: unknown knob %d", knob);
   }
   return fail(c, AIGV_ERR_ARG, "aigv_ctx_tune: value %d out of range for knob %d", value, knob);
@@ -2008,6 +2029,8 @@ int aigv_tune_gemm(int mode, double rate256) {
   // mode = kernel choice (0 auto, 1 128-tile, 2 256-tile) + 16 * (256-kernel schedule variant 0..3, experiments)
   // mode bits 4..6: 0 = keep the default schedule, 1 + v = select 256-kernel schedule variant v (0..3)
   // bits 10..13: tile order of the 256 kernel for every shape (default 0: by weight size, gemm256.hip): 1 = row groups, 1 + g = groups of g column tiles
+  // bits 14..15: tile kernel of a row plan's body: 0 by fill (default), 1 = 256 tiles, 2 = 128 tiles
+  g_tune.body_tile = (mode >> 14) & 3;
   g_tune.order_sel = (mode >> 10) & 15;
   mode &= 1023;
   const int vsel = mode >> 4;

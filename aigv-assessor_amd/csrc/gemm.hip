@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // ---- tile mapping -------------------------------------------------------------------------
-  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+  // rows: tile tm covers rows [tm * 128, ..) of the matrix, or - with a half-tile table (GemmArgs::row_tab, the per-sequence row plans
+  // of api.hip) - the table's half tm: `valid` rows from its base row
+  const int nbm = p.row_tab ? p.tab_halves : (p.M + BM - 1) / BM, nbn = p.N / BN;
   const int nwg = nbm * nbn;
   int wg;
   {
@@ -47,7 +49,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   const int gsz = min(nbm - first_m, GROUP_M);
   const int in_g = wg - group * per_group;
   const int tm = first_m + in_g % gsz, tn = in_g / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int n0 = tn * BN;
+  int m0 = tm * BM, mend = p.M;
+  if (p.row_tab) {
+    m0 = __builtin_amdgcn_readfirstlane(p.row_tab[2 * tm]);
+    mend = m0 + __builtin_amdgcn_readfirstlane(p.row_tab[2 * tm + 1]);
+  }
 
   // ---- staging addresses ----------------------------------------------------------------------
   // wave-instruction i of this wave fills rows (wave*4+i)*8 .. +7 of the tile; lane -> row lane>>3,
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rl = (wave * 4 + i) * 8 + lr;
-    const int ra = min(m0 + rl, p.M - 1);  // clamp: rows past M are computed on a copy, never stored
+    const int ra = min(m0 + rl, mend - 1);  // clamp: rows past the end are computed on a copy, never stored
     srcA[i] = p.A + (size_t)ra * p.lda + lc * 8;
     srcW[i] = p.W + (size_t)(n0 + rl) * p.ldw + lc * 8;
   }
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + fr;
-    if (m >= p.M) continue;
+    if (m >= mend) continue;
     if constexpr (EPI == EPI_PARTIAL) {
       float* slab = p.part + ((size_t)blockIdx.y * p.M + m) * p.N;
 #pragma unroll
@@ -190,7 +197,9 @@ template <int EPI>
 hipError_t launch(const GemmArgs& a, hipStream_t s) {
   static LdsAttrOnce lds_attr;
   if (hipError_t e = lds_attr.ensure((const void*)gemm_bf16_kernel<EPI>, 2 * STAGE_BYTES); e != hipSuccess) return e;
-  const int nbm = (a.M + BM - 1) / BM, nbn = a.N / BN;
+  if (a.row_tab && (EPI == EPI_PARTIAL || EPI == EPI_PATCH)) return hipErrorInvalidValue;   // the table form has no slab / patch row mapping here
+  const int nbm = a.row_tab ? a.tab_halves : (a.M + BM - 1) / BM, nbn = a.N / BN;
+  if (nbm <= 0) return hipSuccess;
   hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nbm * nbn), dim3(256), 2 * STAGE_BYTES, s, a);
   return hipGetLastError();
 }
@@ -307,6 +316,7 @@ hipError_t aigv_launch_gemm_splitk_fp8(const GemmArgs& a, int epi, int k_slices,
 
 hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s, bool tile256) {
   if (k_slices < 2 || (a.K / BK) % k_slices || !ws || epi == EPI_PATCH || epi >= EPI_COUNT) return hipErrorInvalidValue;
+  if (!tile256 && a.row_tab) return hipErrorInvalidValue;   // the 128 kernel's slabs have no table mapping
   if (tile256) {
     GemmArgs b = a;
     b.part = ws;

@@ -195,8 +195,9 @@ int aigv_decode_eos(aigv_ctx* ctx, int64_t* tokens, int32_t* state, const int64_
 int aigv_op_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
                  const void* resid, int ldr, const void* pos, int np, int M, int N, int K, int epi, void* stream);
 /* The same GEMM with its M = cu_host[n_seq] rows divided into n_seq independent sequences (HOST int32 cu_host[0..n_seq], cu[0] = 0; epi
- * 0..4): the dispatch of the scoring pass.  Every sequence's rows [0, 256 * floor(L / 256)) run on the full-K 256x256 kernel as whole
- * tiles addressed through a half-tile table, its remaining rows as (ragged) half tiles with a split-K factor that depends on (N, K)
+ * 0..4): the dispatch of the scoring pass.  Every sequence's rows [0, 256 * floor(L / 256)) run in full K as whole tiles addressed
+ * through a half-tile table on the 256x256 kernel (AIGV_TUNE_BODY_TILE = 2: on the 128x128 kernel, which sums every element in the same
+ * order - same bits, a test alias), its remaining rows as (ragged) half tiles with a split-K factor that depends on (N, K)
  * only, remainders of <= 4 rows on the weight-streaming kernel in its fixed form - a row's result depends on its own sequence alone,
  * never on the other sequences of the call.  Synchronises the stream (test entry point). */
 int aigv_op_gemm_rows(const void* A, int lda, const void* W, int ldw, void* C, int ldc, const void* bias, const void* ls,
@@ -283,13 +284,14 @@ enum aigv_tune_knob {
   AIGV_TUNE_GEMM256_ORDER = 1,   /* tile order of the 256 kernel: 0 by weight size, 1 row groups, 1 + g groups of g column tiles */
   AIGV_TUNE_GEMM256_VARIANT = 2, /* 0 the shipped schedule, 1 + v schedule variant v (0..3) */
   AIGV_TUNE_ATTN_WAVES = 3,      /* prefill attention: 0 default, 4 / 8 waves per workgroup */
-  AIGV_TUNE_SKINNY_P = 4         /* decode GEMV form: 0 per-shape default, 1 / 2 / 4 */
+  AIGV_TUNE_SKINNY_P = 4,        /* decode GEMV form: 0 per-shape default, 1 / 2 / 4 */
+  AIGV_TUNE_BODY_TILE = 5        /* tile kernel of a row plan's body rows: 0 / 1 = 256x256 (shipped), 2 = 128x128 (same bits, slower) */
 };
 int aigv_ctx_tune(aigv_ctx* ctx, int knob, int value);
 /* GEMM tile-kernel selection: mode 0 = cost model (default), 1 = always the 128x128 kernel, 2 = always the 256x256
  * phase-interleaved kernel where N % 256 == 0; rate256 > 0 overrides the model's relative throughput of the 256 kernel. */
 /* mode bits 4..6: 1 + v selects schedule variant v of the 256 kernel (0 = keep); bits 10..13: tile order of the 256 kernel, 0 = by weight
- * size (default), 1 = row groups, 1 + g = groups of g column tiles. */
+ * size (default), 1 = row groups, 1 + g = groups of g column tiles; bits 14..15: tile kernel of a row plan's body (AIGV_TUNE_BODY_TILE). */
 int aigv_tune_gemm(int mode, double rate256);
 /* The row bands run_gemm would cut an M x N x K problem into (host logic only, no GPU): plan[0] = row tiles (x256 rows) on the
  * 256x256 kernel in whole rounds, or -1 = the whole problem in one launch of that kernel; plan[1] = row tiles on the 256x256

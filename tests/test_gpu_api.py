@@ -579,11 +579,13 @@ def test_experiment_knobs_live_in_the_context(rig):
     base = score(model)
     assert torch.equal(score(other)["score1"], base["score1"])
     try:
-        for knob, value in (("attn_waves", 8), ("gemm256_order", 1), ("gemm256_order", 3), ("gemm256_variant", 4), ("gemm_mode", 2), ("skinny_p", 2)):
+        for knob, value in (("attn_waves", 8), ("gemm256_order", 1), ("gemm256_order", 3), ("gemm256_variant", 4), ("gemm_mode", 2), ("skinny_p", 2), ("body_tile", 1), ("body_tile", 2)):
             other.tune(knob, value)
             got = score(other)
             assert torch.equal(got["logit"], base["logit"]), (knob, value)
             assert (got["score1"].float() - base["score1"].float()).abs().max() <= 2.0 ** -8, (knob, value)
+            if knob == "body_tile":      # the two tile kernels sum in the same order: not one bit moves
+                assert torch.equal(got["score1"], base["score1"])
             assert torch.equal(score(model)["score1"], base["score1"])           # the first context never moved
             other.tune(knob, -1)
         assert torch.equal(score(other)["score1"], base["score1"])

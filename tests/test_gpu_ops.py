@@ -184,6 +184,26 @@ def test_gemm_row_plan_is_batch_invariant(lib, N, K, epi):
             assert torch.equal(got[i * n:(i + 1) * n].view(torch.int16), both[sl].view(torch.int16))
 
 
+@pytest.mark.parametrize("lens,N,K", [([2176], 512, 1024), ([1025] * 8, 1024, 1024), ([2176, 300, 1025], 1024, 3584), ([2233], 4096, 4096)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_row_plan_body_tile_changes_no_bit(lib, lens, N, K, epi):
+    """A row plan's body rows can run on the 256x256 kernel (shipped) or on the 128x128 kernel through the same half-tile table.  Both sum
+    every output element over the full K in the same order, so the two give the same BITS - the fact behind 'gemm modes 1 and 2 are
+    batch-invariant and identical to the default on body rows': forced 256 == forced 128 == default."""
+    from aigv_assessor_amd import native
+    g = torch.Generator().manual_seed(sum(lens) + N + K + epi)
+    A, W, bias, ls, resid, nout = _gemm_rows_case(g, lens, N, K, epi)
+    outs = []
+    try:
+        for body_tile in (1, 2, 0):
+            native.check(lib.aigv_tune_gemm(0 + 32 + (body_tile << 14), 0.0))
+            outs.append(_run_gemm_rows(lib, A, W, bias, ls, resid, nout, lens, epi))
+    finally:
+        native.check(lib.aigv_tune_gemm(0 + 32, 0.0))
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)) and torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+
+
 @pytest.mark.parametrize("mode", [1, 2 + 16, 2 + 32, 2 + 64, 0])
 @pytest.mark.parametrize("M,N,K,epi", [(1100, 512, 448, 0), (777, 256, 64, 1), (515, 768, 1024, 2), (300, 256, 192, 3),
                                         (1029, 1024, 512, 4), (256, 256, 128, 0),
