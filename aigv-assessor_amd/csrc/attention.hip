@@ -32,6 +32,18 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int KT = 64;    // keys per tile
 
+// Exchange between lane l and lane l ^ 32 (the two halves of a query's key range) as ONE VALU instruction (v_permlane32_swap: both halves
+// of the wave receive the low half's and the high half's value) - __shfl_xor(x, 32) compiles to ds_bpermute_b32, an LDS round trip.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ float xhalf_max(float x) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Diagnostic build only (-DAIGV_ATTN_STAMP, scripts/attn_stamp.py): where a wave's cycles go, summed over all waves of all launches.
 // Slots per head dim (0: d = 64, 1: d = 128): 0 waves, 1 total, 2 prologue (Q fragments, first DMA), 3 wait for the tile + barrier,
 // 4 DMA issue, 5 S^T = K Q^T incl. fragment reads and the row maximum, 6 softmax + P V, 7 epilogue, 8 tiles computed.  The stamps
@@ -366,15 +378,16 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
 #pragma unroll
         for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[st][e]);
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     STAMP(t3);
     STAMP_ADD(5, t2, t3);
-    const float m_new = fmaxf(m_run, tmax);
     // Lazy rescale: the running reference m_run only moves when some row's maximum has grown by more than 2^8 in the exp2
     // domain (a new row maximum turns up in almost every tile, a jump of 8 octaves almost never after the first).  Until
     // then p = exp2((s - m_run) * c) may exceed 1 (< 2^8): harmless in fp32 / bf16, and the final division by l uses the
     // same reference, so the result is the same softmax.  (NaN-safe: -inf - -inf compares false -> no move, mc = 0.)
-    if (__any((m_new - m_run) * sc > 8.0f)) {
+    // The test runs on the lane's OWN maximum (the other half of the row's keys sits in lane ^ 32): some lane sees a jump exactly when the
+    // row's maximum jumps, so the exchange between the halves is only paid on the rare tiles that move m (same bits as exchanging first).
+    if (__any((tmax - m_run) * sc > 8.0f)) {
+      const float m_new = fmaxf(m_run, xhalf_max(tmax));
       // rows with no visible key yet keep m = -inf; guard the exp argument (m_run = -inf -> alpha = 0)
       const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m_run - m_new) * sc);
       l_run *= alpha;
@@ -426,11 +439,7 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
         }
       }
     }
-    {
-      float psum = ps0 + ps1;
-      psum += __shfl_xor(psum, 32, 64);
-      l_run += psum;
-    }
+    l_run += xhalf_sum(ps0 + ps1);
     // quarter 0's softmax (8 fma, 8 exp, 8 add, 4 cvt), then per MFMA of quarters 0..2 its two transposed reads and 28 / NDT of the
     // next quarter's VALU instructions, then quarter 3's MFMAs
     __builtin_amdgcn_sched_group_barrier(0x002, 28, 0);

@@ -1,6 +1,6 @@
 """A few launches of the two headline attention shapes, for rocprofv3 --pmc passes (scripts/pmc_sq_summary.py)."""
-import math, sys, torch
-sys.path.insert(0, '.')
+import math, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aigv_assessor_amd import native
 from aigv_assessor_amd.native import ptr
 import os
