@@ -121,6 +121,15 @@ class InternVLChatConfig:
             l = dict(l)
             if "architectures" in l and l["architectures"] is not None:
                 l["architectures"] = tuple(l["architectures"])
+            if (l.get("architectures") or ("",))[0] == "LlamaForCausalLM":
+                # transformers' LlamaConfig: the same field names as InternLM2Config (which was derived from it) with its own defaults;
+                # newer transformers versions nest the rotary base under rope_parameters
+                rp = l.get("rope_parameters") or {}
+                l.setdefault("rope_theta", rp.get("rope_theta", 10000.0))
+                l.setdefault("rms_norm_eps", 1e-6)
+                l.setdefault("num_key_value_heads", l.get("num_attention_heads", 32))
+                if l.get("attention_bias") or l.get("mlp_bias"):
+                    raise NotImplementedError("Llama configurations with projection biases are not on this path")
             l = _pick(InternLM2Config, l)
         cfg = _pick(cls, d)
         cfg.vision_config, cfg.llm_config = v, l

@@ -164,9 +164,10 @@ class InternVLChatModel(nn.Module):
         super().__init__()
         if vision_model is not None or language_model is not None:
             raise NotImplementedError("pass weights through load_state_dict / from_pretrained")
-        if config.llm_config.architectures[0] != "InternLM2ForCausalLM":
-            # same restriction as the reference ctor accepts Llama too (modeling_internvl_chat.py:228-233);
-            # only InternLM2 is on this hot path
+        if config.llm_config.architectures[0] not in ("InternLM2ForCausalLM", "LlamaForCausalLM"):
+            # the two families the reference constructor accepts (modeling_internvl_chat.py:228-233).  A Llama checkpoint is re-packed
+            # into the InternLM2 weight layout when it is loaded (weights.llama_to_internlm2): the kernels and this module's parameter
+            # names are the same for both families
             raise NotImplementedError(f"{config.llm_config.architectures[0]} is not implemented.")
         if dtype != torch.bfloat16:
             raise NotImplementedError("the gfx950 path computes in bf16 (the reference eval dtype, stage2_eval.py:780)")
@@ -263,6 +264,7 @@ class InternVLChatModel(nn.Module):
             from .slowfast import SlowFastR50
             self.slowfast_model = SlowFastR50(sf)
         sd = {k: v for k, v in state_dict.items() if not k.startswith("slowfast_model.")}
+        sd = self._family_names(sd)
         if self.stage == 1:
             sd = {k: v for k, v in sd.items() if not k.startswith("mlpscore.")}
         own = dict(self.named_parameters())
@@ -280,11 +282,23 @@ class InternVLChatModel(nn.Module):
         self._invalidate()
         return missing, unexpected
 
+    def _family_names(self, sd):
+        """A transformers-Llama state dict (the reference's second LLM family) -> this module's InternLM2-layout names and packing."""
+        from . import weights
+        if not weights.is_llama_state_dict(sd):
+            return sd
+        if self.llm_arch_name != "LlamaForCausalLM":
+            raise RuntimeError("load_state_dict: Llama tensor names in a checkpoint for an InternLM2 configuration")
+        return weights.llama_to_internlm2(sd, self.config.llm_config)
+
     def load_state_dict_stream(self, named_tensors):
         """load_state_dict from an iterable of (name, tensor) without ever holding the whole state dict on the host (InternVL2-26B: 51 GB):
         every tensor is copied into its parameter as it arrives.  Names the model does not own raise; returns the names never seen."""
         own = dict(self.named_parameters())
         seen = set()
+        if self.llm_arch_name == "LlamaForCausalLM":
+            from .weights import llama_stream_to_internlm2
+            named_tensors = llama_stream_to_internlm2(named_tensors, self.config.llm_config)
         with torch.no_grad():
             for k, v in named_tensors:
                 if self.stage == 1 and k.startswith("mlpscore."):

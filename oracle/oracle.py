@@ -179,7 +179,7 @@ def scatter_embeds(sd: SD, input_ids: Tensor, img_context_token_id: int, vit_emb
     row <- motion token, all others in order <- visual tokens) and CHAT:788-797 (generate(): no motion
     token, every slot <- visual tokens).
     A count mismatch raises (the reference catches it and overwrites a prefix, CHAT:381-386)."""
-    emb = F.embedding(input_ids, sd["language_model.model.tok_embeddings.weight"]).clone()
+    emb = F.embedding(input_ids, embed_weight(sd)).clone()
     b, n, c = emb.shape
     emb = emb.reshape(b * n, c)
     sel = input_ids == img_context_token_id
@@ -247,6 +247,23 @@ def additive_mask(attention_mask: Tensor, q_len: int, past_len: int, dtype) -> T
 LLM_LINEAR_HOOK = None
 
 
+# The reference constructor also accepts transformers' LlamaForCausalLM (CHAT:228-229).  transformers is a pip dependency of the reference
+# (requirements pin 4.37.2; not vendored in /root/reference), so the Llama branch below restates its published modeling_llama.py: the same
+# eager attention, RMSNorm, rotate-half RoPE and SwiGLU MLP as InternLM2 (whose file was derived from it) with q / k / v as three Linears
+# and HF's tensor names.  One arithmetic difference exists between transformers versions: 4.37 divides the scores by sqrt(d) as InternLM2
+# does, the version installed in the build container (5.x, eager_attention_forward) multiplies them by d ** -0.5 - the fixture
+# tests/golden/e2e_llama.pt was recorded from the reference running on the installed version, so LLAMA_SCALE_BY_MULTIPLY defaults to True.
+LLAMA_SCALE_BY_MULTIPLY = True
+
+
+def is_llama(sd: SD) -> bool:
+    return "language_model.model.embed_tokens.weight" in sd
+
+
+def embed_weight(sd: SD) -> Tensor:
+    return sd["language_model.model.embed_tokens.weight"] if is_llama(sd) else sd["language_model.model.tok_embeddings.weight"]
+
+
 def _llm_linear(x: Tensor, w: Tensor, layer: int, name: str) -> Tensor:
     if LLM_LINEAR_HOOK is not None:
         return LLM_LINEAR_HOOK(x, w, layer, name)
@@ -258,14 +275,21 @@ def llm_attention(sd: SD, cfg, i: int, x: Tensor, mask: Tensor, position_ids: Te
     """InternLM2Attention.forward, eager (LM:355-440).  wqkv output features are ordered
     (kv_head, slot, d) with slots 0..g-1 = that group's q heads, slot g = K, slot g+1 = V (LM:375-385)."""
     l = cfg.llm_config
-    p = f"language_model.model.layers.{i}.attention."
     b, n, _ = x.shape
     nh, nkv, d = l.num_attention_heads, l.num_key_value_heads, l.head_dim
     g = nh // nkv
-    qkv = _llm_linear(x, sd[p + "wqkv.weight"], i, "wqkv").view(b, n, nkv, g + 2, d)
-    q = qkv[..., :g, :].reshape(b, n, nh, d).transpose(1, 2)
-    k = qkv[..., g, :].transpose(1, 2)
-    v = qkv[..., g + 1, :].transpose(1, 2)
+    llama = is_llama(sd)
+    if llama:   # LlamaAttention.forward: q_proj / k_proj / v_proj, heads in order (kv head j serves q heads j g .. j g + g - 1: repeat_kv)
+        p = f"language_model.model.layers.{i}.self_attn."
+        q = _llm_linear(x, sd[p + "q_proj.weight"], i, "q_proj").view(b, n, nh, d).transpose(1, 2)
+        k = _llm_linear(x, sd[p + "k_proj.weight"], i, "k_proj").view(b, n, nkv, d).transpose(1, 2)
+        v = _llm_linear(x, sd[p + "v_proj.weight"], i, "v_proj").view(b, n, nkv, d).transpose(1, 2)
+    else:
+        p = f"language_model.model.layers.{i}.attention."
+        qkv = _llm_linear(x, sd[p + "wqkv.weight"], i, "wqkv").view(b, n, nkv, g + 2, d)
+        q = qkv[..., :g, :].reshape(b, n, nh, d).transpose(1, 2)
+        k = qkv[..., g, :].transpose(1, 2)
+        v = qkv[..., g + 1, :].transpose(1, 2)
     kv_len = n + (past[0].shape[-2] if past is not None else 0)
     cos, sin = rope_tables(d, l.rope_theta, kv_len, v.dtype, l.max_position_embeddings, l.rope_scaling)
     q, k = apply_rope(q, k, cos, sin, position_ids)
@@ -275,15 +299,24 @@ def llm_attention(sd: SD, cfg, i: int, x: Tensor, mask: Tensor, position_ids: Te
     present = (k, v)
     kr = k[:, :, None].expand(b, nkv, g, kv_len, d).reshape(b, nh, kv_len, d)  # repeat_kv LM:282-291
     vr = v[:, :, None].expand(b, nkv, g, kv_len, d).reshape(b, nh, kv_len, d)
-    w = torch.matmul(q, kr.transpose(2, 3)) / math.sqrt(d)
+    if llama and LLAMA_SCALE_BY_MULTIPLY:
+        w = torch.matmul(q, kr.transpose(2, 3)) * (d ** -0.5)
+    else:
+        w = torch.matmul(q, kr.transpose(2, 3)) / math.sqrt(d)
     w = w + mask
     w = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
     y = torch.matmul(w, vr).transpose(1, 2).contiguous().reshape(b, n, nh * d)
+    if llama:
+        return _llm_linear(y, sd[p + "o_proj.weight"], i, "o_proj"), present
     return _llm_linear(y, sd[p + "wo.weight"], i, "wo"), present
 
 
 def llm_mlp(sd: SD, i: int, x: Tensor) -> Tensor:
     """InternLM2MLP.forward (LM:264-278): w2(silu(w1 x) * w3 x)."""
+    if is_llama(sd):   # LlamaMLP.forward: down_proj(act(gate_proj(x)) * up_proj(x))
+        p = f"language_model.model.layers.{i}.mlp."
+        return _llm_linear(F.silu(_llm_linear(x, sd[p + "gate_proj.weight"], i, "gate_proj")) * _llm_linear(x, sd[p + "up_proj.weight"], i, "up_proj"),
+                           sd[p + "down_proj.weight"], i, "down_proj")
     p = f"language_model.model.layers.{i}.feed_forward."
     return _llm_linear(F.silu(_llm_linear(x, sd[p + "w1.weight"], i, "w1")) * _llm_linear(x, sd[p + "w3.weight"], i, "w3"),
                        sd[p + "w2.weight"], i, "w2")
@@ -293,10 +326,11 @@ def llm_layer(sd: SD, cfg, i: int, x: Tensor, mask: Tensor, position_ids: Tensor
     """InternLM2DecoderLayer.forward (LM:635-695)."""
     p = f"language_model.model.layers.{i}."
     eps = cfg.llm_config.rms_norm_eps
-    a, present = llm_attention(sd, cfg, i, rms_norm_cast_then_scale(x, sd[p + "attention_norm.weight"], eps),
+    n1, n2 = ("input_layernorm.weight", "post_attention_layernorm.weight") if is_llama(sd) else ("attention_norm.weight", "ffn_norm.weight")
+    a, present = llm_attention(sd, cfg, i, rms_norm_cast_then_scale(x, sd[p + n1], eps),
                                mask, position_ids, past)
     x = x + a
-    x = x + llm_mlp(sd, i, rms_norm_cast_then_scale(x, sd[p + "ffn_norm.weight"], eps))
+    x = x + llm_mlp(sd, i, rms_norm_cast_then_scale(x, sd[p + n2], eps))
     return x, present
 
 
@@ -327,7 +361,7 @@ def llm_forward(sd: SD, cfg, inputs_embeds: Tensor, attention_mask: Optional[Ten
 
 def lm_logits(sd: SD, hidden: Tensor) -> Tensor:
     """InternLM2ForCausalLM.forward lm-head (LM:1094-1096): matmul in the model dtype, THEN .float()."""
-    return F.linear(hidden, sd["language_model.output.weight"]).float()
+    return F.linear(hidden, sd["language_model.lm_head.weight"] if is_llama(sd) else sd["language_model.output.weight"]).float()
 
 
 def score_head(sd: SD, cfg, x: Tensor) -> Tensor:
@@ -406,7 +440,7 @@ def greedy_generate(sd: SD, cfg, inputs_embeds: Tensor, attention_mask: Tensor, 
                 break
         mask = torch.cat([mask, torch.ones((b, 1), dtype=mask.dtype)], dim=1)
         pos = (mask.cumsum(-1) - 1)[:, -1:]
-        emb = F.embedding(nxt[:, None], sd["language_model.model.tok_embeddings.weight"])
+        emb = F.embedding(nxt[:, None], embed_weight(sd))
         hidden, past, _ = llm_forward(sd, cfg, emb, mask.bool(), pos, past)
     return torch.stack(out, dim=1)
 

@@ -469,6 +469,66 @@ def test_against_reference_golden_vectors(golden_dir):
         torch.cuda.empty_cache()
 
 
+def test_llama_family_against_the_reference_golden_vectors(golden_dir):
+    """The reference's second LLM family (modeling_internvl_chat.py:228-229: transformers' LlamaForCausalLM): a checkpoint with HF Llama
+    tensor names, loaded through load_state_dict (re-packed on the host: weights.llama_to_internlm2), against the outputs the REFERENCE
+    recorded with that LLM class (tests/golden/make_golden_llama.py) - same bars as the InternLM2 fixture of the same widths."""
+    from aigv_assessor_amd import weights
+    g = torch.load(os.path.join(golden_dir, "e2e_llama.pt"), weights_only=True)
+    cfg = pkg.InternVLChatConfig.from_dict(dict(vision_config=g["vision_config"], llm_config=g["llm_config"], force_image_size=448, select_layer=-1))
+    for tag in ("bf16_b1", "bf16_b2"):
+        c = g[tag]
+        B, T, seed = c["B"], c["T"], c["seed"]
+        sd = weights.internlm2_to_llama(synth.make_state_dict(cfg, seed=seed, rich=True), cfg.llm_config)
+        toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+        pv, motion, flags = synth.synthetic_frames(B * T, 448, seed=seed), synth.synthetic_motion(B, 2304, seed=seed), torch.ones(B * T, 1, dtype=torch.long)
+        model = make_model(cfg, sd)
+        assert model.llm_arch_name == "LlamaForCausalLM"
+        model.img_context_token_id = toks["img_context_token_id"]
+        out = model(mos=torch.full((B,), 0.5, dtype=BF), pixel_values=pv, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+                    image_flags=flags, labels=toks["labels"], motion_feature=motion)
+        want = c["label"] != -100
+        ref = O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion, toks["img_context_token_id"],
+                             stage=2, return_intermediates=True)      # the oracle's Llama branch (bit-pinned to the reference: test_oracle_golden)
+        logits = ref["logits"][..., :-1, :].reshape(-1, ref["logits"].shape[-1])[want]
+        assert assert_levels(out["logit"].cpu()[want], c["logit"][want], logits) <= 2
+        score_ok(out["score1"], c["score1"], ulps=4)
+        score_near_fp32(out["score1"], c["score1"], cfg, sd, toks, pv, motion, flags)
+        if tag == "bf16_b1":   # greedy decode through the KV cache against the reference LLM's own cache path
+            n_prompt = c["greedy_prompt_len"]
+            ids = toks["input_ids"][:, :n_prompt]
+            vit = O.extract_feature(sd, cfg, pv).reshape(-1, 4096)
+            emb = O.scatter_embeds(sd, ids, toks["img_context_token_id"], torch.cat([vit, vit[:1]]), None)
+            got = model.generate2(input_embeds=emb, attention_mask=torch.ones(1, n_prompt, dtype=torch.long), max_new_tokens=6)
+            assert torch.equal(got.cpu(), c["greedy_tokens"]), (got.cpu().tolist(), c["greedy_tokens"].tolist())
+        del model
+        torch.cuda.empty_cache()
+
+
+def test_llama_family_streamed_load_equals_the_dict_load():
+    """load_state_dict_stream with HF Llama names (q / k / v arrive one by one and leave as one packed wqkv) == load_state_dict."""
+    from aigv_assessor_amd import weights
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    cfg = pkg.tiny(image_size=224)
+    cfg.llm_config.architectures = ("LlamaForCausalLM",)
+    packed = synth.make_state_dict(cfg, seed=3, rich=True)
+    sd = weights.internlm2_to_llama(packed, cfg.llm_config)
+    a = make_model(cfg, sd)
+    b = InternVLChatModel(cfg)
+    assert b.load_state_dict_stream(iter(sd.items())) == []
+    b = b.eval().cuda()
+    toks = synth.canonical_tokens(cfg, 2, 4, seed=3)
+    kw = dict(pixel_values=synth.synthetic_frames(8, 224, seed=3), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+              image_flags=torch.ones(8, 1, dtype=torch.long), labels=toks["labels"], motion_feature=synth.synthetic_motion(2, cfg.motion_dim, seed=3))
+    for m in (a, b):
+        m.img_context_token_id = toks["img_context_token_id"]
+    oa, ob = a(**kw), b(**kw)
+    assert torch.equal(oa["score1"], ob["score1"]) and torch.equal(oa["logit"], ob["logit"])
+    with pytest.raises(RuntimeError):      # Llama names into an InternLM2 configuration
+        cfg2 = pkg.tiny(image_size=224)
+        InternVLChatModel(cfg2).load_state_dict(sd)
+
+
 def test_score_accuracy_matches_reference_bf16_path():
     """Over several seeds the HIP score must be as close to the fp32 oracle as the reference-faithful bf16 oracle is."""
     cfg = pkg.tiny(image_size=224, llm_layers=3, vit_layers=3)

@@ -553,3 +553,30 @@ def test_beam_search_follows_transformers(num_beams, eos, length_penalty, early_
         assert got.shape == want.shape and torch.equal(got, want), (seed, got.tolist(), want.tolist())
         checked += 1
     assert checked == 4
+
+
+def test_llama_family_config_and_streamed_repacking():
+    """The reference's second LLM family (modeling_internvl_chat.py:228-233): a LlamaForCausalLM llm_config parses with transformers'
+    LlamaConfig defaults where InternLM2's differ, the streamed re-packing equals the dict one, and other families still raise."""
+    import aigv_assessor_amd as pkg
+    from aigv_assessor_amd import synth, weights
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    d = dict(architectures=["LlamaForCausalLM"], hidden_size=256, intermediate_size=384, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2, vocab_size=64)
+    cfg = pkg.InternVLChatConfig.from_dict(dict(llm_config=d, vision_config=dict(hidden_size=64, intermediate_size=128, num_attention_heads=1, num_hidden_layers=1)))
+    l = cfg.llm_config
+    assert l.architectures == ("LlamaForCausalLM",) and l.rope_theta == 10000.0 and l.rms_norm_eps == 1e-6 and l.head_dim == 64
+    assert pkg.InternVLChatConfig.from_dict(dict(llm_config=dict(d, rope_parameters=dict(rope_theta=5e5, rope_type="default")))).llm_config.rope_theta == 5e5
+    with pytest.raises(NotImplementedError):
+        pkg.InternVLChatConfig.from_dict(dict(llm_config=dict(d, attention_bias=True)))
+    packed = synth.make_state_dict(cfg, seed=2, rich=True)
+    sd = weights.internlm2_to_llama(packed, l)
+    assert len(sd) == len(packed) + 2 * l.num_hidden_layers and "language_model.model.layers.1.self_attn.k_proj.weight" in sd
+    streamed = dict(weights.llama_stream_to_internlm2(iter(sd.items()), l))
+    assert set(streamed) == set(packed) and all(torch.equal(streamed[k], packed[k]) for k in packed)
+    with pytest.raises(KeyError):       # a layer whose v_proj never arrives
+        dict(weights.llama_stream_to_internlm2(((k, v) for k, v in sd.items() if not k.endswith("layers.1.self_attn.v_proj.weight")), l))
+    m = InternVLChatModel(cfg)          # constructs (host side only) and owns InternLM2-layout parameters for both families
+    assert m.llm_arch_name == "LlamaForCausalLM" and "language_model.model.layers.0.attention.wqkv.weight" in dict(m.named_parameters())
+    cfg.llm_config.architectures = ("Qwen2ForCausalLM",)
+    with pytest.raises(NotImplementedError):
+        InternVLChatModel(cfg)

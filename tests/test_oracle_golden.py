@@ -300,3 +300,69 @@ def test_26b_fixture_structure_and_streamed_weights():
     a = synth.make_state_dict(small, seed=11, rich=True)
     b = dict(synth.make_state_dict_iter(small, seed=11, rich=True))
     assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
+# ---- the reference's second LLM family: transformers' LlamaForCausalLM (modeling_internvl_chat.py:228-229) ----------------------------------
+@pytest.fixture(scope="module")
+def e2e_llama(golden_dir):
+    return torch.load(os.path.join(golden_dir, "e2e_llama.pt"), weights_only=True)
+
+
+def _llama_case(g, tag):
+    from aigv_assessor_amd import weights
+    c = g[tag]
+    dt = DT[c["dtype"]]
+    cfg = pkg.InternVLChatConfig.from_dict(dict(vision_config=g["vision_config"], llm_config=g["llm_config"], force_image_size=448, select_layer=-1))
+    assert cfg.llm_config.architectures[0] == "LlamaForCausalLM" and cfg.llm_config.rope_theta == 10000.0
+    packed = synth.make_state_dict(cfg, seed=c["seed"], dtype=dt, rich=True)
+    return c, dt, cfg, packed, weights.internlm2_to_llama(packed, cfg.llm_config)
+
+
+@pytest.mark.parametrize("tag", ["bf16_b1", "fp32_b1", "bf16_b2"])
+def test_llama_family_end_to_end_matches_the_reference(e2e_llama, tag):
+    """The oracle's Llama branch (HF names, q / k / v as three Linears, scores * d ** -0.5 as the installed transformers does) against the
+    REFERENCE built with llm architectures = ['LlamaForCausalLM'] (tests/golden/make_golden_llama.py)."""
+    c, dt, cfg, _packed, sd = _llama_case(e2e_llama, tag)
+    B, T, seed = c["B"], c["T"], c["seed"]
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    out = O.forward_eval(sd, cfg, synth.synthetic_frames(B * T, 448, seed=seed, dtype=dt), toks["input_ids"], toks["attention_mask"],
+                         torch.ones(B * T, 1, dtype=torch.long), toks["labels"], synth.synthetic_motion(B, 2304, seed=seed, dtype=dt),
+                         toks["img_context_token_id"], mos=torch.full((B,), 0.5, dtype=dt), stage=2, return_intermediates=True)
+    assert torch.equal(out["label"], c["label"]) and torch.equal(out["logit"], c["logit"])
+    assert close(out["hidden"][:, -4, :], c["hidden_m4"], dt, frac=0.01)
+    assert close(out["hidden"][..., ::13, ::41], c["hidden_sub"], dt, frac=0.01)
+    assert close(out["score1"], c["score1"], dt) and close(out["loss"], c["loss"], dt)
+
+
+def test_llama_family_greedy_decode_matches_the_reference_cache_path(e2e_llama):
+    c, _dt, cfg, _packed, sd = _llama_case(e2e_llama, "bf16_b1")
+    seed, n_prompt = c["seed"], c["greedy_prompt_len"]
+    toks = synth.canonical_tokens(cfg, 1, 8, seed=seed)
+    ids = toks["input_ids"][:, :n_prompt]
+    vit = O.extract_feature(sd, cfg, synth.synthetic_frames(8, 448, seed=seed)).reshape(-1, 4096)
+    emb = O.scatter_embeds(sd, ids, toks["img_context_token_id"], torch.cat([vit, vit[:1]]), None)
+    out = O.greedy_generate(sd, cfg, emb, torch.ones(1, n_prompt, dtype=torch.long), max_new_tokens=6)
+    assert torch.equal(out, c["greedy_tokens"])
+
+
+def test_llama_weights_repack_to_the_internlm2_layout_and_back(e2e_llama):
+    """weights.llama_to_internlm2 (the load-time re-packing the HIP path relies on): a bijection on the tensors, and the packed model
+    computes the same function - the InternLM2 branch of the oracle on the re-packed weights reproduces the reference's Llama pass up to
+    bf16 noise (x / sqrt(d) there, x * d ** -0.5 here; one packed GEMM there, three here): scores within one bf16 ulp, the argmax of a
+    640-word random-weight head moving on ~1 % of the rows (near-ties)."""
+    from aigv_assessor_amd import weights
+    c, dt, cfg, packed, sd = _llama_case(e2e_llama, "bf16_b2")
+    assert weights.is_llama_state_dict(sd) and not weights.is_llama_state_dict(packed)
+    back = weights.llama_to_internlm2(sd, cfg.llm_config)
+    assert set(back) == set(packed) and all(torch.equal(back[k], packed[k]) for k in packed)
+    B, T, seed = c["B"], c["T"], c["seed"]
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    args = (cfg, synth.synthetic_frames(B * T, 448, seed=seed, dtype=dt), toks["input_ids"], toks["attention_mask"], torch.ones(B * T, 1, dtype=torch.long),
+            toks["labels"], synth.synthetic_motion(B, 2304, seed=seed, dtype=dt), toks["img_context_token_id"])
+    a = O.forward_eval(back, *args, stage=2)
+    assert (a["logit"] != c["logit"]).float().mean().item() <= 0.03
+    assert (a["score1"].float() - c["score1"].float()).abs().max() <= 2.0 ** -8
+    bad = dict(sd)
+    bad["language_model.model.layers.0.self_attn.q_proj.bias"] = torch.zeros(4096)
+    with pytest.raises(NotImplementedError):
+        weights.llama_to_internlm2(bad, cfg.llm_config)
