@@ -580,3 +580,26 @@ def test_llama_family_config_and_streamed_repacking():
     cfg.llm_config.architectures = ("Qwen2ForCausalLM",)
     with pytest.raises(NotImplementedError):
         InternVLChatModel(cfg)
+
+
+def test_llama_family_lora_adapters_merge_before_the_repacking():
+    """A stage-2 LoRA checkpoint of the Llama family (peft targets q_proj / k_proj / v_proj / o_proj / gate_proj / up_proj / down_proj,
+    modeling_internvl_chat.py:288-305): W + 2 B A on the HF names first, then the re-packing - equal to re-packing the merged matrices."""
+    import aigv_assessor_amd as pkg
+    from aigv_assessor_amd import synth, weights
+    cfg = pkg.tiny(llm_hidden=128, llm_heads=2, llm_kv_heads=1, llm_layers=1, llm_inter=192, vocab=64)
+    cfg.llm_config.architectures = ("LlamaForCausalLM",)
+    l = cfg.llm_config
+    sd = weights.internlm2_to_llama(synth.make_state_dict(cfg, seed=4, rich=True), l)
+    g = torch.Generator().manual_seed(1)
+    lora, want = {}, dict(sd)
+    for name in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"):
+        k = f"language_model.model.layers.0.{name}"
+        w = sd[k + ".weight"]
+        a, b = torch.randn(4, w.shape[1], generator=g).to(torch.bfloat16), torch.randn(w.shape[0], 4, generator=g).to(torch.bfloat16)
+        lora[k.replace("language_model.", "language_model.base_model.model.") + ".lora_A.default.weight"] = a
+        lora[k.replace("language_model.", "language_model.base_model.model.") + ".lora_B.default.weight"] = b
+        want[k + ".weight"] = (w.float() + 2.0 * (b.float() @ a.float())).to(w.dtype)
+    merged = weights.llama_to_internlm2(weights.merge_lora_state_dict(sd, lora), l)
+    ref = weights.llama_to_internlm2(want, l)
+    assert set(merged) == set(ref) and all(torch.equal(merged[k], ref[k]) for k in ref)
