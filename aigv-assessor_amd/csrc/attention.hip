@@ -6,6 +6,8 @@
 // 32 query rows; the workgroup streams 64-key K/V tiles through a double-buffered LDS ring filled by LDS-DMA
 // (global_load_lds, 16 B/lane): tile t+1 is in flight while tile t is multiplied; one barrier per tile.
 //
+// Non-causal key counts 64 j + 1 (InternViT: cls + 1024 patches): the loop covers keys 1.. in full tiles, key 0 is merged in the epilogue ("lead key").
+//
 // MFMA formulation ("key on the row, query on the lane"):
 //   S^T[key, q] = K · Q^T      v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128, XOR-swizzled),
 //                              B = Q^T fragments held in registers for the whole kernel.
@@ -20,6 +22,7 @@
 // (aigv_set_attention_numerics 0); the softmax runs in fp32, P rounds to bf16 before P·V (un-normalised; the row is divided at
 // the end), the output rounds to bf16.  With RS the kernel sits ~4x closer to the eager bf16 result than that result sits to
 // fp64 truth; without it, it is at least as accurate against fp64 truth as the eager path (tests/test_gpu_ops.py).
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -121,7 +124,12 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
   if (q0 >= len) return;
   if (p.q_tail > 0 && q0 + QB <= len - p.q_tail) return;   // this block's rows are not consumed (last-layer row trimming)
   const int kv_off = p.kv_off ? p.kv_off[seq] : p.kv_len_offset;   // keys in front of this sequence's first query row
-  const int kv_len = len + kv_off;                // keys visible in total (plain prefill: offset 0)
+  const int kv_all = len + kv_off;                // keys visible in total (plain prefill: offset 0)
+  // Lead key (non-causal, key count = 64 j + 1: InternViT's 1025 = cls + 1024 patches): the tile loop would spend a whole masked tile on the
+  // one left-over key - 1 / 17 of a workgroup's work.  The loop runs over keys 1.. in full, unmasked tiles and key 0 is merged at the end
+  // like one more softmax state (a dot product, two exp2 and a scaled row add per query row, in the epilogue where the loop's registers are free).
+  const int lead = (!CAUSAL && !p.no_lead_key && kv_off == 0 && (kv_all % KT) == 1) ? 1 : 0;
+  const int kv_len = kv_all - lead;               // keys the tile loop covers (K / V tile bases advance by `lead` rows)
   // Ragged last block of a NON-causal sequence with at most 32 rows (ViT: 1025 = 8 x 128 + 1): instead of one wave doing the
   // whole key range for those rows while three idle - the block would last as long as a full one - all waves take the SAME
   // query slice and every NW-th key tile each; their softmax states are merged through LDS at the end (key split).
@@ -158,8 +166,10 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
     n_tiles = min(n_tiles, last_q / KT + 1);
   }
   const size_t kv_seq = p.kv_seq_stride ? (size_t)seq * p.kv_seq_stride : 0;
-  const bf16_t* kbase = p.k + (p.kv_seq_stride ? kv_seq : (size_t)row0 * p.ldk) + (size_t)hk * p.kv_head_stride;
-  const bf16_t* vbase = p.v + (p.kv_seq_stride ? kv_seq : (size_t)row0 * p.ldv) + (size_t)hk * p.kv_head_stride;
+  const bf16_t* k_row0 = p.k + (p.kv_seq_stride ? kv_seq : (size_t)row0 * p.ldk) + (size_t)hk * p.kv_head_stride;
+  const bf16_t* v_row0 = p.v + (p.kv_seq_stride ? kv_seq : (size_t)row0 * p.ldv) + (size_t)hk * p.kv_head_stride;
+  const bf16_t* kbase = k_row0 + (size_t)lead * p.ldk;
+  const bf16_t* vbase = v_row0 + (size_t)lead * p.ldv;
 
   // LDS-DMA staging: a wave-instruction writes 1 KB = RPI rows linearly, so the bank swizzles are applied to the per-lane
   // SOURCE chunk (the same XOR the fragment reads apply).  Keys past kv_len re-read the last valid row (masked later).
@@ -500,6 +510,38 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[i][e] += o[2 + i * 16 + e] * aw;
     }
+    m_run = M;     // (the lead-key merge below continues from the merged state)
+  }
+
+  if (lead) {
+    // ---- the lead key (see above), merged like one more softmax state: M = max(m, s0), O = O e^(m - M) + v0 e^(s0 - M), l likewise.
+    // Its K elements sit at this lane's query-fragment positions, its V elements at this lane's O^T positions; the loop's registers are free now.
+    u16x8 k0r[NKS];
+    u16x4 v0r[NDT * 4];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) k0r[ks] = *(const u16x8*)(k_row0 + 16 * ks + 8 * h);
+#pragma unroll
+    for (int i = 0; i < NDT * 4; ++i) v0r[i] = *(const u16x4*)(v_row0 + 32 * (i >> 2) + 8 * (i & 3) + 4 * h);
+    float s0 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const u16x8 qq = __builtin_bit_cast(u16x8, qf[ks]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s0 = __builtin_fmaf(bf2f(qq[j]), bf2f(k0r[ks][j]), s0);
+    }
+    s0 = xhalf_sum(s0);                      // the other half of the row's dimensions sits in lane ^ 32
+    if constexpr (RS) {
+      if (p.round_scores) s0 = rbf(s0);
+      if (p.round_scores == 2) s0 = rbf(s0 * inv_div);
+    }
+    const float M = fmaxf(m_run, s0);
+    const float a0 = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - M) * sc);
+    const float a1 = __builtin_amdgcn_exp2f((s0 - M) * sc);
+    l_run = l_run * a0 + a1;
+#pragma unroll
+    for (int i = 0; i < NDT * 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) oacc[i >> 2][4 * (i & 3) + e] = oacc[i >> 2][4 * (i & 3) + e] * a0 + a1 * bf2f(v0r[i][e]);
   }
 
   // ---- normalise and store: lane (c,h) owns O[qw+c][32*dt + 8*(e>>2) + 4h + (e&3)] -------------------------
@@ -769,6 +811,8 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
 // profiles/r3_attn8_negative.txt).  aigv_tune_attention: 4 / 8 waves per workgroup (A/B only).
 hipError_t aigv_launch_attention(const AttnArgs& a_in, int head_dim, hipStream_t s) {
   AttnArgs a = a_in;
+  static const bool env_no_lead = getenv("AIGV_NO_LEAD_KEY") != nullptr;   // A/B knob (bench runs): the plain loop for 64 j + 1 keys
+  if (env_no_lead) a.no_lead_key = 1;
   {
     // A power-of-two query pre-scale (InternViT: d^-1/2 = 2^-3) commutes exactly with the bf16 rounding of q and with the fp32 dot
     // products, so it is folded into the softmax's exp2 scale instead of being applied to every query element: the same bits

@@ -469,7 +469,7 @@ def attn_truth(q, k, v, causal, scale_pre, post_div, dtype):
     return (p @ vv).transpose(0, 1)
 
 
-def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False, round_scores=False):
+def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False, round_scores=False, no_lead_key=False):
     from aigv_assessor_amd.native import ptr
     T, h, hk = q.shape[0], q.shape[1], k.shape[1]
     g = h // hk
@@ -484,7 +484,7 @@ def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False, round
     out = torch.full((T, h * d), float("nan"), dtype=BF, device="cuda")
     base = dq.data_ptr()
     sync(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(dev(cu)),
-                               len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal) | (2 if uniform else 0) | (4 if round_scores else 0),
+                               len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal) | (2 if uniform else 0) | (4 if round_scores else 0) | (8 if no_lead_key else 0),
                                post, pre, None), lib)
     return out.cpu().view(T, h, d)
 
@@ -543,6 +543,28 @@ def _attention_case(lib, d, causal, h, hk, lens, uniform, round_scores=False):
     print(f"sum |hip - eager bf16| / sum |eager bf16 - fp64 truth| = {near / max(far, 1e-30):.3f} (round_scores={round_scores})")
     if round_scores:       # what remains is the P rounding (un-normalised here, normalised there) and the output rounding
         assert near <= 0.75 * far, (near, far)
+
+
+@pytest.mark.parametrize("d,h,lens", [(64, 2, [1025, 1025]), (64, 3, [257, 65, 1]), (128, 2, [1025, 129])])
+@pytest.mark.parametrize("round_scores", [True, False])
+def test_attention_lead_key_form_equals_the_plain_loop_up_to_rounding(lib, d, h, lens, round_scores):
+    """Non-causal key counts 64 j + 1 (InternViT: cls + 1024 patches): key 0 enters as the initial softmax state and the loop runs over 16
+    full, unmasked tiles instead of 16 + one tile with a single live key.  Same softmax, another fp32 summation order: both forms pass the
+    eager-reference bars (test_attention_matches_eager_reference runs the default = lead form) and sit within output rounding of each other."""
+    g = torch.Generator().manual_seed(sum(lens) + d + h)
+    T = sum(lens)
+    q = (torch.randn(T, h, d, generator=g) * 1.5).to(BF)
+    k = (torch.randn(T, h, d, generator=g) * 1.5).to(BF)
+    v = torch.randn(T, h, d, generator=g).to(BF)
+    k[0] *= 4.0           # a dominant lead key in the first sequence: its weight decides most rows
+    a = run_attention(lib, q, k, v, lens, False, d, d ** -0.5, 1.0, False, round_scores, no_lead_key=False).float()
+    b = run_attention(lib, q, k, v, lens, False, d, d ** -0.5, 1.0, False, round_scores, no_lead_key=True).float()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    # outputs are weighted means of O(1) values: an element's rounding noise is a bf16 ulp of the ROW's scale, not of its own (possibly tiny) value
+    scale = b.abs().amax(-1, keepdim=True).clamp_min(1e-3)
+    assert ((a - b).abs() <= 2.0 ** -7 * scale).all(), ((a - b).abs() / scale).max().item()
+    assert (a - b).abs().mean().item() <= 2.0 ** -10 * b.abs().mean().item()
+    assert (a != b).float().mean().item() <= 0.25
 
 
 def test_attention_with_fused_query_rope_equals_rope_then_attention(lib):
