@@ -1938,7 +1938,7 @@ int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void
   a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
   a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
   a.causal = causal & 1; a.uniform_len = (causal >> 1) & 1; a.post_div = post_div; a.q_prescale = q_prescale;
-  a.round_scores = (causal >> 2) & 1; a.no_lead_key = (causal >> 3) & 1; a.waves = g_tune.attn_waves;
+  a.round_scores = (causal >> 2) & 1; a.lead_key = (causal >> 3) & 1; a.waves = g_tune.attn_waves;
   if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));
   return 0;
@@ -1953,7 +1953,7 @@ int aigv_op_attention_rope(const void* q, int ldq, const void* k, int ldk, const
   a.o = (bf16_t*)o; a.ldo = ldo; a.cu = cu; a.n_seq = n_seq; a.max_len = max_len; a.n_heads = n_heads;
   a.n_kv_heads = n_kv_heads; a.q_group_stride = q_group_stride; a.kv_head_stride = kv_head_stride;
   a.causal = causal & 1; a.uniform_len = (causal >> 1) & 1; a.post_div = post_div; a.q_prescale = q_prescale;
-  a.round_scores = (causal >> 2) & 1; a.no_lead_key = (causal >> 3) & 1; a.waves = g_tune.attn_waves;
+  a.round_scores = (causal >> 2) & 1; a.lead_key = (causal >> 3) & 1; a.waves = g_tune.attn_waves;
   a.rope_pos = pos; a.rope_cos = (const bf16_t*)cos; a.rope_sin = (const bf16_t*)sin;
   if (const char* m = aigv_attn_check(a, head_dim)) return fail(nullptr, AIGV_ERR_ARG, "%s", m);
   HIPCHK(nullptr, aigv_launch_attention(a, head_dim, (hipStream_t)stream));

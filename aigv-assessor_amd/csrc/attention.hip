@@ -6,7 +6,7 @@
 // 32 query rows; the workgroup streams 64-key K/V tiles through a double-buffered LDS ring filled by LDS-DMA
 // (global_load_lds, 16 B/lane): tile t+1 is in flight while tile t is multiplied; one barrier per tile.
 //
-// Non-causal key counts 64 j + 1 (InternViT: cls + 1024 patches): the loop covers keys 1.. in full tiles, key 0 is merged in the epilogue ("lead key").
+// Non-causal key counts 64 j + 1 (InternViT: cls + 1024 patches), opt-in: the loop covers keys 1.. in full tiles, key 0 is merged in the epilogue ("lead key").
 //
 // MFMA formulation ("key on the row, query on the lane"):
 //   S^T[key, q] = K · Q^T      v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128, XOR-swizzled),
@@ -126,9 +126,12 @@ __global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 4 : 2) void attn_fw
   const int kv_off = p.kv_off ? p.kv_off[seq] : p.kv_len_offset;   // keys in front of this sequence's first query row
   const int kv_all = len + kv_off;                // keys visible in total (plain prefill: offset 0)
   // Lead key (non-causal, key count = 64 j + 1: InternViT's 1025 = cls + 1024 patches): the tile loop would spend a whole masked tile on the
-  // one left-over key - 1 / 17 of a workgroup's work.  The loop runs over keys 1.. in full, unmasked tiles and key 0 is merged at the end
-  // like one more softmax state (a dot product, two exp2 and a scaled row add per query row, in the epilogue where the loop's registers are free).
-  const int lead = (!CAUSAL && !p.no_lead_key && kv_off == 0 && (kv_all % KT) == 1) ? 1 : 0;
+  // one left-over key - 1 / 17 of a workgroup's work.  With AttnArgs::lead_key the loop runs over keys 1.. in full, unmasked tiles and key 0 is
+  // merged at the end like one more softmax state (a dot product, two exp2 and a scaled row add per query row, in the epilogue where the loop's
+  // registers are free).  OPT-IN: -2 % on the InternViT shape in-step and statistically neutral on the 13 reference-recorded clips (mean 2.96
+  // against 3.19 bf16 ulps from the reference's scores), but another fp32 summation order re-rolls each clip's rounding noise, and the recorded
+  // per-batch numbers of the default path are kept as they are (profiles/r4_attn_stagger_negative.txt, 6).
+  const int lead = (!CAUSAL && p.lead_key && kv_off == 0 && (kv_all % KT) == 1) ? 1 : 0;
   const int kv_len = kv_all - lead;               // keys the tile loop covers (K / V tile bases advance by `lead` rows)
   // Ragged last block of a NON-causal sequence with at most 32 rows (ViT: 1025 = 8 x 128 + 1): instead of one wave doing the
   // whole key range for those rows while three idle - the block would last as long as a full one - all waves take the SAME
@@ -811,8 +814,8 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
 // profiles/r3_attn8_negative.txt).  aigv_tune_attention: 4 / 8 waves per workgroup (A/B only).
 hipError_t aigv_launch_attention(const AttnArgs& a_in, int head_dim, hipStream_t s) {
   AttnArgs a = a_in;
-  static const bool env_no_lead = getenv("AIGV_NO_LEAD_KEY") != nullptr;   // A/B knob (bench runs): the plain loop for 64 j + 1 keys
-  if (env_no_lead) a.no_lead_key = 1;
+  static const bool env_lead = getenv("AIGV_LEAD_KEY") != nullptr;   // A/B knob (bench runs): the lead-key form for 64 j + 1 keys
+  if (env_lead) a.lead_key = 1;
   {
     // A power-of-two query pre-scale (InternViT: d^-1/2 = 2^-3) commutes exactly with the bf16 rounding of q and with the fp32 dot
     // products, so it is folded into the softmax's exp2 scale instead of being applied to every query element: the same bits

@@ -94,7 +94,7 @@ struct AttnArgs {
   int uniform_len;              // every sequence has max_len rows (InternViT frames): lets the dispatcher split the query rows between kernels
   // row range of ONE kernel launch (set by aigv_launch_attention when it splits the rows between the two kernels; 0 = no limit):
   int waves;                    // 0 = default (4 waves per workgroup); 4 / 8 forced (A/B: aigv_tune_attention / aigv_ctx_tune)
-  int no_lead_key;              // != 0: keep the plain tile loop for key counts 64 j + 1 (A/B and tests; see attention.hip "lead key")
+  int lead_key;                 // != 0: non-causal key counts 64 j + 1 run as full tiles over keys 1.. + key 0 merged in the epilogue (opt-in; attention.hip "lead key")
   int q_begin;                  // the launch computes query rows >= q_begin (a multiple of the workgroup's 128 rows) only; 0 everywhere at present
 };
 const char* aigv_attn_check(const AttnArgs& a, int head_dim);

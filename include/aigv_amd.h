@@ -240,8 +240,8 @@ int aigv_op_rope(void* qkv, int ld, const int32_t* pos, const void* cos, const v
                  int slots, int n_groups, int head_dim, void* stream);
 /* q/k/v as in kernels.h AttnArgs; cu is a DEVICE int32[n_seq+1].  causal: bit 0 = causal mask; bit 1 = "every sequence has
  * exactly max_len rows" (InternViT frames), which lets the dispatcher give a short left-over query block to the key-split kernel;
- * bit 2 = the score matrix rounds to bf16 as in the reference's eager path (aigv_set_attention_numerics mode 1); bit 3 = keep the plain
- * tile loop for non-causal key counts 64 j + 1 (default: key 0 enters as the initial softmax state and the loop runs over full tiles). */
+ * bit 2 = the score matrix rounds to bf16 as in the reference's eager path (aigv_set_attention_numerics mode 1); bit 3 = the
+ * lead-key form for non-causal key counts 64 j + 1 (full tiles over keys 1.., key 0 merged in the epilogue; opt-in, off in the scoring pass). */
 int aigv_op_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
                       const int32_t* cu, int n_seq, int max_len, int n_heads, int n_kv_heads, int q_group_stride,
                       int kv_head_stride, int head_dim, int causal, float post_div, float q_prescale, void* stream);

@@ -469,7 +469,7 @@ def attn_truth(q, k, v, causal, scale_pre, post_div, dtype):
     return (p @ vv).transpose(0, 1)
 
 
-def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False, round_scores=False, no_lead_key=False):
+def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False, round_scores=False, lead_key=False):
     from aigv_assessor_amd.native import ptr
     T, h, hk = q.shape[0], q.shape[1], k.shape[1]
     g = h // hk
@@ -484,7 +484,7 @@ def run_attention(lib, q, k, v, lens, causal, d, pre, post, uniform=False, round
     out = torch.full((T, h * d), float("nan"), dtype=BF, device="cuda")
     base = dq.data_ptr()
     sync(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(dev(cu)),
-                               len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal) | (2 if uniform else 0) | (4 if round_scores else 0) | (8 if no_lead_key else 0),
+                               len(lens), max(lens), h, hk, (g + 2) * d, (g + 2) * d, d, int(causal) | (2 if uniform else 0) | (4 if round_scores else 0) | (8 if lead_key else 0),
                                post, pre, None), lib)
     return out.cpu().view(T, h, d)
 
@@ -548,17 +548,17 @@ def _attention_case(lib, d, causal, h, hk, lens, uniform, round_scores=False):
 @pytest.mark.parametrize("d,h,lens", [(64, 2, [1025, 1025]), (64, 3, [257, 65, 1]), (128, 2, [1025, 129])])
 @pytest.mark.parametrize("round_scores", [True, False])
 def test_attention_lead_key_form_equals_the_plain_loop_up_to_rounding(lib, d, h, lens, round_scores):
-    """Non-causal key counts 64 j + 1 (InternViT: cls + 1024 patches): key 0 enters as the initial softmax state and the loop runs over 16
-    full, unmasked tiles instead of 16 + one tile with a single live key.  Same softmax, another fp32 summation order: both forms pass the
-    eager-reference bars (test_attention_matches_eager_reference runs the default = lead form) and sit within output rounding of each other."""
+    """Non-causal key counts 64 j + 1 (InternViT: cls + 1024 patches), the opt-in lead-key form: the loop runs over 16 full, unmasked tiles
+    and key 0 is merged in the epilogue, instead of 16 tiles + one tile with a single live key.  Same softmax, another fp32 summation
+    order: within one bf16 ulp of the row scale of the default form (incl. the key-split block of the 1025th row and a one-key sequence)."""
     g = torch.Generator().manual_seed(sum(lens) + d + h)
     T = sum(lens)
     q = (torch.randn(T, h, d, generator=g) * 1.5).to(BF)
     k = (torch.randn(T, h, d, generator=g) * 1.5).to(BF)
     v = torch.randn(T, h, d, generator=g).to(BF)
     k[0] *= 4.0           # a dominant lead key in the first sequence: its weight decides most rows
-    a = run_attention(lib, q, k, v, lens, False, d, d ** -0.5, 1.0, False, round_scores, no_lead_key=False).float()
-    b = run_attention(lib, q, k, v, lens, False, d, d ** -0.5, 1.0, False, round_scores, no_lead_key=True).float()
+    a = run_attention(lib, q, k, v, lens, False, d, d ** -0.5, 1.0, False, round_scores, lead_key=True).float()
+    b = run_attention(lib, q, k, v, lens, False, d, d ** -0.5, 1.0, False, round_scores, lead_key=False).float()
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     # outputs are weighted means of O(1) values: an element's rounding noise is a bf16 ulp of the ROW's scale, not of its own (possibly tiny) value
     scale = b.abs().amax(-1, keepdim=True).clamp_min(1e-3)
