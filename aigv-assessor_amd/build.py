@@ -14,13 +14,15 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "attention.hip", "rowops.hip", "head.hip", "head8.hip", "ingest.hip", "slowfast.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "gemmco.hip", "attention.hip", "rowops.hip", "head.hip", "head8.hip", "ingest.hip", "slowfast.hip"]
 HEADERS = ["common.h", "kernels.h", "attn_lay.h", os.path.join("..", "..", "include", "aigv_amd.h")]
 OUT = os.path.join(HERE, "libaigv_amd.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file additions.  The attention kernels' softmax is written one score at a time on purpose (v_pk_*_f32 is slower beside MFMAs): keep
 # hipcc's SLP vectoriser from re-packing it
 EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+# diagnostic builds (scripts/*_stamp.py, scripts/gemmco_diag.py): AIGV_HIPCC_DEFINES="-DAIGV_CO_DIAG ..." adds defines to every file; never set for the product
+DIAG_DEFINES = os.environ.get("AIGV_HIPCC_DEFINES", "").split()
 
 
 def _mtime(p: str) -> float:
@@ -51,7 +53,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 4) -> str:
         hipcc = "hipcc"
 
     def compile_one(src: str):
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        cmd = [hipcc] + FLAGS + DIAG_DEFINES + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         return src, subprocess.run(cmd, capture_output=True, text=True)

@@ -46,6 +46,22 @@ class InternVisionConfig:
         return self.hidden_size // self.num_attention_heads
 
 
+def _normalise_rope_scaling(sc):
+    """{'type': 'linear' | 'dynamic', 'factor': f} whatever spelling the configuration uses ('rope_type' is transformers' newer alias of
+    'type'); 'default' / None -> None.  Anything else (llama3, yarn, longrope ...) is not built here: wrong RoPE is wrong logits with no
+    error, so it raises instead of running unscaled."""
+    if not sc:
+        return None
+    kind = sc.get("type", sc.get("rope_type"))
+    if kind in (None, "default"):
+        return None
+    if kind not in ("linear", "dynamic"):
+        raise NotImplementedError(f"rope scaling type {kind!r} is not on this path (linear and dynamic-NTK are)")
+    if "factor" not in sc:
+        raise ValueError(f"rope scaling {sc!r} has no factor")
+    return {"type": kind, "factor": float(sc["factor"])}
+
+
 @dataclass
 class InternLM2Config:
     hidden_size: int = 4096
@@ -122,14 +138,25 @@ class InternVLChatConfig:
             if "architectures" in l and l["architectures"] is not None:
                 l["architectures"] = tuple(l["architectures"])
             if (l.get("architectures") or ("",))[0] == "LlamaForCausalLM":
-                # transformers' LlamaConfig: the same field names as InternLM2Config (which was derived from it) with its own defaults;
-                # newer transformers versions nest the rotary base under rope_parameters
-                rp = l.get("rope_parameters") or {}
+                # transformers' LlamaConfig: the same field names as InternLM2Config (which was derived from it) with its OWN defaults
+                # (configuration_llama.py); newer transformers versions nest the rotary base and scaling under rope_parameters
+                rp = dict(l.get("rope_parameters") or {})
                 l.setdefault("rope_theta", rp.get("rope_theta", 10000.0))
-                l.setdefault("rms_norm_eps", 1e-6)
-                l.setdefault("num_key_value_heads", l.get("num_attention_heads", 32))
+                for key, default in (("vocab_size", 32000), ("hidden_size", 4096), ("intermediate_size", 11008), ("num_hidden_layers", 32),
+                                     ("num_attention_heads", 32), ("max_position_embeddings", 2048), ("rms_norm_eps", 1e-6),
+                                     ("pad_token_id", None), ("bos_token_id", 1), ("eos_token_id", 2)):
+                    l.setdefault(key, default)
+                l.setdefault("num_key_value_heads", l["num_attention_heads"])
                 if l.get("attention_bias") or l.get("mlp_bias"):
                     raise NotImplementedError("Llama configurations with projection biases are not on this path")
+                if l.get("head_dim") not in (None, l["hidden_size"] // l["num_attention_heads"]):
+                    raise NotImplementedError(f"head_dim {l['head_dim']} != hidden_size // num_attention_heads is not on this path")
+                sc = l.get("rope_scaling")
+                if sc is None and (rp.get("rope_type") or rp.get("type") or "default") != "default":
+                    sc = rp                                                      # scaling carried inside rope_parameters
+                l["rope_scaling"] = _normalise_rope_scaling(sc)
+            elif l.get("rope_scaling") is not None:
+                l["rope_scaling"] = _normalise_rope_scaling(l["rope_scaling"])
             l = _pick(InternLM2Config, l)
         cfg = _pick(cls, d)
         cfg.vision_config, cfg.llm_config = v, l

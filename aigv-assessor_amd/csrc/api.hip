@@ -85,7 +85,7 @@ struct aigv_ctx {
   int32_t* v_cu = nullptr;
   bf16_t *p_t = nullptr, *p_mid = nullptr;
   bf16_t *l_h = nullptr, *l_t = nullptr, *l_qkv = nullptr, *l_ao = nullptr, *l_ffn = nullptr, *l_rows = nullptr;
-  int32_t *l_pos = nullptr, *l_seq = nullptr, *l_cu = nullptr, *l_rowidx = nullptr, *l_kvlen = nullptr;
+  int32_t *l_pos = nullptr, *l_seq = nullptr, *l_cu = nullptr, *l_rowidx = nullptr, *l_rowidx2 = nullptr, *l_kvlen = nullptr;
   unsigned long long* l_packed = nullptr;
   int32_t* l_neg1 = nullptr;   // max_tokens x int32 -1: the "plain text token" slot map of aigv_llm_extend
   // fp8 mode of the InternLM2 prefill GEMMs (aigv_set_precision): weights quantised once, activations per row on the fly
@@ -98,9 +98,10 @@ struct aigv_ctx {
   const RowPlan* cur_rp = nullptr;  // plan the InternLM2 layer helpers run under (null: batch-level dispatch, aigv_llm_extend)
   bool trim_last_layer = true;
   int attn_round_scores = 1;   // prefill attention: the reference's bf16 rounding points of the score matrix (aigv_set_attention_numerics)
-  int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2 / 3
+  int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2 / 3 / 4
   // the other experiment knobs of this context (aigv_ctx_tune): -1 = follow the process default (aigv_tune_*)
-  int t_order = -1, t_variant = -1, t_attn_waves = -1, t_skinny_p = -1, t_body_tile = -1;
+  int t_order = -1, t_variant = -1, t_attn_waves = -1, t_skinny_p = -1, t_body_tile = -1, t_co_kmax = -1;
+  int t_tail_slices = -1, t_lead_key = -1, t_decode_fused = -1, t_decode_fp8 = -1, t_skinny_p8 = -1;
   size_t splitk_floats = 0;
   float* splitk_ws = nullptr;  // fp32 slabs of the split-K row bands: owned by the context (one launch stream per context at a time)
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 2 (attention out, normed) + [64, I], reused per 64 consumed rows
@@ -222,8 +223,17 @@ struct GemmClassScope {   // GEMM launches inside the scope are booked under `cl
 // Experiment knobs.  The kernel files hold no mutable state: every launch carries its selectors (GemmArgs::order_sel / variant_sel,
 // AttnArgs::waves), filled in here from the context's own setting (aigv_ctx_tune / aigv_set_gemm_mode) or, where the context leaves a
 // knob at -1 and for the context-free aigv_op_* entry points, from these process defaults (aigv_tune_*: tests and A/B scripts).
-// gemm_mode: 0 = row plans (scoring pass) / cost model (op level), 1 = the 128x128 kernel, 2 = the 256x256 kernel, 3 = batch-level cost model
-struct Tune { int gemm_mode = 0, order_sel = 0, variant_sel = 0, attn_waves = 0, skinny_p = 0, body_tile = 0; };
+// gemm_mode: 0 = row plans (scoring pass) / cost model (op level), 1 = the 128x128 kernel, 2 = the 256x256 kernel, 3 = batch-level cost model,
+//            4 = the co-resident 256x128 kernel
+// co_kmax:   GEMMs with K <= co_kmax run on the co-resident 256x128 kernel (gemmco.hip) in modes 0 / 3 - a function of K alone, so a row's
+//            kernel form never depends on its batch; 0 = never
+constexpr int CO_KMAX_DEFAULT = 0;   // measured: profiles/r5_gemmco.txt
+struct Tune {
+  int gemm_mode = 0, order_sel = 0, variant_sel = 0, attn_waves = 0, skinny_p = 0, body_tile = 0, co_kmax = CO_KMAX_DEFAULT;
+  // context-only experiment knobs (aigv_ctx_tune): split-K factor of the tails (0 = the per-shape rule), lead-key attention form for 64 j + 1 keys,
+  // fused-norm decode GEMVs (1 = on), e4m3 decode GEMVs in fp8 mode (1 = on), form of the e4m3 decode GEMVs (0 = per-GEMV defaults)
+  int tail_slices = 0, lead_key = 0, decode_fused = 1, decode_fp8 = 1, skinny_p8 = 0;
+};
 Tune g_tune;
 // the knobs in force for a call: the context's own setting, else the process default
 int resolved_gemm_mode(const aigv_ctx* c) { return (c && c->gemm_mode >= 0) ? c->gemm_mode : g_tune.gemm_mode; }
@@ -236,6 +246,12 @@ Tune tune_of(const aigv_ctx* c) {
     if (c->t_attn_waves >= 0) t.attn_waves = c->t_attn_waves;
     if (c->t_skinny_p >= 0) t.skinny_p = c->t_skinny_p;
     if (c->t_body_tile >= 0) t.body_tile = c->t_body_tile;
+    if (c->t_co_kmax >= 0) t.co_kmax = c->t_co_kmax;
+    if (c->t_tail_slices >= 0) t.tail_slices = c->t_tail_slices;
+    if (c->t_lead_key >= 0) t.lead_key = c->t_lead_key;
+    if (c->t_decode_fused >= 0) t.decode_fused = c->t_decode_fused;
+    if (c->t_decode_fp8 >= 0) t.decode_fp8 = c->t_decode_fp8;
+    if (c->t_skinny_p8 >= 0) t.skinny_p8 = c->t_skinny_p8;
   }
   return t;
 }
@@ -344,6 +360,18 @@ int launch_one(aigv_ctx* c, const GemmArgs& a, int epi, bool use256, hipStream_t
   return 0;
 }
 
+// the co-resident 256x128 kernel (gemmco.hip): every row in full K, ragged row counts and half-tile tables included
+int launch_co(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
+  GEMM_PROF(c, a, s);
+  HIPCHK(c, aigv_launch_gemmco(tuned(c, a), epi, s));
+  return 0;
+}
+// does this GEMM run on the co-resident kernel?  A function of the mode and of K only.
+bool use_co(const aigv_ctx* c, const GemmArgs& a, int mode) {
+  if (!aigv_gemmco_supported(a)) return false;
+  return mode == 4 || ((mode == 0 || mode == 3) && a.K <= tune_of(c).co_kmax);
+}
+
 int launch_splitk(aigv_ctx* c, const GemmArgs& a, int epi, int S, bool tile256, hipStream_t s) {
   float* ws = nullptr;
   TRY(splitk_scratch(c, (size_t)S * a.M * a.N, &ws));
@@ -438,7 +466,8 @@ GemmArgs col_slice(const GemmArgs& a, int n0, int n) {
 
 int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
-  const int mode = resolved_gemm_mode(c) == 3 ? 0 : resolved_gemm_mode(c);
+  if (use_co(c, a, resolved_gemm_mode(c))) return launch_co(c, a, epi, s);
+  const int mode = resolved_gemm_mode(c) == 3 || resolved_gemm_mode(c) == 4 ? 0 : resolved_gemm_mode(c);
   if (const int right = split_columns(a.M, a.N, a.K, epi, mode)) {
     TRY(run_gemm(c, col_slice(a, 0, a.N - right), epi, s));
     return launch_one(c, col_slice(a, a.N - right, right), epi, false, s);
@@ -508,15 +537,16 @@ int build_row_plan(aigv_ctx* c, RowPlan& rp, const int32_t* cu, int n_seq, hipSt
   return 0;
 }
 
-// Split-K factor of the TAIL half tiles of a GEMM: a function of (N, K) only - never of the batch - sized so that two tail row tiles
-// (four clips' 128-row remainders, the benched batch) come to about one round of 256 workgroups.  1 = the tail rides in the body's launch.
-int tail_slices(int N, int K) {
-  static const char* env = getenv("AIGV_TAIL_SLICES");   // A/B knob: one factor for every shape it divides
+// Split-K factor of the TAIL half tiles of a GEMM: a function of (N, K) only - never of the batch or of the number of clips: the largest
+// S in {2, 4, 8} that leaves every slice >= 8 K-tiles and keeps ONE tail row tile's slices (N / 256 x S workgroups) within half a round of
+// the chip (two tail row tiles - four clips' 128-row remainders - then come to about one round; eight clips to two).  1 = the tail rides in
+// the body's launch.  `forced` > 0 (AIGV_TUNE_TAIL_SLICES, experiments): one factor for every shape it divides.
+int tail_slices(int N, int K, int forced) {
   const int tn = N / 256, nk = K / 64;
   int best = 1;
   for (int S : {2, 4, 8})
     if (nk % S == 0 && nk / S >= 8 && 2 * tn * S <= 256) best = S;
-  if (env) { const int v = atoi(env); if (v == 1 || (v > 1 && nk % v == 0 && nk / v >= 4)) best = v; }
+  if (forced == 1 || (forced > 1 && nk % forced == 0 && nk / forced >= 4)) best = forced;
   return best;
 }
 
@@ -536,12 +566,26 @@ int launch_tab(aigv_ctx* c, const GemmArgs& a, int epi, const int32_t* tab, int 
   return 0;
 }
 
-// A GEMM whose rows follow the row plan `rp` (mode 0); modes 1 / 2 run every row on one tile kernel in full K (also batch-invariant).
+int run_tiny_tails(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hipStream_t s);
+
+// A GEMM whose rows follow the row plan `rp` (mode 0); modes 1 / 2 / 4 run every row on one tile kernel in full K (also batch-invariant).
 int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
   if (a.M != rp.rows) return fail(c, AIGV_ERR_STATE, "row plan covers %d rows, the GEMM has %d", rp.rows, a.M);
   const int mode = resolved_gemm_mode(c);
   if (mode == 3) return run_gemm(c, a, epi, s);   // rounds 1-3: batch-level cost-model dispatch (A/B only: not batch-invariant)
+  if (mode == 4) return use_co(c, a, mode) ? launch_co(c, a, epi, s) : launch_one(c, a, epi, false, s);
+  if (use_co(c, a, mode)) {
+    // short-K GEMMs (InternViT): body AND tail half tiles in one launch of the co-resident kernel, full K; tiny tails on the skinny kernel as below
+    if (rp.body_halves + rp.tail_halves > 0) {
+      GemmArgs b = a;
+      b.row_tab = rp.d_tab; b.tab_halves = rp.body_halves + rp.tail_halves;
+      GemmArgs pf = a; pf.M = rp.body_halves * 128 + rp.tail_rows;
+      GEMM_PROF(c, pf, s);
+      HIPCHK(c, aigv_launch_gemmco(tuned(c, b), epi, s));
+    }
+    return run_tiny_tails(c, a, epi, rp, s);
+  }
   if (mode == 1 || a.N < 256) return launch_one(c, a, epi, false, s);
   if (mode == 2 && a.N % 256 == 0) return launch_one(c, a, epi, true, s);
   if (a.N % 256) {   // N = 256 j + 128 (InternViT-6B: 3200, 9600): the last 128 columns of every row on the 128 kernel, full K
@@ -549,7 +593,7 @@ int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hi
     TRY(run_gemm_rows(c, col_slice(a, 0, a.N - 128), epi, rp, s));
     return launch_one(c, col_slice(a, a.N - 128, 128), epi, false, s);
   }
-  const int S = tail_slices(a.N, a.K);
+  const int S = tail_slices(a.N, a.K, tune_of(c).tail_slices);
   // The body rows may run on either tile kernel: both sum every output element over the full K in the same order, so not one bit moves
   // (tests/test_gpu_ops.py pins that).  Shipped: always the 256 tiles - for one clip, whose wo / w2 / ViT proj / fc2 bodies are only 128
   // tiles, the 128 kernel (512 tiles, two per CU) was expected to win by the cost model and measured 1-3 % slower per clip
@@ -580,6 +624,11 @@ int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hi
       TRY(launch_tab(c, a, epi, rp.d_tab + 2 * (rp.body_halves + h0), nh, nh * 128, S, s));   // (profile: ragged halves counted as full)
     }
   }
+  return run_tiny_tails(c, a, epi, rp, s);
+}
+
+// tails of <= TINY_TAIL rows (InternViT: 1025 = 4 * 256 + 1) on the weight-streaming skinny kernel in its fixed 4-slice form
+int run_tiny_tails(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hipStream_t s) {
   const int sk = skinny_epi(epi);
   for (const RowPlan::Tiny& t : rp.tiny) {
     if (sk < 0 || a.K % 128) return fail(c, AIGV_ERR_STATE, "no skinny form for epilogue %d / K=%d (tiny sequence tails)", epi, a.K);
@@ -601,6 +650,7 @@ int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hi
 int run_gemm_full(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
   if (const char* m = aigv_gemm_check(a, epi)) return fail(c, AIGV_ERR_ARG, "%s (M=%d N=%d K=%d epi=%d)", m, a.M, a.N, a.K, epi);
   const int mode = resolved_gemm_mode(c);
+  if (use_co(c, a, mode)) return launch_co(c, a, epi, s);
   if (mode == 1 || a.N < 256 || (a.N % 256 && epi == EPI_SWIGLU)) return launch_one(c, a, epi, false, s);
   if (a.N % 256) {
     TRY(launch_one(c, col_slice(a, 0, a.N - 128), epi, true, s));
@@ -742,6 +792,7 @@ static int alloc_workspaces(aigv_ctx* c) {
     if ((rc = dalloc(c, &c->l_seq, T))) break;
     if ((rc = dalloc(c, &c->l_cu, (size_t)k.max_seqs + 1))) break;
     if ((rc = dalloc(c, &c->l_rowidx, (size_t)k.max_out_rows + k.max_seqs + 64))) break;
+    if ((rc = dalloc(c, &c->l_rowidx2, (size_t)k.max_out_rows + k.max_seqs + 64))) break;
     if ((rc = dalloc(c, &c->l_kvlen, (size_t)k.max_seqs))) break;
     if ((rc = dalloc(c, &c->l_packed, (size_t)64))) break;
     if ((rc = dalloc(c, &c->l_trim, (size_t)64 * (2 * k.llm_hidden + k.llm_inter)))) break;
@@ -1137,7 +1188,7 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
         a.n_heads = a.n_kv_heads = k.vit_heads;
         a.q_group_stride = a.kv_head_stride = c->vit_head_dim;
         a.causal = 0; a.post_div = 1.0f; a.q_prescale = 1.0f / sqrtf((float)c->vit_head_dim);
-        a.round_scores = c->attn_round_scores; a.waves = tune_of(c).attn_waves; a.waves = tune_of(c).attn_waves;
+        a.round_scores = c->attn_round_scores; a.waves = tune_of(c).attn_waves; a.lead_key = tune_of(c).lead_key;
         a.uniform_len = 1;
         if (const char* m = aigv_attn_check(a, c->vit_head_dim)) return fail(c, AIGV_ERR_ARG, "%s", m);
         ProfScope ps(c, AIGV_PROF_ATTN_VIT, 4.0 * F * (double)c->S * c->S * Hv, 2.0 * 4 * rows * (double)Hv, s);
@@ -1345,8 +1396,27 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
     while (cu[b + 1] <= v) ++b;
     q_tail = std::max(q_tail, cu[b + 1] - v);
   }
-  // (the rule is per clip - at most 16 consumed rows per clip on average - so a clip takes the same path whatever its batch)
-  const bool trim = c->trim_last_layer && n_out > 0 && n_out <= 16 * B && H % 128 == 0 && I % 128 == 0;
+  // The rule is PER CLIP, so that a clip's consumed rows take the same kernels whatever its batch mates are: the consumed rows of a clip
+  // with at most TRIM_ROWS of them finish on the weight-streaming kernel (its fixed form), those of a clip with more on the tile kernels
+  // with all the other rows.  All clips small (the eval scripts' case): `trim` - the last layer runs for the consumed rows only.  Mixed
+  // batch: the last layer runs for every row AND the small clips' consumed rows are finished on the streaming path and put back in place.
+  constexpr int TRIM_ROWS = 16;
+  std::vector<int32_t> small_rows;
+  {
+    std::vector<int> per_clip(B, 0), clip_of(c->h_rowidx.size());
+    for (size_t i = 0; i < c->h_rowidx.size(); ++i) {
+      int b = 0;
+      while (cu[b + 1] <= c->h_rowidx[i]) ++b;
+      clip_of[i] = b;
+      ++per_clip[b];
+    }
+    for (size_t i = 0; i < c->h_rowidx.size(); ++i)
+      if (per_clip[clip_of[i]] <= TRIM_ROWS) small_rows.push_back(c->h_rowidx[i]);
+  }
+  const bool trim_ok = c->trim_last_layer && n_out > 0 && H % 128 == 0 && I % 128 == 0;
+  const bool trim = trim_ok && (int)small_rows.size() == n_out;
+  const bool mixed = trim_ok && !trim && !small_rows.empty();
+  if (mixed) HIPCHK(c, aigv_launch_write_ints(small_rows.data(), (int)small_rows.size(), c->l_rowidx2, s));
   double attn_flops = 0;
   for (int b = 0; b < B; ++b) { const double L = cu[b + 1] - cu[b]; attn_flops += 4.0 * (L * (L + 1) / 2) * D * k.llm_heads; }
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
@@ -1376,21 +1446,28 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
       ProfScope ps(c, AIGV_PROF_ATTN_LLM, last_trim ? 0.0 : attn_flops, 2.0 * T * ((double)c->qkv_out + H), s);
       HIPCHK(c, aigv_launch_attention(a, D, s));
     }
-    if (trim && li == k.llm_layers - 1) {
+    if ((trim || mixed) && li == k.llm_layers - 1) {
       // 64 rows at a time through the weight-streaming kernel in its fixed 4-slice form (p = 0: the same bits whatever the row count);
-      // the finished rows collect in l_trim_h, in l_rowidx order
+      // the finished rows collect in l_trim_h, in l_rowidx (mixed: l_rowidx2) order
+      const int32_t* idx = trim ? c->l_rowidx : c->l_rowidx2;
+      const int n_fin = trim ? n_out : (int)small_rows.size();
       bf16_t *t_ao = c->l_trim, *t_n = t_ao + (size_t)64 * H, *t_ffn = t_n + (size_t)64 * H, *t_h = c->l_trim_h;
-      for (int r0 = 0; r0 < n_out; r0 += 64) {
-        const int nr = std::min(64, n_out - r0);
+      for (int r0 = 0; r0 < n_fin; r0 += 64) {
+        const int nr = std::min(64, n_fin - r0);
         bf16_t* h = t_h + (size_t)r0 * H;
-        HIPCHK(c, aigv_launch_gather_rows(c->l_ao, H, c->l_rowidx + r0, nr, t_ao, H, s));
-        HIPCHK(c, aigv_launch_gather_rows(c->l_h, H, c->l_rowidx + r0, nr, h, H, s));
+        HIPCHK(c, aigv_launch_gather_rows(c->l_ao, H, idx + r0, nr, t_ao, H, s));
+        HIPCHK(c, aigv_launch_gather_rows(c->l_h, H, idx + r0, nr, h, H, s));
         TRY(run_skinny(c, t_ao, H, nr, L.wo, H, H, H, nullptr, h, H, h, H, 1, s, 0));
         HIPCHK(c, aigv_launch_rmsnorm(h, H, L.fn, t_n, H, nr, H, k.rms_eps, nullptr, s));
         TRY(run_skinny(c, t_n, H, nr, L.w13, H, 2 * I, H, nullptr, nullptr, 0, t_ffn, I, 2, s, 0));
         TRY(run_skinny(c, t_ffn, I, nr, L.w2, I, H, I, nullptr, h, H, h, H, 1, s, 0));
       }
-      TRY(final_rows(c, score, B, R, argmax, t_h, true, s));
+      if (trim) {
+        TRY(final_rows(c, score, B, R, argmax, t_h, true, s));
+        break;
+      }
+      TRY(llm_layer_post(c, li, T, s));                                                          // every row on the tile kernels ...
+      HIPCHK(c, aigv_launch_scatter_rows(t_h, c->l_rowidx2, n_fin, c->l_h, H, H, s));            // ... the small clips' consumed rows put back
       break;
     }
     TRY(llm_layer_post(c, li, T, s));
@@ -1615,17 +1692,35 @@ int aigv_ctx_tune(aigv_ctx* c, int knob, int value) {
       if (value < -1 || value > 15) break;
       c->t_order = value; return 0;
     case AIGV_TUNE_GEMM256_VARIANT:
-      if (value < -1 || value > 4) break;
+      if (value < -1 || value > 6) break;
       c->t_variant = value; return 0;
     case AIGV_TUNE_ATTN_WAVES:
       if (value != -1 && value != 0 && value != 4 && value != 8) break;
       c->t_attn_waves = value; return 0;
     case AIGV_TUNE_SKINNY_P:
-      if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4) break;
+      if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && !(value >= 1000 && value < 1000 + 4096)) break;
       c->t_skinny_p = value; return 0;
     case AIGV_TUNE_BODY_TILE:
       if (value < -1 || value > 2) break;
       c->t_body_tile = value; return 0;
+    case AIGV_TUNE_CO_KMAX:
+      if (value < -1 || value > 65536 || (value > 0 && value % 64)) break;
+      c->t_co_kmax = value; return 0;
+    case AIGV_TUNE_TAIL_SLICES:
+      if (value < -1 || value > 16) break;
+      c->t_tail_slices = value; return 0;
+    case AIGV_TUNE_ATTN_LEAD_KEY:
+      if (value < -1 || value > 1) break;
+      c->t_lead_key = value; return 0;
+    case AIGV_TUNE_DECODE_FUSED:
+      if (value < -1 || value > 1) break;
+      c->t_decode_fused = value; return 0;
+    case AIGV_TUNE_DECODE_FP8:
+      if (value < -1 || value > 1) break;
+      c->t_decode_fp8 = value; return 0;
+    case AIGV_TUNE_SKINNY_P8:
+      if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4) break;
+      c->t_skinny_p8 = value; return 0;
     default: return fail(c, AIGV_ERR_ARG, "aigv_ctx_tune: unknown knob %d", knob);
   }
   return fail(c, AIGV_ERR_ARG, "aigv_ctx_tune: value %d out of range for knob %d", value, knob);
@@ -1640,7 +1735,7 @@ int aigv_set_attention_numerics(aigv_ctx* c, int mode) {
 
 int aigv_set_gemm_mode(aigv_ctx* c, int mode) {
   if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_gemm_mode: null context");
-  if (mode < -1 || mode > 3) return fail(c, AIGV_ERR_ARG, "aigv_set_gemm_mode: mode must be -1 (process default), 0 (row plans), 1 (128 tile), 2 (256 tile) or 3 (batch-level dispatch)");
+  if (mode < -1 || mode > 4) return fail(c, AIGV_ERR_ARG, "aigv_set_gemm_mode: mode must be -1 (process default), 0 (row plans), 1 (128 tile), 2 (256 tile), 3 (batch-level dispatch) or 4 (co-resident 256x128 tile)");
   c->gemm_mode = mode;
   return 0;
 }
@@ -1668,14 +1763,16 @@ static void decode_forms(aigv_ctx* c, int B, int* pq, int* po, int* p13, int* p2
   }
   *pq = *po = *p13 = pick_form(max_p, k.llm_hidden);
   *p2 = pick_form(max_p, k.llm_inter);
-  if (const int sp = tune_of(c).skinny_p) *pq = *po = *p13 = *p2 = std::min(sp, max_p);
-  static const char* env = getenv("AIGV_DECODE_P");
-  if (env) {
-    int v[4];
-    if (sscanf(env, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) {
+  // AIGV_TUNE_SKINNY_P (experiments): one value for all four, or - value = 1000 + a packed "wqkv, wo, w1|w3, w2" word with 3 bits each
+  // (1 / 2 / 4) - one per GEMV (scripts/decode_bench.py; the sweep of profiles/r2_decode_forms.txt)
+  if (const int sp = tune_of(c).skinny_p) {
+    if (sp < 1000) *pq = *po = *p13 = *p2 = std::min(sp, max_p);
+    else {
       int* out[4] = {pq, po, p13, p2};
-      for (int i = 0; i < 4; ++i)
-        if ((v[i] == 1 || v[i] == 2 || v[i] == 4) && v[i] <= max_p) *out[i] = v[i];
+      for (int i = 0; i < 4; ++i) {
+        const int v = ((sp - 1000) >> (3 * i)) & 7;
+        if ((v == 1 || v == 2 || v == 4) && v <= max_p) *out[i] = v;
+      }
     }
   }
 }
@@ -1698,25 +1795,21 @@ int aigv_decode_step(aigv_ctx* c, const int64_t* ids, int64_t* next, void* strea
   HIPCHK(c, aigv_launch_embed(ids, c->dec_slot, c->tok_emb, nullptr, nullptr, 0, c->l_h, B, H, s));
   const size_t kv_layer = (size_t)k.max_seqs * nkv * k.kv_capacity * D;
   // Up to 4 sequences: attention_norm / ffn_norm are applied by the GEMV that consumes them (NormArgs in head.hip; same bits), 6
-  // launches per layer instead of 8.  AIGV_DECODE_FUSED=0 keeps the separate norm kernels (A/B).
-  static const bool fused_env = getenv("AIGV_DECODE_FUSED") ? atoi(getenv("AIGV_DECODE_FUSED")) != 0 : true;
-  const bool fused = fused_env && B <= 4 && aigv_skinny_norm_fusable(H);
+  // launches per layer instead of 8.  AIGV_TUNE_DECODE_FUSED = 0 keeps the separate norm kernels (A/B).
+  const Tune tn_ = tune_of(c);
+  const bool fused = tn_.decode_fused != 0 && B <= 4 && aigv_skinny_norm_fusable(H);
   // sub-slab forms of the four GEMVs (skinny_kernel's P; head.hip): chosen so that the workgroups come to a whole number per CU.
-  // AIGV_DECODE_P="wqkv,wo,w13,w2" overrides (A/B); aigv_tune_skinny forces one value everywhere it is legal.
+  // AIGV_TUNE_SKINNY_P / aigv_tune_skinny force one value everywhere it is legal (or one per GEMV: decode_forms).
   int pq, po, p13, p2;
   decode_forms(c, B, &pq, &po, &p13, &p2);
   // fp8 mode: the linears the prefill runs in e4m3 stream their e4m3 copies here too (head8.hip: half the bytes per token; the
   // x rows are normalised and quantised by the GEMV itself) - up to 4 sequences and for the widths the kernel is built for; larger
-  // batches decode from the bf16 weights.  AIGV_DECODE_FP8=0 keeps the bf16 GEMVs (A/B).  AIGV_DECODE_P8 = forms, as AIGV_DECODE_P.
-  static const bool f8_env = getenv("AIGV_DECODE_FP8") ? atoi(getenv("AIGV_DECODE_FP8")) != 0 : true;
-  const bool f8 = f8_env && c->fp8_llm && B <= 4 && aigv_skinny_fp8_supported(H, true) && aigv_skinny_fp8_supported(I, false) && D == 128;
+  // batches decode from the bf16 weights.  AIGV_TUNE_DECODE_FP8 = 0 keeps the bf16 GEMVs (A/B); AIGV_TUNE_SKINNY_P8 = one form for all four.
+  const bool f8 = tn_.decode_fp8 != 0 && c->fp8_llm && B <= 4 && aigv_skinny_fp8_supported(H, true) && aigv_skinny_fp8_supported(I, false) && D == 128;
   int q8[4] = {4, 2, 4, 2};
   {
-    static const char* env8 = getenv("AIGV_DECODE_P8");
-    int v[4];
-    if (env8 && sscanf(env8, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
-      for (int i = 0; i < 4; ++i)
-        if (v[i] == 1 || v[i] == 2 || v[i] == 4) q8[i] = v[i];
+    if (const int v = tn_.skinny_p8)
+      for (int i = 0; i < 4; ++i) q8[i] = v;
     if (I / (4 * q8[3]) < 256 || I % (512 * q8[3])) q8[3] = 1;
   }
   for (int li = 0; li < k.llm_layers; ++li) {
@@ -2035,11 +2128,17 @@ int aigv_tune_gemm(int mode, double rate256) {
   mode &= 1023;
   const int vsel = mode >> 4;
   mode &= 15;
-  if (mode < 0 || mode > 3 || vsel < 0 || vsel > 4)
-    return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_gemm: mode must be 0 (auto), 1 (128 tile), 2 (256 tile) or 3 (batch-level dispatch in the scoring pass)");
+  if (mode < 0 || mode > 4 || vsel < 0 || vsel > 6)
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_gemm: mode must be 0 (auto), 1 (128 tile), 2 (256 tile), 3 (batch-level dispatch in the scoring pass) or 4 (co-resident 256x128 tile)");
   if (vsel > 0) g_tune.variant_sel = vsel;
   g_tune.gemm_mode = mode;
   if (rate256 > 0) g_rate256 = rate256;
+  return 0;
+}
+
+int aigv_tune_co_gemm(int kmax) {
+  if (kmax < 0 || kmax > 65536 || kmax % 64) return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_co_gemm: K threshold must be 0 (off) or a multiple of 64");
+  g_tune.co_kmax = kmax;
   return 0;
 }
 

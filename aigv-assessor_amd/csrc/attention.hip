@@ -814,8 +814,6 @@ static hipError_t launch_attention32(const AttnArgs& a, int head_dim, hipStream_
 // profiles/r3_attn8_negative.txt).  aigv_tune_attention: 4 / 8 waves per workgroup (A/B only).
 hipError_t aigv_launch_attention(const AttnArgs& a_in, int head_dim, hipStream_t s) {
   AttnArgs a = a_in;
-  static const bool env_lead = getenv("AIGV_LEAD_KEY") != nullptr;   // A/B knob (bench runs): the lead-key form for 64 j + 1 keys
-  if (env_lead) a.lead_key = 1;
   {
     // A power-of-two query pre-scale (InternViT: d^-1/2 = 2^-3) commutes exactly with the bf16 rounding of q and with the fp32 dot
     // products, so it is folded into the softmax's exp2 scale instead of being applied to every query element: the same bits

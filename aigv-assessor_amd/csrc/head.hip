@@ -397,21 +397,15 @@ hipError_t launch_skinny(const bf16_t* x, int ldx, int R, const bf16_t* W, int l
   }
   const int ns = (EPI == SK_SWIGLU) ? 2 : (EPI == SK_ARGMAX && rt >= 2) ? 4 : 1;   // = NS of the kernel
   const int blocks = (N + 16 * ns - 1) / (16 * ns);
-  // A/B knob (scripts/decode_gemv_bench.py).  Measured on the 8B decode shapes: non-temporal weight loads are SLOWER here
-  // (wqkv 12.5 -> 14.8 us, w2 24.9 -> 29.9 us, w1|w3 47.9 -> 54.9 us), so the default stays the plain cache policy.
-  static const bool nt = getenv("AIGV_SKINNY_NT") ? atoi(getenv("AIGV_SKINNY_NT")) != 0 : false;
+  // (non-temporal weight loads were measured SLOWER on the 8B decode shapes - wqkv 12.5 -> 14.8 us, w2 24.9 -> 29.9 us, w1|w3 47.9 -> 54.9 us -
+  //  and the form was removed: plain cache policy everywhere)
 #define GO(RT) hipLaunchKernelGGL((skinny_kernel<RT, EPI>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls)
   if constexpr (EPI == SK_STORE || EPI == SK_RESID) {
-    static const int max8 = getenv("AIGV_SKINNY8_MAX_BLOCKS") ? atoi(getenv("AIGV_SKINNY8_MAX_BLOCKS")) : 256;   // A/B knob (scripts/decode_gemv_bench.py)
+    constexpr int max8 = 256;   // at most one slab per CU
     if (rt == 1 && K % 256 == 0 && blocks <= max8 && p != 0) {   // a decode GEMV with about one slab per CU: 8 K slices per workgroup (p == 0: the caller wants ONE form for every row count)
-      if (nt) hipLaunchKernelGGL((skinny_kernel<1, EPI, 8, true>), dim3(blocks), dim3(512), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
-      else hipLaunchKernelGGL((skinny_kernel<1, EPI, 8>), dim3(blocks), dim3(512), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
+      hipLaunchKernelGGL((skinny_kernel<1, EPI, 8>), dim3(blocks), dim3(512), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
       return hipGetLastError();
     }
-  }
-  if (rt == 1 && nt) {   // the decode GEMVs and other one-tile weight streams
-    hipLaunchKernelGGL((skinny_kernel<1, EPI, 4, true>), dim3(blocks), dim3(256), 0, s, x, ldx, R, W, ldw, N, K, bias, resid, ldr, out, ldo, packed, ls);
-    return hipGetLastError();
   }
   switch (rt) {
     case 1: GO(1); break;

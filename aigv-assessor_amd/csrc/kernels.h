@@ -62,6 +62,9 @@ hipError_t aigv_launch_rmsnorm_quant_fp8(const bf16_t* x, int ldx, const bf16_t*
 hipError_t aigv_launch_quant_fp8_rows(const bf16_t* x, int ldx, int rows, int K, uint8_t* q, int ldq, float* scale, hipStream_t s);
 bool aigv_gemm256_supported(const GemmArgs& a);
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);        // 256x256 phase-interleaved kernel
+// 256x128 tile, four waves, two co-resident workgroups per CU (gemmco.hip): same bits as the 256 kernel; takes the half-tile table too
+bool aigv_gemmco_supported(const GemmArgs& a);
+hipError_t aigv_launch_gemmco(const GemmArgs& a, int epi, hipStream_t s);
 
 // ---- attention ------------------------------------------------------------------------------------
 // Packed varlen layout: sequence s occupies rows cu[s] .. cu[s+1]-1 of the token-major buffers.
@@ -120,6 +123,7 @@ hipError_t aigv_launch_pixel_shuffle(const bf16_t* vit, int grid, int Hv, bf16_t
 hipError_t aigv_launch_im2col(const bf16_t* frames, int F, int C, int S, int P, int Kp, bf16_t* out, hipStream_t s);
 // x[f*(np+1)] = cls_pos (class token + its position row, precomputed) for every frame
 hipError_t aigv_launch_gather_rows(const bf16_t* src, int ld, const int32_t* idx, int n, bf16_t* dst, int H, hipStream_t s);
+hipError_t aigv_launch_scatter_rows(const bf16_t* src, const int32_t* idx, int n, bf16_t* dst, int ld, int H, hipStream_t s);   // dst[idx[i]] = src[i]
 hipError_t aigv_launch_cls_rows(const bf16_t* cls_pos, bf16_t* x, int F, int tokens_per_frame, int H, hipStream_t s);
 // RoPE in place on the fused qkv rows: per kv group, slots 0..g (q heads and K) are rotated.
 // slots [first_rot, first_rot + n_rot) of every group are rotated in place (q heads + K: first_rot 0, n_rot g + 1; K only: g, 1)

@@ -224,6 +224,13 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ src, int ld, const
   for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x) *(u16x8*)(dst + (size_t)i * H + (c << 3)) = *(const u16x8*)(row + (c << 3));
 }
 
+// dst[idx[i], :] = src[i, :]  (the inverse: finished rows back to their places; duplicate indices carry identical rows)
+__global__ void scatter_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ idx, bf16_t* __restrict__ dst, int ld, int H) {
+  const int i = blockIdx.x;
+  bf16_t* row = dst + (size_t)idx[i] * ld;
+  for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x) *(u16x8*)(row + (c << 3)) = *(const u16x8*)(src + (size_t)i * H + (c << 3));
+}
+
 // ---- RoPE in place (modeling_internlm2.py:247-261): out = bf16(bf16(x*cos) + bf16(rot(x)*sin)) ---------
 // qkv row layout: n_groups x slots_per_group x D; slots [0, n_rot) of every group are rotated (q heads + K).
 // cos/sin tables are [max_pos, D/2] bf16 (the second half of the reference's table repeats the first).
@@ -522,6 +529,13 @@ hipError_t aigv_launch_gather_rows(const bf16_t* src, int ld, const int32_t* idx
   if (n <= 0) return hipSuccess;
   if (H % 8 || ld % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, s, src, ld, idx, dst, H);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_scatter_rows(const bf16_t* src, const int32_t* idx, int n, bf16_t* dst, int ld, int H, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (H % 8 || ld % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(256), 0, s, src, idx, dst, ld, H);
   return hipGetLastError();
 }
 

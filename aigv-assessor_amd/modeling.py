@@ -291,26 +291,47 @@ class InternVLChatModel(nn.Module):
             raise RuntimeError("load_state_dict: Llama tensor names in a checkpoint for an InternLM2 configuration")
         return weights.llama_to_internlm2(sd, self.config.llm_config)
 
-    def load_state_dict_stream(self, named_tensors):
+    def load_state_dict_stream(self, named_tensors, strict: bool = True):
         """load_state_dict from an iterable of (name, tensor) without ever holding the whole state dict on the host (InternVL2-26B: 51 GB):
-        every tensor is copied into its parameter as it arrives.  Names the model does not own raise; returns the names never seen."""
+        every tensor is copied into its parameter as it arrives.  The same contract as load_state_dict: InternLM2-layout names always load,
+        transformers-Llama names are re-packed on the fly (Llama configurations only), ``slowfast_model.*`` tensors build the motion branch,
+        names the model does not own raise, and so do missing tensors unless ``strict=False`` (then their names are returned).  Whatever
+        happens, the native copy of the weights is invalidated - a failed stream never leaves it silently out of step with the module."""
+        from .weights import llama_stream_to_internlm2
         own = dict(self.named_parameters())
         seen = set()
-        if self.llm_arch_name == "LlamaForCausalLM":
-            from .weights import llama_stream_to_internlm2
-            named_tensors = llama_stream_to_internlm2(named_tensors, self.config.llm_config)
-        with torch.no_grad():
+        slowfast = {}
+
+        def routed():
             for k, v in named_tensors:
-                if self.stage == 1 and k.startswith("mlpscore."):
+                if k.startswith("slowfast_model."):
+                    slowfast[k] = v
                     continue
-                if k not in own:
-                    raise RuntimeError(f"load_state_dict_stream: unexpected tensor {k}")
-                if tuple(v.shape) != tuple(own[k].shape):
-                    raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(own[k].shape)}")
-                own[k].copy_(v.to(own[k].dtype))
-                seen.add(k)
-        self._invalidate()
-        return [k for k in own if k not in seen]
+                yield k, v
+
+        stream = routed()
+        if self.llm_arch_name == "LlamaForCausalLM":
+            stream = llama_stream_to_internlm2(stream, self.config.llm_config)     # (InternLM2-layout names pass through unchanged)
+        try:
+            with torch.no_grad():
+                for k, v in stream:
+                    if self.stage == 1 and k.startswith("mlpscore."):
+                        continue
+                    if k not in own:
+                        raise RuntimeError(f"load_state_dict_stream: unexpected tensor {k}")
+                    if tuple(v.shape) != tuple(own[k].shape):
+                        raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(own[k].shape)}")
+                    own[k].copy_(v.to(own[k].dtype))
+                    seen.add(k)
+            if slowfast:
+                from .slowfast import SlowFastR50
+                self.slowfast_model = SlowFastR50(slowfast)
+        finally:
+            self._invalidate()
+        missing = [k for k in own if k not in seen]
+        if strict and missing:
+            raise RuntimeError(f"load_state_dict_stream: missing {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        return missing
 
     def _apply(self, fn, *a, **k):  # .cuda() / .to(): weights move, the native copy must follow
         out = super()._apply(fn, *a, **k)
@@ -1189,7 +1210,8 @@ class InternVLChatModel(nn.Module):
         lib, ctx = self._native()
         native.check(lib.aigv_set_gemm_mode(ctx, int(mode)), ctx)
 
-    TUNE_KNOBS = {"gemm_mode": 0, "gemm256_order": 1, "gemm256_variant": 2, "attn_waves": 3, "skinny_p": 4, "body_tile": 5}
+    TUNE_KNOBS = {"gemm_mode": 0, "gemm256_order": 1, "gemm256_variant": 2, "attn_waves": 3, "skinny_p": 4, "body_tile": 5, "co_kmax": 6,
+                  "tail_slices": 7, "attn_lead_key": 8, "decode_fused": 9, "decode_fp8": 10, "skinny_p8": 11}
 
     def tune(self, knob: str, value: int = -1):
         """Experiment knobs of THIS model's context (aigv_ctx_tune; -1 = follow the process default): tests and A/B runs only."""

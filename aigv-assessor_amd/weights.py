@@ -148,6 +148,10 @@ def llama_stream_to_internlm2(named_tensors, llm_cfg):
     pending: Dict[int, Dict[str, torch.Tensor]] = {}
     for k, v in named_tensors:
         m = _LLAMA_LAYER.match(k)
+        if k in ("language_model.model.tok_embeddings.weight", "language_model.output.weight") or (
+                m and m.group(2).split(".")[0] in ("attention", "feed_forward", "attention_norm", "ffn_norm")):
+            yield k, v      # already InternLM2 layout (what load_state_dict accepts too)
+            continue
         if m and m.group(2) in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight"):
             i = int(m.group(1))
             pending.setdefault(i, {})[k] = v

@@ -338,10 +338,15 @@ def spawn_ranks(n):
     failure ends the others."""
     import socket
     import subprocess
+    # the rendezvous port: a free one picked by the kernel.  The socket is closed before the ranks bind it (torch's TCPStore has no way to
+    # adopt an open socket): a small window in which another process could take it - rank 0 then fails to listen, exits non-zero, and the
+    # loop below ends the others instead of hanging.
     so = socket.socket()
+    so.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     so.bind(("127.0.0.1", 0))
     port = so.getsockname()[1]
     so.close()
+    deadline = time.time() + float(os.environ.get("AIGV_BENCH_DEADLINE_S", "3000"))   # the whole job; a hung collective must not hang the launcher
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -350,6 +355,7 @@ def spawn_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     live = set(range(n))
+    kill_at = None          # after a failure: SIGTERM at once, SIGKILL ten seconds later (a rank inside an RCCL collective whose peer died ignores SIGTERM)
     while live:
         for r in sorted(live):
             code = procs[r].poll()
@@ -361,6 +367,17 @@ def spawn_ranks(n):
                 print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
                 for o in live:
                     procs[o].terminate()
+                kill_at = time.time() + 10.0
+        if rc == 0 and live and time.time() > deadline:
+            rc = 124
+            print(f"bench.py: ranks {sorted(live)} still running at the deadline; stopping them", file=sys.stderr)
+            for o in live:
+                procs[o].terminate()
+            kill_at = time.time() + 10.0
+        if kill_at is not None and live and time.time() > kill_at:
+            for o in live:
+                procs[o].kill()      # the exact child PIDs this function started
+            kill_at = None
         time.sleep(0.2)
     return rc
 
@@ -415,6 +432,7 @@ def main():
     ap.add_argument("--attn-kernel", type=int, default=0, choices=[0, 4, 8],
                     help="A/B: force one form of the prefill-attention kernel (aigv_tune_attention): 4 / 8 waves per workgroup; 0 = default")
     ap.add_argument("--tune-gemm", type=int, default=0, help="A/B: aigv_tune_gemm mode word (kernel choice + 16 * (1 + 256-kernel schedule variant))")
+    ap.add_argument("--co-kmax", type=int, default=-1, help="A/B: largest K the co-resident 256x128 GEMM kernel takes (aigv_tune_co_gemm); 0 = never, -1 = the library default")
     ap.add_argument("--serial-motion", action="store_true", help="A/B: run the SlowFast branch on the launch stream in front of the ViT instead of on a side stream beside it")
     ap.add_argument("--attn-numerics", default="reference", choices=["reference", "fp32"],
                     help="prefill attention: 'reference' rounds the score matrix to bf16 where the reference's eager path does (default); 'fp32' keeps fp32 scores (A/B)")
@@ -422,6 +440,8 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
     ap.add_argument("--no-parity", action="store_true", help="skip the score / level comparison with the reference's recorded outputs (tests/golden/e2e_8b_r3.pt; ~1.5 min of CPU weight generation)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse the multi-process control flow on gloo / CPU with a stand-in model (no measurement)")
+    ap.add_argument("--dry-run-fault", default="", choices=["", "stuck-peer"],
+                    help="with --dry-run-cpu only (tests): 'stuck-peer' = rank 1 exits with code 3 and rank 0 ignores SIGTERM and sleeps, the state of a rank inside a collective whose peer died")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -432,6 +452,13 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     dry = args.dry_run_cpu
+    if args.dry_run_fault == "stuck-peer" and dry and world > 1:
+        if rank == 1:
+            raise SystemExit(3)
+        import signal
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        time.sleep(300)
+        raise SystemExit(0)
     if args.ingest and world > 1:
         raise SystemExit("--ingest is a single-GPU variant (the per-rank ingest of a frame shard is not wired into score_clips_dp)")
     if dry:
@@ -495,6 +522,9 @@ def main():
         if args.tune_gemm:
             from aigv_assessor_amd import native
             native.check(native.load().aigv_tune_gemm(args.tune_gemm, 0.0))
+        if args.co_kmax >= 0:
+            from aigv_assessor_amd import native
+            native.check(native.load().aigv_tune_co_gemm(args.co_kmax))
     # inputs resident in HBM before the timed region (token ids are host data in the reference loop; tiny either way)
     # (CPU generator: at N = 1 these are the values tests/golden/e2e_8b_r3.pt was recorded on by the imported reference)
     pv = synth.synthetic_frames(B * T, cfg.image_size, seed=0).to(dev)

@@ -163,8 +163,9 @@ int aigv_set_row_trimming(aigv_ctx* ctx, int on);
 int aigv_set_attention_numerics(aigv_ctx* ctx, int mode);
 /* GEMM tile choice of THIS context: -1 = follow the process default set by aigv_tune_gemm (the state after aigv_ctx_create),
  * 0 = the per-sequence row plan (aigv_op_gemm_rows: the default; a clip's / frame's bits do not depend on its batch mates),
- * 1 = every row on the 128x128 kernel, 2 = every row on the 256x256 kernel wherever its shape rules allow (both in full K, so
- * batch-invariant too, but slower: test aliases).  Split-K scratch is per context too.  aigv_llm_extend (continuations of a kept
+ * 1 = every row on the 128x128 kernel, 2 = every row on the 256x256 kernel wherever its shape rules allow, 4 = every row on the
+ * co-resident 256x128 kernel (all three in full K, so batch-invariant too and bit-identical with one another: test aliases).  In modes
+ * 0 and 3 the GEMMs with K <= AIGV_TUNE_CO_KMAX (InternViT's K = 1024 linears, the patch embedding) run on the co-resident kernel.  Split-K scratch is per context too.  aigv_llm_extend (continuations of a kept
  * prefix) still uses the batch-level cost-model dispatch of aigv_op_gemm. */
 int aigv_set_gemm_mode(aigv_ctx* ctx, int mode);
 
@@ -285,15 +286,23 @@ enum aigv_tune_knob {
   AIGV_TUNE_GEMM256_ORDER = 1,   /* tile order of the 256 kernel: 0 by weight size, 1 row groups, 1 + g groups of g column tiles */
   AIGV_TUNE_GEMM256_VARIANT = 2, /* 0 the shipped schedule, 1 + v schedule variant v (0..3) */
   AIGV_TUNE_ATTN_WAVES = 3,      /* prefill attention: 0 default, 4 / 8 waves per workgroup */
-  AIGV_TUNE_SKINNY_P = 4,        /* decode GEMV form: 0 per-shape default, 1 / 2 / 4 */
-  AIGV_TUNE_BODY_TILE = 5        /* tile kernel of a row plan's body rows: 0 / 1 = 256x256 (shipped), 2 = 128x128 (same bits, slower) */
+  AIGV_TUNE_SKINNY_P = 4,        /* decode GEMV form: 0 per-shape default, 1 / 2 / 4; 1000 + (wqkv | wo << 3 | w1w3 << 6 | w2 << 9) = one form per GEMV */
+  AIGV_TUNE_BODY_TILE = 5,       /* tile kernel of a row plan's body rows: 0 / 1 = 256x256 (shipped), 2 = 128x128 (same bits, slower) */
+  AIGV_TUNE_CO_KMAX = 6,         /* GEMMs with K <= value run on the co-resident 256x128 kernel (same bits as the 256x256 one): 0 never (default) */
+  AIGV_TUNE_TAIL_SLICES = 7,     /* split-K factor of the row plans' tail half tiles: 0 = the per-(N, K) rule, 1 = inside the body's launch, S = one factor wherever it divides */
+  AIGV_TUNE_ATTN_LEAD_KEY = 8,   /* InternViT attention (64 j + 1 keys): 1 = full tiles over keys 1.. + key 0 merged in the epilogue (another summation order) */
+  AIGV_TUNE_DECODE_FUSED = 9,    /* decode: 1 (default) = RMSNorm inside the GEMV that consumes it, 0 = separate norm kernels */
+  AIGV_TUNE_DECODE_FP8 = 10,     /* decode in fp8 mode: 1 (default) = e4m3 GEMVs, 0 = bf16 GEMVs */
+  AIGV_TUNE_SKINNY_P8 = 11       /* form of the e4m3 decode GEMVs: 0 per-GEMV defaults, 1 / 2 / 4 */
 };
 int aigv_ctx_tune(aigv_ctx* ctx, int knob, int value);
 /* GEMM tile-kernel selection: mode 0 = cost model (default), 1 = always the 128x128 kernel, 2 = always the 256x256
- * phase-interleaved kernel where N % 256 == 0; rate256 > 0 overrides the model's relative throughput of the 256 kernel. */
+ * phase-interleaved kernel where N % 256 == 0, 4 = always the co-resident 256x128 kernel; rate256 > 0 overrides the model's relative throughput of the 256 kernel. */
 /* mode bits 4..6: 1 + v selects schedule variant v of the 256 kernel (0 = keep); bits 10..13: tile order of the 256 kernel, 0 = by weight
  * size (default), 1 = row groups, 1 + g = groups of g column tiles; bits 14..15: tile kernel of a row plan's body (AIGV_TUNE_BODY_TILE). */
 int aigv_tune_gemm(int mode, double rate256);
+/* Process default of AIGV_TUNE_CO_KMAX: 0 = the co-resident 256x128 kernel is never chosen by the dispatcher, else the largest K it takes. */
+int aigv_tune_co_gemm(int kmax);
 /* The row bands run_gemm would cut an M x N x K problem into (host logic only, no GPU): plan[0] = row tiles (x256 rows) on the
  * 256x256 kernel in whole rounds, or -1 = the whole problem in one launch of that kernel; plan[1] = row tiles on the 256x256
  * kernel with split-K, plan[2] = their K slices; plan[3] = remaining rows, plan[4] = their kernel (0 none, 1 skinny

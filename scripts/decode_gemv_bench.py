@@ -1,5 +1,5 @@
 """Decode GEMVs (one x row) on the 8B shapes: us per launch and TB/s of weights.  A/B of the 8-wave form:
-AIGV_SKINNY8_MAX_BLOCKS=0 python scripts/decode_gemv_bench.py   vs   python scripts/decode_gemv_bench.py"""
+python scripts/decode_gemv_bench.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aigv_assessor_amd import native

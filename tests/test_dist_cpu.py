@@ -165,6 +165,11 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     # a rank that dies takes the command down with a non-zero exit code (an option the ranks reject)
     bad = subprocess.run(cmd + ["--precision", "nonsense"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert bad.returncode != 0
+    # ... also when the surviving rank ignores SIGTERM (a rank inside a collective whose peer died): SIGKILL after ten seconds
+    import time
+    t0 = time.time()
+    stuck = subprocess.run(cmd + ["--dry-run-fault", "stuck-peer"], capture_output=True, text=True, timeout=200, env=env, cwd=root)
+    assert stuck.returncode == 3 and time.time() - t0 < 120, (stuck.returncode, time.time() - t0, stuck.stderr[-500:])
 
 
 def _gather_worker(rank, world, port, q, counts):

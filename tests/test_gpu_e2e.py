@@ -186,6 +186,37 @@ def test_last_layer_row_trimming_is_output_equivalent():
     assert bool((d <= 2.0 ** -7 * full["score1"].float().abs().cpu().clamp_min(0.5)).all()), d
 
 
+def test_row_trimming_rule_is_per_clip_in_a_mixed_batch():
+    """which kernels finish a clip's consumed rows must follow from the clip alone.  A clip with 11 consumed rows (score row +
+    10 answer rows) next to a clip with 31 (21 more answer rows unmasked in its labels): the first finishes on the weight-streaming path
+    and the second on the tile kernels with every other row, alone AND together - scores and level tokens of both are bit-identical
+    alone vs in the batch, in either order."""
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    model, sd, toks, pv, motion, ref, out = run_case(cfg, B=2, T=2, seed=33)
+    labels = toks["labels"].clone()
+    ans = (labels[1] != -100).nonzero().flatten()
+    extra = torch.arange(int(ans[0]) - 21, int(ans[0]))                     # 21 more consumed rows in front of clip 1's answer
+    labels[1, extra] = toks["input_ids"][1, extra]
+    assert int((labels[0] != -100).sum()) + 1 <= 16 < int((labels[1] != -100).sum()) + 1
+    n1 = toks["input_ids"].shape[1] - 1
+
+    def run(order):
+        idx = torch.tensor(order)
+        fidx = (idx[:, None] * 2 + torch.arange(2)[None, :]).flatten()
+        o = model(mos=None, pixel_values=pv[fidx], input_ids=toks["input_ids"][idx], attention_mask=toks["attention_mask"][idx],
+                  image_flags=torch.ones(len(fidx), 1, dtype=torch.long), labels=labels[idx], motion_feature=motion[idx])
+        torch.cuda.synchronize()
+        return {b: (o["score1"][i:i + 1].clone(), o["logit"][i * n1:(i + 1) * n1].clone()) for i, b in enumerate(order)}
+
+    alone = {**run([0]), **run([1])}
+    for order in ([0, 1], [1, 0]):
+        both = run(order)
+        for b in (0, 1):
+            assert torch.equal(both[b][0], alone[b][0]), (order, b, both[b][0], alone[b][0])
+            assert torch.equal(both[b][1], alone[b][1]), (order, b)
+    assert int((alone[1][1] >= 0).sum()) == 31 and int((alone[0][1] >= 0).sum()) == 10
+
+
 def test_shared_prefix_scoring_matches_separate_passes():
     """Four prompts behind one video prefix: the prefix runs once into the KV cache, every prompt continues
     its own question / answer tokens (aigv_llm_extend).  Each result must be that of a separate full pass: identical level

@@ -233,6 +233,89 @@ def test_gemm_tile_kernels_agree(lib, mode, M, N, K, epi):
     ulp_check(dC, want, frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
+def _op_gemm_mode(lib, mode, co_kmax, A, W, epi, bias, ls, resid, pos=None, np_=0, rows_out=None):
+    """aigv_op_gemm under process GEMM mode ``mode`` and co-resident threshold ``co_kmax``; defaults restored afterwards."""
+    from aigv_assessor_amd import native
+    from aigv_assessor_amd.native import ptr
+    M, K, N = A.shape[0], A.shape[1], W.shape[0]
+    nout = N // 2 if epi == 4 else N
+    dC = torch.full((rows_out or M, nout), float("nan"), dtype=BF, device="cuda")
+    db, dl, dr, dp = (dev(t) if t is not None else None for t in (bias, ls, resid, pos))
+    native.check(lib.aigv_tune_gemm(mode, 0.0))
+    native.check(lib.aigv_tune_co_gemm(co_kmax))
+    try:
+        sync(lib.aigv_op_gemm(ptr(dev(A)), K, ptr(dev(W)), K, ptr(dC), nout, ptr(db), ptr(dl), ptr(dr), nout, ptr(dp), np_, M, N, K, epi, None), lib)
+    finally:
+        native.check(lib.aigv_tune_gemm(0 + 32, 0.0))
+        native.check(lib.aigv_tune_co_gemm(0))
+    return dC.cpu()
+
+
+# InternViT's four linears at a few frames (qkv 3072, proj 1024, fc1 4096 out of K = 1024; fc2 K = 4096), ragged row counts (a last
+# tile with one valid half, with 1 row, with 129 rows), K-tile counts 1, 2, 3 (prologue / tail paths of the ring), odd and even, N = 128
+@pytest.mark.parametrize("M,N,K", [(2050, 3072, 1024), (1025, 1024, 1024), (1300, 4096, 1024), (1153, 1024, 4096), (256, 128, 64), (257, 256, 128),
+                                   (129, 384, 192), (4099, 512, 448), (77, 640, 1088)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_co_resident_kernel_equals_the_256_kernel_bit_for_bit(lib, M, N, K, epi):
+    """gemmco.hip (256 x 128 tile, two workgroups per CU) against gemm256.hip / gemm.hip: the same MFMA chain per output element and the
+    same epilogue rounding points, so torch.equal - the property that lets the dispatcher move InternViT's K = 1024 linears onto it
+    without moving one recorded bit (reference semantics: modeling_intern_vit.py:192-228)."""
+    g = torch.Generator().manual_seed(M * 3 + N + K + epi)
+    A, W, bias, ls, resid, nout = _gemm_rows_case(g, [M], N, K, epi)
+    co = _op_gemm_mode(lib, 4, 0, A, W, epi, bias, ls, resid)
+    assert torch.isfinite(co.float()).all()
+    ref = _op_gemm_mode(lib, 2 if N % 256 == 0 else 1, 0, A, W, epi, bias, ls, resid)
+    assert torch.equal(co.view(torch.int16), ref.view(torch.int16)), f"{int((co.view(torch.int16) != ref.view(torch.int16)).sum())} elements differ"
+    ulp_check(co, gemm_ref(A, W, epi, bias, ls, resid), frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
+    # and the default dispatch (mode 0) takes it for K <= 1024 and only then: same bits either way
+    auto = _op_gemm_mode(lib, 0, 1024, A, W, epi, bias, ls, resid)
+    if K <= 1024:
+        assert torch.equal(auto.view(torch.int16), co.view(torch.int16))
+
+
+def test_gemm_co_resident_kernel_patch_epilogue(lib):
+    """The patch-embedding epilogue (bias, position rows, one skipped class row per frame; K = 640 as at 448 px / patch 14) on the
+    co-resident kernel == on the 256 kernel."""
+    g = torch.Generator().manual_seed(11)
+    F_, np_, N, K = 3, 1024, 1024, 640
+    M = F_ * np_
+    A, W = (torch.randn(M, K, generator=g) * 0.5).to(BF), (torch.randn(N, K, generator=g) * 0.1).to(BF)
+    bias, pos = (torch.randn(N, generator=g) * 0.1).to(BF), torch.randn(np_ + 1, N, generator=g).to(BF)
+    outs = [_op_gemm_mode(lib, mode, 0, A, W, 5, bias, None, None, pos, np_, rows_out=F_ * (np_ + 1)).view(F_, np_ + 1, N)[:, 1:] for mode in (4, 2)]
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].reshape(M, N).view(torch.int16), outs[1].reshape(M, N).view(torch.int16))
+    ulp_check(outs[0].reshape(M, N), gemm_ref(A, W, 5, bias=bias, pos=pos, np_=np_), atol_rel=2.0 ** -7)
+
+
+@pytest.mark.parametrize("lens,N,K", [([1025] * 8, 3072, 1024), ([1025, 1027, 258, 3], 256, 256), ([300, 77, 1000, 129, 511], 768, 512), ([2176, 131], 1024, 1024)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_row_plan_on_the_co_resident_kernel(lib, lens, N, K, epi):
+    """aigv_op_gemm_rows with K <= the co-resident threshold (aigv_tune_co_gemm; off by default): body AND tail half tiles of every sequence in ONE launch of gemmco.hip
+    through the half-tile table (ragged halves, halves of different sequences sharing a tile), tiny tails on the skinny kernel.  Every
+    sequence alone == inside the batch (bits), and the body / tail rows equal the full-K tile kernels' bits."""
+    from aigv_assessor_amd import native
+    g = torch.Generator().manual_seed(sum(lens) + N + K + epi)
+    A, W, bias, ls, resid, nout = _gemm_rows_case(g, lens, N, K, epi)
+    native.check(lib.aigv_tune_co_gemm(1024))                                     # (the shipped default is 0 = never: profiles/r5_gemmco.txt)
+    try:
+        both = _run_gemm_rows(lib, A, W, bias, ls, resid, nout, lens, epi)
+        ulp_check(both, gemm_ref(A, W, epi, bias, ls, resid), frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
+        r0 = 0
+        for n in lens:
+            sl = slice(r0, r0 + n)
+            one = _run_gemm_rows(lib, A[sl], W, bias, ls, None if resid is None else resid[sl], nout, [n], epi)
+            assert torch.equal(one.view(torch.int16), both[sl].view(torch.int16)), f"sequence of {n} rows at {r0}"
+            r0 += n
+    finally:
+        native.check(lib.aigv_tune_co_gemm(0))
+    full = _op_gemm_mode(lib, 2 if N % 256 == 0 else 1, 0, A, W, epi, bias, ls, resid)   # every row on one tile kernel, full K
+    r0 = 0
+    for n in lens:
+        keep = n - (n % 256 if n % 256 <= 4 else 0)                                # tiny tails run on the skinny kernel (another summation order)
+        assert torch.equal(full[r0:r0 + keep].view(torch.int16), both[r0:r0 + keep].view(torch.int16)), f"sequence of {n} rows at {r0}"
+        r0 += n
+
+
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
 def test_gemm_tile_order_changes_no_bit(lib, epi):
     """The 256x256 kernel's workgroup -> tile map (row groups / groups of g column tiles: GemmArgs::order, gemm256.hip) only decides WHICH

@@ -171,6 +171,14 @@ def test_product_path_never_imports_the_oracle():
                 assert "/root/reference" not in txt, f
 
 
+def test_product_library_reads_no_environment_variable():
+    """a stray variable must not be able to re-roll a summation order.  Every experiment knob of the kernels is a field of
+    the context (aigv_ctx_tune) or a process default set by an explicit call (aigv_tune_*); the native sources hold no getenv."""
+    csrc = os.path.join(ROOT, "aigv-assessor_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join("..", "..", "include", "aigv_amd.h")]:
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
 def test_canonical_layout_and_special_ids():
     c8 = pkg.internvl2_8b()
     assert synth.canonical_len(c8, 8) == 2177 and synth.canonical_len(c8, 16) == 4281
@@ -575,8 +583,39 @@ def test_llama_family_config_and_streamed_repacking():
     assert set(streamed) == set(packed) and all(torch.equal(streamed[k], packed[k]) for k in packed)
     with pytest.raises(KeyError):       # a layer whose v_proj never arrives
         dict(weights.llama_stream_to_internlm2(((k, v) for k, v in sd.items() if not k.endswith("layers.1.self_attn.v_proj.weight")), l))
+    # rope scaling reaches the tables whatever the spelling, and what is not built raises instead of running unscaled
+    base = dict(d, max_position_embeddings=4096)
+    for given in (dict(rope_scaling=dict(type="linear", factor=2.0)), dict(rope_scaling=dict(rope_type="linear", factor=2.0)),
+                  dict(rope_parameters=dict(rope_theta=10000.0, rope_type="linear", factor=2.0))):
+        assert pkg.InternVLChatConfig.from_dict(dict(llm_config=dict(base, **given))).llm_config.rope_scaling == {"type": "linear", "factor": 2.0}
+    assert pkg.InternVLChatConfig.from_dict(dict(llm_config=dict(base, rope_scaling=dict(rope_type="dynamic", factor=4)))).llm_config.rope_scaling["type"] == "dynamic"
+    assert pkg.InternVLChatConfig.from_dict(dict(llm_config=dict(base, rope_scaling=dict(rope_type="default")))).llm_config.rope_scaling is None
+    for bad in (dict(rope_scaling=dict(rope_type="llama3", factor=8.0)), dict(rope_parameters=dict(rope_type="yarn", factor=4.0)), dict(head_dim=32)):
+        with pytest.raises(NotImplementedError):
+            pkg.InternVLChatConfig.from_dict(dict(llm_config=dict(base, **bad)))
+    lc = pkg.InternVLChatConfig.from_dict(dict(llm_config=dict(architectures=["LlamaForCausalLM"]))).llm_config      # LlamaConfig's own defaults
+    assert (lc.max_position_embeddings, lc.vocab_size, lc.intermediate_size, lc.num_key_value_heads, lc.head_dim) == (2048, 32000, 11008, 32, 128)
+    assert pkg.InternVLChatConfig.from_dict(dict(llm_config=dict(rope_scaling=dict(type="dynamic", factor=2.0)))).llm_config.rope_scaling == {"type": "dynamic", "factor": 2.0}
     m = InternVLChatModel(cfg)          # constructs (host side only) and owns InternLM2-layout parameters for both families
     assert m.llm_arch_name == "LlamaForCausalLM" and "language_model.model.layers.0.attention.wqkv.weight" in dict(m.named_parameters())
+    # load_state_dict_stream == load_state_dict: Llama names and InternLM2 names both load on a Llama configuration, missing
+    # tensors raise unless strict=False, an exception mid-stream still invalidates the native copy
+    ref = InternVLChatModel(cfg)
+    ref.load_state_dict(sd)
+    for source in (sd, packed):
+        m2 = InternVLChatModel(cfg)
+        m2._dirty = False
+        assert m2.load_state_dict_stream(iter(source.items())) == [] and m2._dirty
+        assert all(torch.equal(a, b) for a, b in zip(m2.parameters(), ref.parameters()))
+    m2 = InternVLChatModel(cfg)
+    short = [(k, v) for k, v in packed.items() if not k.startswith("mlpscore.fc5")]
+    with pytest.raises(RuntimeError, match="missing"):
+        m2.load_state_dict_stream(iter(short))
+    assert sorted(m2.load_state_dict_stream(iter(short), strict=False)) == ["mlpscore.fc5.bias", "mlpscore.fc5.weight"]
+    m2._dirty = False
+    with pytest.raises(RuntimeError, match="unexpected"):
+        m2.load_state_dict_stream(iter(list(packed.items())[:3] + [("not.a.parameter", torch.zeros(1))]))
+    assert m2._dirty
     cfg.llm_config.architectures = ("Qwen2ForCausalLM",)
     with pytest.raises(NotImplementedError):
         InternVLChatModel(cfg)
