@@ -101,7 +101,7 @@ struct aigv_ctx {
   int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2 / 3 / 4
   // the other experiment knobs of this context (aigv_ctx_tune): -1 = follow the process default (aigv_tune_*)
   int t_order = -1, t_variant = -1, t_attn_waves = -1, t_skinny_p = -1, t_body_tile = -1, t_co_kmax = -1;
-  int t_tail_slices = -1, t_lead_key = -1, t_decode_fused = -1, t_decode_fp8 = -1, t_skinny_p8 = -1;
+  int t_tail_slices = -1, t_lead_key = -1, t_decode_fused = -1, t_decode_fp8 = -1, t_skinny_p8 = -1, t_fuse_tails = -1;
   size_t splitk_floats = 0;
   float* splitk_ws = nullptr;  // fp32 slabs of the split-K row bands: owned by the context (one launch stream per context at a time)
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 2 (attention out, normed) + [64, I], reused per 64 consumed rows
@@ -233,6 +233,7 @@ struct Tune {
   // context-only experiment knobs (aigv_ctx_tune): split-K factor of the tails (0 = the per-shape rule), lead-key attention form for 64 j + 1 keys,
   // fused-norm decode GEMVs (1 = on), e4m3 decode GEMVs in fp8 mode (1 = on), form of the e4m3 decode GEMVs (0 = per-GEMV defaults)
   int tail_slices = 0, lead_key = 0, decode_fused = 1, decode_fp8 = 1, skinny_p8 = 0;
+  int fuse_tails = 0;   // tail K slices inside the body's launch: 0 = when the body leaves CUs idle, 1 = never, 2 = always (same bits each way)
 };
 Tune g_tune;
 // the knobs in force for a call: the context's own setting, else the process default
@@ -252,6 +253,7 @@ Tune tune_of(const aigv_ctx* c) {
     if (c->t_decode_fused >= 0) t.decode_fused = c->t_decode_fused;
     if (c->t_decode_fp8 >= 0) t.decode_fp8 = c->t_decode_fp8;
     if (c->t_skinny_p8 >= 0) t.skinny_p8 = c->t_skinny_p8;
+    if (c->t_fuse_tails >= 0) t.fuse_tails = c->t_fuse_tails;
   }
   return t;
 }
@@ -612,6 +614,26 @@ int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hi
   } else if (!tails_apart) {
     TRY(launch_tab(c, a, epi, rp.d_tab, rp.body_halves + rp.tail_halves, rp.body_halves * 128 + rp.tail_rows, 1, s));
   } else {
+    // A body that leaves part of its last round of CUs idle (one or two clips) takes the tail's K slices into its own launch: the same
+    // slices, slabs and finalize pass as the two-launch form - not one bit differs, so the choice may follow the fill (fuse_tails).
+    const int tn = a.N / 256;
+    const long body_wg = (long)(rp.body_halves / 2) * tn, slice_wg = (long)((rp.tail_halves + 1) / 2) * tn * S;
+    const size_t need = (size_t)S * ((rp.tail_halves + 1) / 2) * 256 * a.N;
+    const int fuse_knob = tune_of(c).fuse_tails;   // 0 = by fill, 1 = never, 2 = whenever the shapes allow
+    const bool by_fill = body_wg % 256 != 0 && body_wg % 256 + slice_wg <= 320;
+    if (rp.body_halves > 0 && (rp.body_halves & 1) == 0 && need <= (c ? c->splitk_floats : SPLITK_MAX_FLOATS) && fuse_knob != 1 && (by_fill || fuse_knob == 2)) {
+      float* ws = nullptr;
+      TRY(splitk_scratch(c, need, &ws));
+      GemmArgs b = tuned(c, a);
+      b.row_tab = rp.d_tab; b.tab_halves = rp.body_halves; b.fuse_tail_halves = rp.tail_halves; b.part = ws; b.k_slices = S;
+      GemmArgs pf = a; pf.M = rp.body_halves * 128 + rp.tail_halves * 128;
+      GEMM_PROF(c, pf, s);
+      HIPCHK(c, aigv_launch_gemm256_fused(b, epi, s));
+      GemmArgs f = a;
+      f.row_tab = rp.d_tab + 2 * rp.body_halves; f.tab_halves = rp.tail_halves;
+      HIPCHK(c, aigv_launch_gemm_finalize(f, epi, S, ws, s));
+      return run_tiny_tails(c, a, epi, rp, s);
+    }
     TRY(launch_tab(c, a, epi, rp.d_tab, rp.body_halves, rp.body_halves * 128, 1, s));
   }
   if (tails_apart) {
@@ -1718,6 +1740,9 @@ int aigv_ctx_tune(aigv_ctx* c, int knob, int value) {
     case AIGV_TUNE_DECODE_FP8:
       if (value < -1 || value > 1) break;
       c->t_decode_fp8 = value; return 0;
+    case AIGV_TUNE_FUSE_TAILS:
+      if (value < -1 || value > 2) break;
+      c->t_fuse_tails = value; return 0;
     case AIGV_TUNE_SKINNY_P8:
       if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4) break;
       c->t_skinny_p8 = value; return 0;
@@ -2134,6 +2159,18 @@ int aigv_tune_gemm(int mode, double rate256) {
   g_tune.gemm_mode = mode;
   if (rate256 > 0) g_rate256 = rate256;
   return 0;
+}
+
+// process default of a context-only knob (the context-free aigv_op_* entry points and contexts that left it at -1 follow it): tests and A/B scripts
+int aigv_tune_default(int knob, int value) {
+  switch (knob) {
+    case AIGV_TUNE_TAIL_SLICES: if (value < 0 || value > 16) break; g_tune.tail_slices = value; return 0;
+    case AIGV_TUNE_FUSE_TAILS: if (value < 0 || value > 2) break; g_tune.fuse_tails = value; return 0;
+    case AIGV_TUNE_ATTN_LEAD_KEY: if (value < 0 || value > 1) break; g_tune.lead_key = value; return 0;
+    case AIGV_TUNE_CO_KMAX: return aigv_tune_co_gemm(value);
+    default: return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_default: knob %d has no process default here (aigv_tune_gemm / _attention / _skinny set the others)", knob);
+  }
+  return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_default: value %d out of range for knob %d", value, knob);
 }
 
 int aigv_tune_co_gemm(int kmax) {

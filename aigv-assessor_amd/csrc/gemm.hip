@@ -314,6 +314,21 @@ hipError_t aigv_launch_gemm_splitk_fp8(const GemmArgs& a, int epi, int k_slices,
   return hipGetLastError();
 }
 
+// the second half of a split-K GEMM on its own: sum the k_slices slabs in slice order + epilogue `epi` (a.row_tab / a.tab_halves = the rows
+// the slabs hold, as the slice launch addressed them)
+hipError_t aigv_launch_gemm_finalize(const GemmArgs& a, int epi, int k_slices, const float* ws, hipStream_t s) {
+  if (k_slices < 2 || !ws) return hipErrorInvalidValue;
+  switch (epi) {
+    case EPI_STORE: launch_finalize<EPI_STORE>(a, ws, k_slices, s); break;
+    case EPI_GELU: launch_finalize<EPI_GELU>(a, ws, k_slices, s); break;
+    case EPI_LS_RESID: launch_finalize<EPI_LS_RESID>(a, ws, k_slices, s); break;
+    case EPI_RESID: launch_finalize<EPI_RESID>(a, ws, k_slices, s); break;
+    case EPI_SWIGLU: launch_finalize<EPI_SWIGLU>(a, ws, k_slices, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t aigv_launch_gemm_splitk(const GemmArgs& a, int epi, int k_slices, float* ws, hipStream_t s, bool tile256) {
   if (k_slices < 2 || (a.K / BK) % k_slices || !ws || epi == EPI_PATCH || epi >= EPI_COUNT) return hipErrorInvalidValue;
   if (!tile256 && a.row_tab) return hipErrorInvalidValue;   // the 128 kernel's slabs have no table mapping

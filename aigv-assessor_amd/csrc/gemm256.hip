@@ -79,9 +79,15 @@ __device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uni
 // FP8 (EPI_STORE only): A / W rows hold e4m3 bytes; the 128-byte K-tile rows, the LDS image and the DMA stream are unchanged (a
 //      64-deep bf16 K-tile and a 128-deep fp8 K-tile are the same bytes), a phase issues eight v_mfma_scale_f32_16x16x128_f8f6f4 with
 //      unit block scales instead of sixteen bf16 MFMAs, and the epilogue multiplies by the per-row and per-column fp32 scales.
-template <int EPI, int VAR, bool FP8 = false>
+// FUSE: one launch holds the BODY tiles of a row plan (workgroups [0, p.fuse_body_wg): epilogue EPI, the table's first p.tab_halves halves)
+//      and the split-K SLICES of its tail tiles behind them (p.k_slices workgroups per tile of the p.fuse_tail_halves halves that follow in
+//      the table: fp32 slabs, as EPI_PARTIAL) - for launches whose body does not fill its last round of CUs (one or two clips), where a
+//      separate slice launch would run behind a half-empty chip.  Same slices, same slabs, same finalize pass: not one bit differs from the
+//      two-launch form.
+template <int EPI, int VAR, bool FP8 = false, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   static_assert(!FP8 || ((VAR & 4) != 0 && EPI != EPI_PATCH), "the fp8 form uses the LDS-staged epilogue (or writes split-K slabs)");
+  static_assert(!FUSE || (!FP8 && EPI != EPI_PARTIAL && EPI != EPI_PATCH), "the fused form: bf16, a body epilogue");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,14 +96,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 
   // ---- tile mapping: XCD-aware bijective remap, then groups of GROUP_M256 row-tiles sweep the column tiles ----
   const int nbm = p.row_tab ? (p.tab_halves + 1) / 2 : (p.M + TM - 1) / TM, nbn = p.N / TN;
-  const int nwg = nbm * nbn;
+  const int n_body = nbm * nbn;
+  // (FUSE) the blocks behind the body tiles are the tail tiles' K slices.  The role follows the RAW block index - the long body tiles are
+  // dispatched first and dealt evenly over the XCDs - and each role has its own XCD-aware remap (blocks with equal index mod 8 share an XCD
+  // within a role either way).
+  const bool is_slice = FUSE && (int)blockIdx.x >= n_body;
+  const int nwg = is_slice ? ((p.fuse_tail_halves + 1) / 2) * nbn * p.k_slices : n_body;
   int wg;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int bid = is_slice ? (int)blockIdx.x - n_body : (int)blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  const bool partial = (EPI == EPI_PARTIAL) || is_slice;
+  int slice_idx = (EPI == EPI_PARTIAL) ? (int)blockIdx.y : 0;
   int tm, tn;
-  if (p.order == 0) {
+  if (is_slice) {   // K slice `slice_idx` of tail tile (tm, tn): the slices of a tile are neighbours
+    slice_idx = wg % p.k_slices;
+    const int tile = wg / p.k_slices;
+    tn = tile % nbn; tm = tile / nbn;
+  } else if (p.order == 0) {
     const int per_group = GROUP_M256 * nbn;
     const int grp = wg / per_group, first_m = grp * GROUP_M256;
     const int gsz = min(nbm - first_m, GROUP_M256);
@@ -120,7 +137,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   if (p.row_tab) {
     const int h = 2 * tm + g;
     hb = 0; hv = 0;
-    if (h < p.tab_halves) { hb = p.row_tab[2 * h]; hv = p.row_tab[2 * h + 1]; }
+    if (is_slice) {   // the tail halves follow the body halves in the table
+      if (h < p.fuse_tail_halves) { hb = p.row_tab[2 * (p.tab_halves + h)]; hv = p.row_tab[2 * (p.tab_halves + h) + 1]; }
+    } else if (h < p.tab_halves) { hb = p.row_tab[2 * h]; hv = p.row_tab[2 * h + 1]; }
   } else {
     hb = tm * TM + g * 128; hv = min(p.M - hb, 128);
     if (hv <= 0) { hb = p.M - 1; hv = 0; }
@@ -135,8 +154,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   const int lr = lane >> 3, lc = (lane & 7) ^ lr;
   // wave-uniform tile bases (SGPRs) + 32-bit per-lane byte offsets: global_load_lds saddr + voffset, no 64-bit VALU
   // split-K (EPI_PARTIAL): blockIdx.y picks the K slice
-  const int nk = (EPI == EPI_PARTIAL) ? p.K / TK / p.k_slices : p.K / TK;
-  const size_t kbase = (EPI == EPI_PARTIAL) ? (size_t)blockIdx.y * nk * TK : 0;
+  const int nk = partial ? p.K / TK / p.k_slices : p.K / TK;
+  const size_t kbase = partial ? (size_t)slice_idx * nk * TK : 0;
   const char* tileA = (const char*)(p.A + (size_t)hb * p.lda + kbase);
   const char* tileW = (const char*)(p.W + (size_t)n0 * p.ldw + kbase);
   unsigned off[4][2];   // [unit][instr], at k = 0
@@ -294,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     PHASE_TAIL(I0)
     // the last tile of a residual epilogue: the K stream has nothing left to issue; phases 1 and 2 issue the first residual half
     // instead (4 LDS-DMA each).  The stream itself has fully landed after phase 1's wait (vmcnt(4) = only those 4 younger).
-    const bool last_r = RESID_PF && !steady && (t == nk - 1);
+    const bool last_r = RESID_PF && !steady && (t == nk - 1) && !is_slice;   // (a fused K slice stores fp32 sums: no residual to fetch)
     // ---- j = 1 ----
     read_b1(sb);
     if constexpr (steady) dma(t + 1, 1); else issue(t + 1, 3);
@@ -355,8 +374,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #define GSTAMP_FINISH()
 #endif
 
-  if constexpr (EPI == EPI_PARTIAL) {
-    // ---- split-K slice: fp32 partial sums into slab blockIdx.y ([M][N], the layout gemm_finalize_kernel sums) ----
+  auto store_partial = [&]() __attribute__((always_inline)) {
+    // ---- split-K slice: fp32 partial sums into slab `slice_idx` ([M][N], the layout gemm_finalize_kernel sums) ----
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -365,8 +384,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         if (m >= hend) continue;
         // slab rows: the output row itself, or (table form) the compact row (half index) * 128 + row inside the half
         const size_t srow = p.row_tab ? (size_t)((2 * tm + g) * 128 - hb) + m : (size_t)m;
-        const size_t slab_rows = p.row_tab ? (size_t)nbm * TM : (size_t)p.M;
-        float* row = p.part + ((size_t)blockIdx.y * slab_rows + srow) * p.N + n0 + wc * 64 + fq * 4;
+        const size_t slab_rows = p.row_tab ? (size_t)(FUSE ? (p.fuse_tail_halves + 1) / 2 : nbm) * TM : (size_t)p.M;
+        float* row = p.part + ((size_t)slice_idx * slab_rows + srow) * p.N + n0 + wc * 64 + fq * 4;
         // fp8: the slabs hold SCALED partial sums ((acc * row scale) * column scale is linear in acc), so the finalize pass is the bf16 one
         const float rs = FP8 ? p.row_scale[m] : 1.f;
 #pragma unroll
@@ -378,6 +397,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             *(f32x4*)(row + nh * 32 + nt * 16) = v;
           }
       }
+  };
+  if constexpr (FUSE) {
+    if (is_slice) {
+      store_partial();
+      GSTAMP_FINISH();
+      return;
+    }
+  }
+  if constexpr (EPI == EPI_PARTIAL) {
+    store_partial();
     GSTAMP_FINISH();
     return;
   } else if constexpr (RESID_PF) {
@@ -744,6 +773,35 @@ hipError_t aigv_launch_gemm256_partial(const GemmArgs& a, hipStream_t s) {
   const int nbm = row_tiles(a), nbn = a.N / TN;
   hipLaunchKernelGGL((gemm256_kernel<EPI_PARTIAL, 7>), dim3(nbm * nbn, a.k_slices), dim3(512), LDS_BYTES, s, a);
   return hipGetLastError();
+}
+
+// body tiles + the K slices of the tail tiles in ONE launch (gemm256_kernel<.., FUSE>): a.row_tab = body halves (a.tab_halves, an even
+// count) followed by a.fuse_tail_halves tail halves; a.part / a.k_slices as for aigv_launch_gemm256_partial.  The caller runs the finalize
+// pass over the tail table afterwards.
+template <int EPI>
+static hipError_t launch256_fused(const GemmArgs& a, hipStream_t s) {
+  static LdsAttrOnce lds_attr;
+  if (hipError_t e = lds_attr.ensure((const void*)gemm256_kernel<EPI, 7, false, true>, LDS_BYTES); e != hipSuccess) return e;
+  const int nbm = (a.tab_halves + 1) / 2, nbn = a.N / TN;
+  GemmArgs b = a;
+  b.order = tile_order(a, (size_t)a.N * (size_t)a.K >= ((size_t)32 << 20), nbm);
+  b.fuse_body_wg = nbm * nbn;
+  const int grid = nbm * nbn + ((a.fuse_tail_halves + 1) / 2) * nbn * a.k_slices;
+  hipLaunchKernelGGL((gemm256_kernel<EPI, 7, false, true>), dim3(grid), dim3(512), LDS_BYTES, s, b);
+  return hipGetLastError();
+}
+
+hipError_t aigv_launch_gemm256_fused(const GemmArgs& a, int epi, hipStream_t s) {
+  if (!aigv_gemm256_supported(a) || !a.row_tab || (a.tab_halves & 1) || a.fuse_tail_halves < 1 || a.k_slices < 2 || (a.K / TK) % a.k_slices || !a.part)
+    return hipErrorInvalidValue;
+  switch (epi) {
+    case EPI_STORE: return launch256_fused<EPI_STORE>(a, s);
+    case EPI_GELU: return launch256_fused<EPI_GELU>(a, s);
+    case EPI_LS_RESID: return launch256_fused<EPI_LS_RESID>(a, s);
+    case EPI_RESID: return launch256_fused<EPI_RESID>(a, s);
+    case EPI_SWIGLU: return launch256_fused<EPI_SWIGLU>(a, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {

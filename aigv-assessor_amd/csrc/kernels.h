@@ -36,6 +36,9 @@ struct GemmArgs {
   // gemm256 only: the rows of a launch as a table of 128-row HALF tiles, (base row, valid rows 0..128) int32 pairs on the device; row
   // tile i = halves 2i, 2i+1.  M is then only the row count of the buffers (slabs of the split-K form are [k_slices][tiles*256][N]).
   const int32_t* row_tab; int tab_halves;
+  // fused body + tail-slice launch (aigv_launch_gemm256_fused): the table continues with fuse_tail_halves tail halves; fuse_body_wg is filled
+  // in by the launcher
+  int fuse_tail_halves, fuse_body_wg;
   // per-launch tuning selectors (0 = the default; set from the context's / the process's knobs by the dispatcher in api.hip - the kernel files
   // hold no mutable state): order_sel 1 = row groups, 1 + g = groups of g column tiles (0: by weight size); variant_sel 1 + v = schedule
   // variant v of the 256 kernel (0: the shipped one)
@@ -61,6 +64,10 @@ hipError_t aigv_launch_rmsnorm_quant_fp8(const bf16_t* x, int ldx, const bf16_t*
                                          hipStream_t s);
 hipError_t aigv_launch_quant_fp8_rows(const bf16_t* x, int ldx, int rows, int K, uint8_t* q, int ldq, float* scale, hipStream_t s);
 bool aigv_gemm256_supported(const GemmArgs& a);
+// one launch: the body tiles of a row plan with epilogue `epi` + the split-K slices (fp32 slabs a.part) of its tail tiles; then
+// aigv_launch_gemm_finalize over the tail table sums the slabs (the second half of aigv_launch_gemm_splitk)
+hipError_t aigv_launch_gemm256_fused(const GemmArgs& a, int epi, hipStream_t s);
+hipError_t aigv_launch_gemm_finalize(const GemmArgs& a, int epi, int k_slices, const float* ws, hipStream_t s);
 hipError_t aigv_launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);        // 256x256 phase-interleaved kernel
 // 256x128 tile, four waves, two co-resident workgroups per CU (gemmco.hip): same bits as the 256 kernel; takes the half-tile table too
 bool aigv_gemmco_supported(const GemmArgs& a);

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "aigv_op_frame_resize_ingest": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P, _P]),
     "aigv_tune_gemm": (_I, [_I, C.c_double]),
     "aigv_tune_co_gemm": (_I, [_I]),
+    "aigv_tune_default": (_I, [_I, _I]),
     "aigv_tune_attention": (_I, [_I]),
     "aigv_tune_skinny": (_I, [_I]),
     "aigv_plan_gemm": (_I, [_I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_double)]),

@@ -1,13 +1,19 @@
-"""Full-size parity statistics on an MI355X: every clip the imported reference was recorded on (tests/golden/e2e_8b_full.pt: five
-one-clip seeds; e2e_8b_r3.pt / e2e_8b_r3b.pt: two batches of four) scored under
+"""Full-size parity statistics on an MI355X: every clip the imported reference was recorded on, scored under
 
-    attention numerics {reference score rounding, fp32 scores}  x  GEMM dispatch modes {0 row plans, 1 128 kernel, 2 256 kernel}
+    attention numerics {reference score rounding, fp32 scores}  [x GEMM dispatch modes {0 row plans, 1 128 kernel, 2 256 kernel} with --modes]
 
-Every (numerics, mode) pair is a CORRECT evaluation of the same arithmetic definition up to fp32 summation order (and, for the numerics,
-up to where the score matrix rounds); the table shows how far each sits from the reference's recorded bf16 and fp32 scores, in bf16 ulps of
-the score, next to the reference's own spread against itself (tests/golden/e2e_8b_r4_self.pt: host thread counts).
+next to the reference's own spread against itself.  Round 5 sample:
 
-    python tests/manual/parity_stats.py [out.json]
+* 37 reference-pinned clips: five one-clip seeds (tests/golden/e2e_8b_full.pt), the two batches of four of rounds 3 (e2e_8b_r3.pt / _r3b.pt) and six
+  more batches of the benched shape (e2e_8b_r5.pt, input seeds 2-7), each with the reference's bf16 score and - where recorded - its fp32 score;
+* 39 reference-vs-itself pairs: the first 13 clips re-scored by the reference under torch.set_num_threads(1 / 2 / 4) against its 8-thread pass
+  (e2e_8b_r5.pt; another fp32 summation order of the same arithmetic) + the five pairs of round 4 (e2e_8b_r4_self.pt).
+
+Every (numerics, mode) pair is a CORRECT evaluation of the same arithmetic definition up to fp32 summation order (and, for the numerics, up to where
+the score matrix rounds).  Printed per arm: mean / 95th percentile / max of |hip - ref bf16| and of |hip - ref fp32| in bf16 ulps of the score, the
+number of clips with the identical bf16 score, level tokens differing; then the same statistics of the reference against itself.
+
+    python tests/manual/parity_stats.py [out.json] [--modes]
 """
 import json
 import os
@@ -29,8 +35,69 @@ def ulp(x):
     return 2.0 ** (torch.tensor(abs(float(x))).clamp_min(1e-30).log2().floor().item() - 7)
 
 
-def main():
+def stats(v):
+    t = torch.tensor(v, dtype=torch.float64)
+    return dict(n=len(v), mean=float(t.mean()), p95=float(t.quantile(0.95)), max=float(t.max()))
+
+
+def fmt(s):
+    return f"mean {s['mean']:.2f}  p95 {s['p95']:.1f}  max {s['max']:.1f}  (n = {s['n']})"
+
+
+def reference_cases():
+    """[(name, B, input seed, ref bf16 scores [B], ref fp32 scores [B] or None, ref bf16 answer tokens, answer rows)]"""
     g = torch.load(os.path.join(G, "e2e_8b_full.pt"), weights_only=True)
+    cases = []
+    for seed in (201, 202, 203, 204, 205):
+        a, b = g["cases"][f"bf16/{seed}"], g["cases"][f"fp32/{seed}"]
+        cases.append((f"one/{seed}", 1, seed, a["score1"].float(), b["score1"].float(), a["logit"], a["answer_rows"]))
+    for f in ("e2e_8b_r3.pt", "e2e_8b_r3b.pt"):
+        gg = torch.load(os.path.join(G, f), weights_only=True)["cases"]
+        a, b = gg["batch4/bf16"], gg["batch4/fp32"]
+        cases.append((f"batch4/seed{a['seed']}", 4, a["seed"], a["score1"].float(), b["score1"].float(), a["logit"], a["answer_rows"]))
+    r5 = os.path.join(G, "e2e_8b_r5.pt")
+    if os.path.exists(r5):
+        c5 = torch.load(r5, weights_only=True)["cases"]
+        for seed in range(2, 8):
+            a = c5.get(f"batch4/seed{seed}/bf16")
+            if a is None:
+                continue
+            b = c5.get(f"batch4/seed{seed}/fp32")
+            cases.append((f"batch4/seed{seed}", 4, seed, a["score1"].float(), None if b is None else b["score1"].float(), a["logit"], a["answer_rows"]))
+    return g, cases
+
+
+def reference_self_pairs(cases):
+    """|ref bf16 under N threads - ref bf16 under 8 threads| in ulps, per clip, for every recorded thread count; level tokens flipped."""
+    out, flips, rows = {}, 0, 0
+    base = {name: (r16, rlog) for name, _B, _s, r16, _r32, rlog, _rows in cases}
+    r5 = os.path.join(G, "e2e_8b_r5.pt")
+    if os.path.exists(r5):
+        c5 = torch.load(r5, weights_only=True)["cases"]
+        for key, c in c5.items():
+            parts = key.split("/")
+            if not parts[-1].startswith("t") or parts[-1] == "t8":
+                continue
+            name = "/".join(parts[:-1])
+            if name not in base:
+                continue
+            r16, rlog = base[name]
+            s = c["score1"].float()
+            out.setdefault(parts[-1], []).extend(abs(float(s[i] - r16[i])) / ulp(r16[i]) for i in range(len(s)))
+            flips += int((c["logit"] != rlog).sum()); rows += int(rlog.numel())
+    r4 = os.path.join(G, "e2e_8b_r4_self.pt")
+    if os.path.exists(r4):
+        c = torch.load(r4, weights_only=True)["cases"]
+        a, b = c["batch4/seed0/t8"]["score1"].float(), c["batch4/seed0/t4"]["score1"].float()
+        out.setdefault("r4:t4", []).extend(abs(float(a[i] - b[i])) / ulp(a[i]) for i in range(4))
+        out.setdefault("r4:t1", []).append(abs(float(c["alone/seed0/clip0/t1"]["score1"].float()[0] - c["alone/seed0/clip0/t8"]["score1"].float()[0])) / ulp(a[0]))
+    return out, flips, rows
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    modes = (0, 1, 2) if "--modes" in sys.argv else (0,)
+    g, cases = reference_cases()
     cfg = pkg.InternVLChatConfig.from_dict(dict(vision_config=g["vision_config"], llm_config=g["llm_config"], force_image_size=448, select_layer=-1))
     dev = torch.device("cuda", 0)
     model = InternVLChatModel(cfg, device=dev, max_clips=4, max_frames=32, max_tokens=4 * synth.canonical_len(cfg, 8))
@@ -40,21 +107,14 @@ def main():
     model.load_state_dict(sd)
     del sd
     model.eval()
-    cases = []   # (name, B, seed, ref bf16 scores, ref fp32 scores, ref bf16 answer tokens, answer rows)
-    for seed in (201, 202, 203, 204, 205):
-        a, b = g["cases"][f"bf16/{seed}"], g["cases"][f"fp32/{seed}"]
-        cases.append((f"one/{seed}", 1, seed, a["score1"].float(), b["score1"].float(), a["logit"], a["answer_rows"]))
-    for f in ("e2e_8b_r3.pt", "e2e_8b_r3b.pt"):
-        gg = torch.load(os.path.join(G, f), weights_only=True)["cases"]
-        a, b = gg["batch4/bf16"], gg["batch4/fp32"]
-        cases.append((f"batch4/seed{a['seed']}", 4, a["seed"], a["score1"].float(), b["score1"].float(), a["logit"], a["answer_rows"]))
+    n_clips = sum(c[1] for c in cases)
+    print(f"{n_clips} reference-pinned clips in {len(cases)} recorded passes", flush=True)
     out = {}
     for numerics in ("reference", "fp32"):
         model.set_attention_numerics(numerics)
-        for mode in (0, 1, 2):
+        for mode in modes:
             model.set_gemm_mode(mode)
-            d16, d32, lev, nlev = [], [], 0, 0
-            per_clip = []
+            d16, d32, lev, nlev, per_clip = [], [], 0, 0, []
             for name, B, seed, r16, r32, rlog, rows in cases:
                 toks = synth.canonical_tokens(cfg, B, 8, seed=seed)
                 model.img_context_token_id = toks["img_context_token_id"]
@@ -66,32 +126,34 @@ def main():
                 for i in range(B):
                     u = ulp(r16[i])
                     d16.append(abs(float(hip[i] - r16[i])) / u)
-                    d32.append(abs(float(hip[i] - r32[i])) / u)
+                    if r32 is not None:
+                        d32.append(abs(float(hip[i] - r32[i])) / u)
                     per_clip.append(round(d16[-1], 1))
                 got = o["logit"].cpu()[rows]
                 lev += int((got != rlog).sum())
                 nlev += int(rlog.numel())
-            t = torch.tensor(d16)
             key = f"{numerics}/gemm{mode}"
-            out[key] = dict(mean_ulps_vs_ref_bf16=float(t.mean()), max_ulps_vs_ref_bf16=float(t.max()), mean_ulps_vs_ref_fp32=float(torch.tensor(d32).mean()),
-                            identical=int((t == 0).sum()),
+            out[key] = dict(vs_ref_bf16=stats(d16), vs_ref_fp32=stats(d32), identical=int(sum(1 for x in d16 if x == 0)),
                             level_tokens_differing=lev, level_rows=nlev, per_clip_ulps=per_clip)
-            print(f"{key:18s} |hip - ref bf16| mean {t.mean():.2f} max {t.max():.1f} ulps, identical {int((t == 0).sum())}/13; vs ref fp32 mean "
-                  f"{torch.tensor(d32).mean():.2f} ulps; level tokens differing {lev}/{nlev}; per clip {per_clip}", flush=True)
+            print(f"{key:18s} |hip - ref bf16| {fmt(out[key]['vs_ref_bf16'])}, identical {out[key]['identical']}/{n_clips};  |hip - ref fp32| {fmt(out[key]['vs_ref_fp32'])};  "
+                  f"level tokens differing {lev}/{nlev}", flush=True)
+            print(f"{'':18s} per clip {per_clip}", flush=True)
+    model.set_gemm_mode(-1)
     # the reference's own two precisions, and its own spread against itself
-    r = torch.tensor([abs(float(r16[i] - r32[i])) / ulp(r16[i]) for _n, B, _s, r16, r32, *_x in cases for i in range(B)])
-    print(f"reference bf16 vs reference fp32: mean {r.mean():.2f} max {r.max():.1f} ulps")
-    out["ref_bf16_vs_ref_fp32"] = dict(mean_ulps=float(r.mean()), max_ulps=float(r.max()))
-    sp = os.path.join(G, "e2e_8b_r4_self.pt")
-    if os.path.exists(sp):
-        c = torch.load(sp, weights_only=True)["cases"]
-        a, b = c["batch4/seed0/t8"]["score1"].float(), c["batch4/seed0/t4"]["score1"].float()
-        s4 = [abs(float(a[i] - b[i])) / ulp(a[i]) for i in range(4)]
-        s1 = abs(float(c["alone/seed0/clip0/t1"]["score1"].float()[0] - c["alone/seed0/clip0/t8"]["score1"].float()[0])) / ulp(a[0])
-        print(f"reference vs itself: 8 vs 4 host threads {s4} ulps (mean {sum(s4) / 4:.2f}); 8 vs 1 threads, clip 0: {s1:.1f} ulps")
-        out["reference_vs_itself"] = dict(threads_8_vs_4_ulps=s4, threads_8_vs_1_clip0_ulps=s1)
-    if len(sys.argv) > 1:
-        json.dump(out, open(sys.argv[1], "w"), indent=1)
+    r = [abs(float(r16[i] - r32[i])) / ulp(r16[i]) for _n, B, _s, r16, r32, *_x in cases if r32 is not None for i in range(B)]
+    out["ref_bf16_vs_ref_fp32"] = stats(r)
+    print(f"reference bf16 vs reference fp32: {fmt(out['ref_bf16_vs_ref_fp32'])}")
+    pairs, flips, rows = reference_self_pairs(cases)
+    allp = [x for k, v in pairs.items() for x in v]
+    for k in sorted(pairs):
+        print(f"reference vs itself, {k:6s} against 8 host threads: {fmt(stats(pairs[k]))}")
+    if allp:
+        out["reference_vs_itself"] = dict(all=stats(allp), by_threads={k: stats(v) for k, v in pairs.items()}, level_tokens_flipped=flips, level_rows=rows,
+                                          identical=int(sum(1 for x in allp if x == 0)))
+        print(f"reference vs itself, all pairs: {fmt(out['reference_vs_itself']['all'])}, identical {out['reference_vs_itself']['identical']}/{len(allp)}; "
+              f"level tokens flipped {flips}/{rows}")
+    if args:
+        json.dump(out, open(args[0], "w"), indent=1)
 
 
 if __name__ == "__main__":

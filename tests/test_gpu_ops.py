@@ -184,6 +184,27 @@ def test_gemm_row_plan_is_batch_invariant(lib, N, K, epi):
             assert torch.equal(got[i * n:(i + 1) * n].view(torch.int16), both[sl].view(torch.int16))
 
 
+@pytest.mark.parametrize("lens,N,K", [([2176], 4096, 4096), ([2176], 6144, 4096), ([2176, 2176], 4096, 14336), ([300, 2176, 641], 1024, 3584), ([2233], 512, 2048)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_row_plan_fused_tail_slices_change_no_bit(lib, lens, N, K, epi):
+    """One or two clips leave the body's last round of CUs part empty; the tail tiles' K slices then run INSIDE the body's launch
+    (gemm256_kernel<.., FUSE>; AIGV_TUNE_FUSE_TAILS 0 = by fill, 1 = never, 2 = always).  Same slices, same slabs, same finalize pass:
+    the three settings give the same bits - which is why the choice may follow the batch's fill without touching batch invariance."""
+    from aigv_assessor_amd import native
+    g = torch.Generator().manual_seed(sum(lens) + N + K + epi)
+    A, W, bias, ls, resid, nout = _gemm_rows_case(g, lens, N, K, epi)
+    outs = []
+    try:
+        for fuse in (1, 2, 0):
+            native.check(lib.aigv_tune_default(12, fuse))
+            outs.append(_run_gemm_rows(lib, A, W, bias, ls, resid, nout, lens, epi))
+    finally:
+        native.check(lib.aigv_tune_default(12, 0))
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)) and torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+    ulp_check(outs[1], gemm_ref(A, W, epi, bias, ls, resid), frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
+
+
 @pytest.mark.parametrize("lens,N,K", [([2176], 512, 1024), ([1025] * 8, 1024, 1024), ([2176, 300, 1025], 1024, 3584), ([2233], 4096, 4096)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
 def test_gemm_row_plan_body_tile_changes_no_bit(lib, lens, N, K, epi):
