@@ -101,7 +101,7 @@ struct aigv_ctx {
   int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2 / 3 / 4
   // the other experiment knobs of this context (aigv_ctx_tune): -1 = follow the process default (aigv_tune_*)
   int t_order = -1, t_variant = -1, t_attn_waves = -1, t_skinny_p = -1, t_body_tile = -1, t_co_kmax = -1;
-  int t_tail_slices = -1, t_lead_key = -1, t_decode_fused = -1, t_decode_fp8 = -1, t_skinny_p8 = -1, t_fuse_tails = -1;
+  int t_tail_slices = -1, t_lead_key = -1, t_decode_fused = -1, t_decode_fp8 = -1, t_skinny_p8 = -1, t_fuse_tails = -1, t_lone_body = -1;
   size_t splitk_floats = 0;
   float* splitk_ws = nullptr;  // fp32 slabs of the split-K row bands: owned by the context (one launch stream per context at a time)
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 2 (attention out, normed) + [64, I], reused per 64 consumed rows
@@ -234,6 +234,7 @@ struct Tune {
   // fused-norm decode GEMVs (1 = on), e4m3 decode GEMVs in fp8 mode (1 = on), form of the e4m3 decode GEMVs (0 = per-GEMV defaults)
   int tail_slices = 0, lead_key = 0, decode_fused = 1, decode_fp8 = 1, skinny_p8 = 0;
   int fuse_tails = 0;   // tail K slices inside the body's launch: 0 = when the body leaves CUs idle, 1 = never, 2 = always (same bits each way)
+  int lone_body = 1;    // bodies of <= 128 tiles on the co-resident kernel's LONE form: 0 = by fill, 1 = never (default: no in-step gain measured), 2 = always (same bits each way)
 };
 Tune g_tune;
 // the knobs in force for a call: the context's own setting, else the process default
@@ -254,6 +255,7 @@ Tune tune_of(const aigv_ctx* c) {
     if (c->t_decode_fp8 >= 0) t.decode_fp8 = c->t_decode_fp8;
     if (c->t_skinny_p8 >= 0) t.skinny_p8 = c->t_skinny_p8;
     if (c->t_fuse_tails >= 0) t.fuse_tails = c->t_fuse_tails;
+    if (c->t_lone_body >= 0) t.lone_body = c->t_lone_body;
   }
   return t;
 }
@@ -602,7 +604,23 @@ int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hi
   // (profiles/r4_negatives.txt, 6); body_tile = 2 keeps the 128 form reachable for tests.
   const bool body128 = rp.body_halves > 0 && tune_of(c).body_tile == 2;
   const bool tails_apart = rp.tail_halves > 0 && S > 1;
-  if (body128) {
+  // A body of at most 128 tiles (one clip's wo / w2, eight frames' proj / fc2) leaves half the CUs idle: the co-resident kernel's LONE form
+  // (gemmco.hip VAR 6: 256 x 128 tiles, one 8-wave workgroup per CU, four of the waves only issue the LDS-DMA requests) gives every CU a
+  // tile - the same bits as the 256 kernel, 18-24 % less time on these bodies in isolation (scripts/gemm_body_ab.py) and NOTHING inside the
+  // one-clip forward (37.9-38.1 ms per clip either way: profiles/r5_loop_shape.txt; the tail's K slices can no longer ride in the idle half of
+  // the chip, and the SlowFast branch's side-stream kernels lose the CUs the half-empty bodies left them).  Off by default (lone_body = 1).
+  const long body_tiles = (long)(rp.body_halves / 2) * (a.N / 256);
+  const int lone_knob = tune_of(c).lone_body;   // 0 = by fill, 1 = never, 2 = whenever the shapes allow
+  const bool lone = !body128 && lone_knob != 1 && rp.body_halves > 0 && a.N % 128 == 0 &&
+                    (lone_knob == 2 || (body_tiles <= 128 && (!tails_apart || a.K / 64 >= 128) && (lone_knob != 3 || tails_apart) && (lone_knob != 4 || !tails_apart)));
+  if (lone) {
+    GemmArgs b = tuned(c, a);
+    b.row_tab = rp.d_tab; b.tab_halves = tails_apart ? rp.body_halves : rp.body_halves + rp.tail_halves;
+    b.variant_sel = 7;
+    GemmArgs pf = a; pf.M = rp.body_halves * 128 + (tails_apart ? 0 : rp.tail_rows);
+    GEMM_PROF(c, pf, s);
+    HIPCHK(c, aigv_launch_gemmco(b, epi, s));
+  } else if (body128) {
     {
       GemmArgs b = a;
       b.row_tab = rp.d_tab; b.tab_halves = rp.body_halves;
@@ -621,7 +639,7 @@ int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hi
     const size_t need = (size_t)S * ((rp.tail_halves + 1) / 2) * 256 * a.N;
     const int fuse_knob = tune_of(c).fuse_tails;   // 0 = by fill, 1 = never, 2 = whenever the shapes allow
     const bool by_fill = body_wg % 256 != 0 && body_wg % 256 + slice_wg <= 320;
-    if (rp.body_halves > 0 && (rp.body_halves & 1) == 0 && need <= (c ? c->splitk_floats : SPLITK_MAX_FLOATS) && fuse_knob != 1 && (by_fill || fuse_knob == 2)) {
+    if (!lone && rp.body_halves > 0 && (rp.body_halves & 1) == 0 && need <= (c ? c->splitk_floats : SPLITK_MAX_FLOATS) && fuse_knob != 1 && (by_fill || fuse_knob == 2)) {
       float* ws = nullptr;
       TRY(splitk_scratch(c, need, &ws));
       GemmArgs b = tuned(c, a);
@@ -634,7 +652,7 @@ int run_gemm_rows(aigv_ctx* c, const GemmArgs& a, int epi, const RowPlan& rp, hi
       HIPCHK(c, aigv_launch_gemm_finalize(f, epi, S, ws, s));
       return run_tiny_tails(c, a, epi, rp, s);
     }
-    TRY(launch_tab(c, a, epi, rp.d_tab, rp.body_halves, rp.body_halves * 128, 1, s));
+    if (!lone) TRY(launch_tab(c, a, epi, rp.d_tab, rp.body_halves, rp.body_halves * 128, 1, s));
   }
   if (tails_apart) {
     const size_t per_pair = (size_t)S * 256 * a.N;
@@ -1714,7 +1732,7 @@ int aigv_ctx_tune(aigv_ctx* c, int knob, int value) {
       if (value < -1 || value > 15) break;
       c->t_order = value; return 0;
     case AIGV_TUNE_GEMM256_VARIANT:
-      if (value < -1 || value > 6) break;
+      if (value < -1 || value > 7) break;
       c->t_variant = value; return 0;
     case AIGV_TUNE_ATTN_WAVES:
       if (value != -1 && value != 0 && value != 4 && value != 8) break;
@@ -1743,6 +1761,9 @@ int aigv_ctx_tune(aigv_ctx* c, int knob, int value) {
     case AIGV_TUNE_FUSE_TAILS:
       if (value < -1 || value > 2) break;
       c->t_fuse_tails = value; return 0;
+    case AIGV_TUNE_LONE_BODY:
+      if (value < -1 || value > 4) break;
+      c->t_lone_body = value; return 0;
     case AIGV_TUNE_SKINNY_P8:
       if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4) break;
       c->t_skinny_p8 = value; return 0;
@@ -2153,7 +2174,7 @@ int aigv_tune_gemm(int mode, double rate256) {
   mode &= 1023;
   const int vsel = mode >> 4;
   mode &= 15;
-  if (mode < 0 || mode > 4 || vsel < 0 || vsel > 6)
+  if (mode < 0 || mode > 4 || vsel < 0 || vsel > 7)
     return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_gemm: mode must be 0 (auto), 1 (128 tile), 2 (256 tile), 3 (batch-level dispatch in the scoring pass) or 4 (co-resident 256x128 tile)");
   if (vsel > 0) g_tune.variant_sel = vsel;
   g_tune.gemm_mode = mode;
@@ -2166,6 +2187,7 @@ int aigv_tune_default(int knob, int value) {
   switch (knob) {
     case AIGV_TUNE_TAIL_SLICES: if (value < 0 || value > 16) break; g_tune.tail_slices = value; return 0;
     case AIGV_TUNE_FUSE_TAILS: if (value < 0 || value > 2) break; g_tune.fuse_tails = value; return 0;
+    case AIGV_TUNE_LONE_BODY: if (value < 0 || value > 2) break; g_tune.lone_body = value; return 0;
     case AIGV_TUNE_ATTN_LEAD_KEY: if (value < 0 || value > 1) break; g_tune.lead_key = value; return 0;
     case AIGV_TUNE_CO_KMAX: return aigv_tune_co_gemm(value);
     default: return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_default: knob %d has no process default here (aigv_tune_gemm / _attention / _skinny set the others)", knob);

@@ -72,11 +72,18 @@ __device__ __forceinline__ void co_glds16(const char* sbase, unsigned voff, unsi
 
 // VAR 0: the reads, DMA requests and MFMAs of a K-tile in blocks (first version, kept for A/B); VAR 1: interleaved - one fragment read or
 // DMA request between consecutive MFMAs, so that a wave's own matrix work covers its load issue
+// VAR 6: the LONE form for launches of at most one workgroup per CU (one clip's wo / w2 bodies: 256 tiles of 256 x 128 where the 256 x 256 kernel
+//        has 128): eight waves, waves 0-3 multiply (and never issue a DMA request), waves 4-7 only issue the LDS-DMA requests - a lone 4-wave
+//        workgroup has no neighbour to cover the ~60 issue cycles of each request, here the loader waves take them off the multiplying waves'
+//        instruction streams.  Same ring, same barriers, same MFMA chains: the same bits.
 template <int EPI, int VAR>
-__global__ __launch_bounds__(256, 2) void gemmco_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(VAR == 6 ? 512 : 256, 2) void gemmco_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool LONE = VAR == 6;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = LONE && wave_id >= 4;
+  const int wave = loader ? wave_id - 4 : wave_id;   // index among the multiplying (or the loading) waves
   const int g = wave >> 1, wc = wave & 1;
 
   // ---- tile mapping: XCD-aware bijective remap, then groups of CO_GROUP_M row tiles sweep the column tiles (or column groups sweep the rows) ----
@@ -278,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void gemmco_kernel(const GemmArgs p) {
   // VAR 3 = no workgroup barriers either (results are garbage: what the loop costs without its memory stream / its rendezvous)
   //                                                       VAR 4 = every DMA request but no vmcnt wait (issue + traffic without the landing
   //                                                       latency), VAR 5 = the same with the A units only (4 of 6)
-  constexpr bool DIAG_NODMA = VAR == 2 || VAR == 3, DIAG_NOBAR = VAR == 3, DIAG_NOWAIT = VAR >= 4, DIAG_AONLY = VAR == 5;
+  // (VAR 6: the multiplying waves run the no-DMA stream for real - the loader waves own the requests and the vmcnt waits)
+  constexpr bool DIAG_NODMA = VAR == 2 || VAR == 3 || LONE, DIAG_NOBAR = VAR == 3, DIAG_NOWAIT = VAR == 4 || VAR == 5, DIAG_AONLY = VAR == 5;
   auto tile_body_i = [&](int t, int base, auto PAR, auto FIRST) __attribute__((always_inline)) {
     constexpr int par = decltype(PAR)::value;
     constexpr bool first = decltype(FIRST)::value;
@@ -352,7 +360,28 @@ __global__ __launch_bounds__(256, 2) void gemmco_kernel(const GemmArgs p) {
   };
 
   // ---- prologue: the six units of tile 0 ----
-  dma(0, I0{}, 0); dma(0, I1{}, 1); dma(0, I2{}, 2); dma(0, I3{}, 3); dma(0, I4{}, 4); dma(0, I5{}, 5);
+  if (!LONE || loader) { dma(0, I0{}, 0); dma(0, I1{}, 1); dma(0, I2{}, 2); dma(0, I3{}, 3); dma(0, I4{}, 4); dma(0, I5{}, 5); }
+  if constexpr (LONE) {
+    if (loader) {   // the loader waves: the waits, barriers and requests of tile_body_i, nothing else
+      int lbase = 0;
+      for (int t = 0; t < nk; ++t) {
+        const bool more = t + 1 < nk;
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        CO_SB(); CO_BARRIER(); CO_SB();   // Y(t)
+        if (more) {
+          dma(t + 1, I0{}, wrap(lbase + 6)); dma(t + 1, I1{}, wrap(lbase + 7)); dma(t + 1, I2{}, wrap(lbase + 8)); dma(t + 1, I3{}, wrap(lbase + 9));
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        CO_SB(); CO_BARRIER(); CO_SB();   // X(t)
+        if (more) { dma(t + 1, I4{}, lbase); dma(t + 1, I5{}, wrap(lbase + 1)); }
+        lbase = wrap(lbase + 6);
+      }
+      CO_BARRIER();   // the multiplying waves' "ring is free" barrier
+      return;
+    }
+  }
 
   using T = std::true_type;
   using F = std::false_type;
@@ -369,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void gemmco_kernel(const GemmArgs p) {
   if ((nk - 1) & 1) mfma16(I1{}, I1{}); else mfma16(I1{}, I0{});
   CO_SB();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if constexpr (VAR >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (diagnostic variants without in-loop waits)
+  if constexpr (VAR == 4 || VAR == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (diagnostic variants without in-loop waits)
   CO_BARRIER();   // every wave is past its last fragment read: the ring is free for the epilogue's staging
   CO_SB();
 
@@ -472,7 +501,7 @@ hipError_t launch_co_v(const GemmArgs& a, hipStream_t s) {
   // tile order as in gemm256.hip: small weights -> an XCD owns row tiles and sweeps W; large weights -> an XCD owns a slice of W
   const bool big_w = (size_t)a.N * (size_t)a.K >= ((size_t)32 << 20);
   b.order = a.order_sel > 0 ? a.order_sel - 1 : (big_w && nbm >= 32 ? 8 : 0);
-  hipLaunchKernelGGL((gemmco_kernel<EPI, VAR>), dim3(nbm * nbn), dim3(256), CO_LDS, s, b);
+  hipLaunchKernelGGL((gemmco_kernel<EPI, VAR>), dim3(nbm * nbn), dim3(VAR == 6 ? 512 : 256), CO_LDS, s, b);
   return hipGetLastError();
 }
 // GemmArgs::variant_sel: 0 = the shipped schedule, 1 + v = schedule variant v (A/B: AIGV_TUNE_GEMM256_VARIANT / aigv_tune_gemm bits 4..6)
@@ -484,6 +513,7 @@ hipError_t launch_co(const GemmArgs& a, hipStream_t s) {
   if (a.variant_sel == 5) return launch_co_v<EPI, 4>(a, s);
   if (a.variant_sel == 6) return launch_co_v<EPI, 5>(a, s);
 #endif
+  if (a.variant_sel == 7) return launch_co_v<EPI, 6>(a, s);   // the lone form (eight waves, four of them loaders)
   return (a.variant_sel == 1) ? launch_co_v<EPI, 0>(a, s) : launch_co_v<EPI, 1>(a, s);
 }
 

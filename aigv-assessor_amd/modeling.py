@@ -1211,7 +1211,7 @@ class InternVLChatModel(nn.Module):
         native.check(lib.aigv_set_gemm_mode(ctx, int(mode)), ctx)
 
     TUNE_KNOBS = {"gemm_mode": 0, "gemm256_order": 1, "gemm256_variant": 2, "attn_waves": 3, "skinny_p": 4, "body_tile": 5, "co_kmax": 6,
-                  "tail_slices": 7, "attn_lead_key": 8, "decode_fused": 9, "decode_fp8": 10, "skinny_p8": 11, "fuse_tails": 12}
+                  "tail_slices": 7, "attn_lead_key": 8, "decode_fused": 9, "decode_fp8": 10, "skinny_p8": 11, "fuse_tails": 12, "lone_body": 13}
 
     def tune(self, knob: str, value: int = -1):
         """Experiment knobs of THIS model's context (aigv_ctx_tune; -1 = follow the process default): tests and A/B runs only."""

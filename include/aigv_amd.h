@@ -294,7 +294,8 @@ enum aigv_tune_knob {
   AIGV_TUNE_DECODE_FUSED = 9,    /* decode: 1 (default) = RMSNorm inside the GEMV that consumes it, 0 = separate norm kernels */
   AIGV_TUNE_DECODE_FP8 = 10,     /* decode in fp8 mode: 1 (default) = e4m3 GEMVs, 0 = bf16 GEMVs */
   AIGV_TUNE_SKINNY_P8 = 11,      /* form of the e4m3 decode GEMVs: 0 per-GEMV defaults, 1 / 2 / 4 */
-  AIGV_TUNE_FUSE_TAILS = 12      /* the tail tiles' K slices inside the body's launch: 0 = when the body leaves CUs idle (default), 1 = never, 2 = always; same bits */
+  AIGV_TUNE_FUSE_TAILS = 12,     /* the tail tiles' K slices inside the body's launch: 0 = when the body leaves CUs idle (default), 1 = never, 2 = always; same bits */
+  AIGV_TUNE_LONE_BODY = 13       /* row-plan bodies of <= 128 tiles on the 256x128 kernel's one-workgroup-per-CU form: 0 = by fill, 1 = never (default), 2 = always, 3 / 4 = by fill for GEMMs with / without split-K tails; same bits */
 };
 int aigv_ctx_tune(aigv_ctx* ctx, int knob, int value);
 /* GEMM tile-kernel selection: mode 0 = cost model (default), 1 = always the 128x128 kernel, 2 = always the 256x256
@@ -304,7 +305,7 @@ int aigv_ctx_tune(aigv_ctx* ctx, int knob, int value);
 int aigv_tune_gemm(int mode, double rate256);
 /* Process default of AIGV_TUNE_CO_KMAX: 0 = the co-resident 256x128 kernel is never chosen by the dispatcher, else the largest K it takes. */
 int aigv_tune_co_gemm(int kmax);
-/* Process default of AIGV_TUNE_TAIL_SLICES / _FUSE_TAILS / _ATTN_LEAD_KEY / _CO_KMAX (value as in aigv_ctx_tune, without the -1). */
+/* Process default of AIGV_TUNE_TAIL_SLICES / _FUSE_TAILS / _LONE_BODY / _ATTN_LEAD_KEY / _CO_KMAX (value as in aigv_ctx_tune, without the -1). */
 int aigv_tune_default(int knob, int value);
 /* The row bands run_gemm would cut an M x N x K problem into (host logic only, no GPU): plan[0] = row tiles (x256 rows) on the
  * 256x256 kernel in whole rounds, or -1 = the whole problem in one launch of that kernel; plan[1] = row tiles on the 256x256

@@ -11,7 +11,7 @@ lib = native.load()
 BF = torch.bfloat16
 LLM = [("wqkv", 6144, 4096, 0), ("wo", 4096, 4096, 3), ("w1|w3", 28672, 4096, 4), ("w2", 4096, 14336, 3)]
 VIT = [("vit qkv", 3072, 1024, 0), ("vit proj", 1024, 1024, 2), ("vit fc1", 4096, 1024, 1), ("vit fc2", 1024, 4096, 2)]
-ARMS = [("rows: 256 body + split-K tails", 0 + 32, 0), ("one launch, co-resident 256x128", 4 + 32, 0), ("one launch, 256x256", 2 + 32, 0)]
+ARMS = [("rows: 256 body + split-K tails", 0 + 32, 0), ("one launch, co-resident 256x128", 4 + 32, 0), ("one launch, 256x128 LONE form", 4 + 16 * 7, 0), ("one launch, 256x256", 2 + 32, 0)]
 
 
 def run(lens, N, K, epi, mode, co_kmax, iters=30):

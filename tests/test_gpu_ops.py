@@ -195,13 +195,16 @@ def test_gemm_row_plan_fused_tail_slices_change_no_bit(lib, lens, N, K, epi):
     A, W, bias, ls, resid, nout = _gemm_rows_case(g, lens, N, K, epi)
     outs = []
     try:
-        for fuse in (1, 2, 0):
+        for fuse, lone in ((1, 1), (2, 1), (0, 1), (1, 2), (0, 0)):   # AIGV_TUNE_FUSE_TAILS (12) x AIGV_TUNE_LONE_BODY (13: the body on gemmco.hip's LONE form)
             native.check(lib.aigv_tune_default(12, fuse))
+            native.check(lib.aigv_tune_default(13, lone))
             outs.append(_run_gemm_rows(lib, A, W, bias, ls, resid, nout, lens, epi))
     finally:
         native.check(lib.aigv_tune_default(12, 0))
+        native.check(lib.aigv_tune_default(13, 0))
     assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)) and torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+    for o in outs[1:]:
+        assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16))
     ulp_check(outs[1], gemm_ref(A, W, epi, bias, ls, resid), frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
@@ -287,6 +290,11 @@ def test_gemm_co_resident_kernel_equals_the_256_kernel_bit_for_bit(lib, M, N, K,
     assert torch.isfinite(co.float()).all()
     ref = _op_gemm_mode(lib, 2 if N % 256 == 0 else 1, 0, A, W, epi, bias, ls, resid)
     assert torch.equal(co.view(torch.int16), ref.view(torch.int16)), f"{int((co.view(torch.int16) != ref.view(torch.int16)).sum())} elements differ"
+    # its other two schedules: reads / requests / MFMAs in blocks (the first version), and the LONE form for launches of at most one workgroup
+    # per CU (eight waves, four of them only issue the LDS-DMA requests) - mode word 4 + 16 * (1 + variant)
+    for word in (4 + 16, 4 + 16 * 7):
+        other = _op_gemm_mode(lib, word, 0, A, W, epi, bias, ls, resid)
+        assert torch.equal(other.view(torch.int16), ref.view(torch.int16)), f"schedule word {word}: {int((other.view(torch.int16) != ref.view(torch.int16)).sum())} elements differ"
     ulp_check(co, gemm_ref(A, W, epi, bias, ls, resid), frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
     # and the default dispatch (mode 0) takes it for K <= 1024 and only then: same bits either way
     auto = _op_gemm_mode(lib, 0, 1024, A, W, epi, bias, ls, resid)
