@@ -97,7 +97,7 @@ struct aigv_ctx {
   RowPlan rp_vit, rp_llm;           // row plans of the InternViT frames (cached per chunk size) and of the current prefill's clips
   const RowPlan* cur_rp = nullptr;  // plan the InternLM2 layer helpers run under (null: batch-level dispatch, aigv_llm_extend)
   bool trim_last_layer = true;
-  int attn_round_scores = 1;   // prefill attention: the reference's bf16 rounding points of the score matrix (aigv_set_attention_numerics)
+  int attn_round_scores = 0;   // prefill attention: 1 = the reference's bf16 rounding points of the score matrix, 0 = fp32 scores (default since round 5: profiles/r5_parity_stats.txt)
   int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2 / 3 / 4
   // the other experiment knobs of this context (aigv_ctx_tune): -1 = follow the process default (aigv_tune_*)
   int t_order = -1, t_variant = -1, t_attn_waves = -1, t_skinny_p = -1, t_body_tile = -1, t_co_kmax = -1;

@@ -156,10 +156,12 @@ int aigv_set_precision(aigv_ctx* ctx, int mode);
  * copy of those rows.  Rows are independent after attention, so the outputs are those of the untrimmed pass (up to the fp32
  * summation order of the kernel that runs the few rows); off = every row through every layer, as the reference does. */
 int aigv_set_row_trimming(aigv_ctx* ctx, int on);
-/* Numerics of the prefill attention (InternViT and InternLM2): 1 (default) = the score matrix carries the reference's rounding points -
- * s = bf16(q k^T), InternLM2 also bf16(s / sqrt(d)) (modeling_internlm2.py:417, modeling_intern_vit.py:153) - before the fp32 softmax;
- * 0 = scores stay fp32 (rounds 1-3: closer to an fp32 evaluation, but 4 instead of 1.5 bf16 ulps (mean) from the reference's scores at
- * full depth: tests/manual/attention_numerics_study.py; ~4 % faster).  P is rounded un-normalised in both modes (no measurable effect). */
+/* Numerics of the prefill attention (InternViT and InternLM2): 0 (default) = the score matrix stays fp32 up to the softmax; 1 = it carries
+ * the reference's rounding points - s = bf16(q k^T), InternLM2 also bf16(s / sqrt(d)) (modeling_internlm2.py:417,
+ * modeling_intern_vit.py:153).  At op level form 1 sits 4x closer to the reference's eager bf16 result; END TO END, over the 37 clips the
+ * imported reference was recorded on, it is NOT closer to the reference's scores (3.09 against 2.80 bf16 ulps mean; the reference moves
+ * 2.56 against itself with the host's thread count), it is farther from the reference's fp32 scores (3.59 against 2.01) and it costs
+ * 1.9 ms of a 116 ms step: profiles/r5_parity_stats.txt.  P is rounded un-normalised in both forms (no measurable effect). */
 int aigv_set_attention_numerics(aigv_ctx* ctx, int mode);
 /* GEMM tile choice of THIS context: -1 = follow the process default set by aigv_tune_gemm (the state after aigv_ctx_create),
  * 0 = the per-sequence row plan (aigv_op_gemm_rows: the default; a clip's / frame's bits do not depend on its batch mates),

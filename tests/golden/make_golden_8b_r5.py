@@ -150,7 +150,9 @@ def merge():
         for k in ("llm_config", "vision_config", "w_seed", "overrides"):
             assert out[k] == d[k], (p, k)
         for k, v in d["cases"].items():
-            assert k not in out["cases"], k
+            if k in out["cases"]:                                                # (one/201/t8, the reproduction check, is re-run by every threads phase)
+                assert torch.equal(out["cases"][k]["score1"], v["score1"]) and torch.equal(out["cases"][k]["logit"], v["logit"]), k
+                continue
             out["cases"][k] = v
     dst = os.path.join(HERE, "e2e_8b_r5.pt")
     torch.save(out, dst)
