@@ -340,6 +340,7 @@ class InternVLChatModel(nn.Module):
 
     def _invalidate(self):
         self._dirty = True
+        self._drop_graphs()
 
     @property
     def device(self):
@@ -602,14 +603,24 @@ class InternVLChatModel(nn.Module):
         row_of[mask] = torch.arange(cu[-1], device=input_ids.device)
         return input_ids[mask].contiguous(), cu, row_of
 
+    def _h2d(self, t):
+        """Host tensor -> device through pinned memory without blocking the host.  While a HIP graph is being captured (``capture_forward``)
+        the pinned staging buffer is kept alive with the graph: its replays copy from that very address."""
+        if t.is_cuda:
+            return t
+        pinned = t.contiguous().pin_memory()
+        keep = getattr(self, "_capture_keep", None)
+        if keep is not None:
+            keep.append(pinned)
+        return pinned.to(self.device, non_blocking=True)
+
     def _prefill(self, ids_packed, slot, cu, vis, n_vis, motion, score_rows, logit_rows, keep_kv=False, kv_cap=0):
         b = len(cu) - 1
         T = cu[-1]
         lib, ctx = self._native(n_tokens=T, n_clips=b, out_rows=len(logit_rows), kv_cap=kv_cap)
         dev = self.device
         def up(t, dt):   # host index arrays go up through pinned memory without blocking the host
-            t = t.to(dt).contiguous()
-            return t if t.is_cuda else t.pin_memory().to(dev, non_blocking=True)
+            return self._h2d(t.to(dt).contiguous())
         ids_d = up(ids_packed, torch.long)
         slot_d = up(slot, torch.int32)
         score = torch.empty(b, dtype=torch.float32, device=dev) if score_rows is not None else None
@@ -635,6 +646,10 @@ class InternVLChatModel(nn.Module):
             raise NotImplementedError("the eval pass takes default positions and no cache, like the reference drivers")
         if self.img_context_token_id is None:
             raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
+        if self._graph_replay_enabled and self._capture_keep is None:
+            out = self._forward_through_graph(mos, pixel_values, input_ids, attention_mask, image_flags, labels, motion_feature, visual_tokens, full_logits)
+            if out is not None:
+                return out
         B, N = input_ids.shape
         n_frames = visual_tokens.shape[0] if visual_tokens is not None else pixel_values.shape[0]
         # ---- index bookkeeping first, on the host (one small D2H copy if the ids live on the device), so that
@@ -648,6 +663,66 @@ class InternVLChatModel(nn.Module):
         score, amax = self._prefill(plan["ids_packed"], plan["slot"], plan["cu"], vit_embeds, plan["n_vis"], motion,
                                     plan["score_rows"], plan["logit_rows"])
         return self._outputs(plan, B, N, score, amax, mos)
+
+    # ---- HIP-graph replay of whole scoring passes (opt-in: enable_graph_replay) ---------------------------------------------------------
+    _graph_replay_enabled = False
+    _capture_keep = None
+    GRAPH_CACHE_SIZE = 8
+
+    def enable_graph_replay(self, on: bool = True):
+        """``forward`` calls whose HOST-side arguments (token ids, masks, labels, frame flags, options) and tensor shapes repeat - the
+        reference's eval loop scores every clip behind the same prompt (stage2_eval.py:908-941) - are captured into a HIP graph on their
+        second occurrence and replayed from the third on: ONE host call launches the ~1000 kernels of the pass (InternViT, projector,
+        SlowFast side stream, InternLM2, heads), the frames are copied into the graph's input buffer first.  Same kernels, same bits
+        (tests/test_gpu_api.py); what changes is the host time per pass (5-6 ms -> ~0.1 ms) - decisive where the host is slower than the
+        GPU's launch stream (a CPU-throttled container: 314 -> 115 ms per step measured, profiles/r5_graph_replay.txt).  Off by default;
+        any weight / mode / knob change drops the captured graphs."""
+        self._graph_replay_enabled = bool(on)
+        self._graphs = {}
+
+    def _drop_graphs(self):
+        if getattr(self, "_graphs", None):
+            self._graphs = {}
+
+    def _forward_through_graph(self, mos, pixel_values, input_ids, attention_mask, image_flags, labels, motion_feature, visual_tokens, full_logits):
+        """The replay path of ``forward``; returns None when the call does not qualify (the eager path then runs)."""
+        if (mos is not None or visual_tokens is not None or pixel_values is None or not pixel_values.is_cuda or self._dirty or self._ctx is None or getattr(self, "_prof_on", False)
+                or (motion_feature is not None and not motion_feature.is_cuda)):
+            return None
+        host = lambda t: None if t is None else t.detach().to("cpu").contiguous()
+        parts = [host(input_ids), host(attention_mask), host(labels), host(image_flags)]
+        key = (tuple(pixel_values.shape), pixel_values.dtype, None if motion_feature is None else tuple(motion_feature.shape), bool(full_logits),
+               int(self.img_context_token_id), id(self.slowfast_model), bool(getattr(self, "overlap_motion_branch", True)),
+               bool(getattr(self, "drop_dead_tail", True)),
+               tuple(None if t is None else (tuple(t.shape), t.dtype, t.numpy().tobytes()) for t in parts))
+        graphs = self.__dict__.setdefault("_graphs", {})
+        ent = graphs.get(key)
+        if ent is None:                      # first occurrence: eager (sizes the context, warms every kernel); remember the key
+            if len(graphs) >= self.GRAPH_CACHE_SIZE:
+                graphs.pop(next(iter(graphs)))
+            graphs[key] = "seen"
+            return None
+        if ent == "seen":                    # second occurrence: capture, on static copies of the device inputs
+            pv_static = pixel_values.clone()
+            mf_static = None if motion_feature is None else motion_feature.clone()
+            try:
+                replay, outputs = self.capture_forward(mos=None, pixel_values=pv_static, input_ids=input_ids, attention_mask=attention_mask, image_flags=image_flags,
+                                                       labels=labels, motion_feature=mf_static, full_logits=full_logits)
+            except Exception:                # a pass that does not capture (an allocation or a synchronisation inside it) stays eager for good
+                graphs[key] = "eager"
+                torch.cuda.synchronize(self.device)
+                return None
+            ent = graphs[key] = (replay, outputs, pv_static, mf_static)
+            replay()
+            return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in outputs.items()}
+        if ent == "eager":
+            return None
+        replay, outputs, pv_static, mf_static = ent
+        pv_static.copy_(pixel_values)
+        if mf_static is not None:
+            mf_static.copy_(motion_feature)
+        replay()
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in outputs.items()}   # (the graph's own output tensors are overwritten by the next replay)
 
     def _plan(self, input_ids, attention_mask, labels, image_flags, n_frames, full_logits=False, drop_dead_tail=None):
         """Host-side token bookkeeping of one pass: packed ids, which packed row takes which visual / motion token
@@ -726,13 +801,12 @@ class InternVLChatModel(nn.Module):
             visual_tokens = self.vit_tokens(pixel_values)
         vit_embeds = self.project(visual_tokens)                       # [F, ntok, H]
         if plan["flags_h"] is not None and int(plan["keep"].numel()) != plan["n_frames"]:
-            vit_embeds = vit_embeds[plan["keep"].pin_memory().to(self.device, non_blocking=True)]
+            vit_embeds = vit_embeds[self._h2d(plan["keep"])]
         return vit_embeds.reshape(-1, H), self.motion_embed(motion_feature)
 
     def _outputs(self, plan, B, N, score, amax, mos):
         dev = self.device
-        def up(t):   # host -> device through pinned memory, never blocking the host (keeps the CPU ahead of the GPU)
-            return t if t.is_cuda else t.contiguous().pin_memory().to(dev, non_blocking=True)
+        up = self._h2d   # host -> device through pinned memory, never blocking the host (keeps the CPU ahead of the GPU)
         logit = torch.full((B * (N - 1),), -1, dtype=torch.long, device=dev)
         if len(plan["logit_rows"]):
             logit.index_copy_(0, up(plan["want"].reshape(-1).nonzero().flatten()), amax)   # index list built on the host: no sync
@@ -1186,6 +1260,7 @@ class InternVLChatModel(nn.Module):
         """"bf16" (default: the reference's dtype flow) or "fp8": the InternLM2 prefill linears of ``forward`` on the e4m3 MFMA with
         per-channel weight scales and per-token activation scales (BASELINE config 5; aigv_set_precision in include/aigv_amd.h).
         The reference has no fp8 path; scores move by the quantisation noise documented in DESIGN.md."""
+        self._drop_graphs()
         if mode not in ("bf16", "fp8"):
             raise ValueError("precision must be 'bf16' or 'fp8'")
         self._precision = mode
@@ -1198,6 +1273,7 @@ class InternVLChatModel(nn.Module):
         imported reference was recorded on the two are equally far from its bf16 scores (2.80 / 3.09 bf16 ulps mean; the reference against
         itself under other host thread counts: 2.56), "fp32" is closer to its fp32 scores (2.01 / 3.59) and ~1.6 % faster
         (profiles/r5_parity_stats.txt)."""
+        self._drop_graphs()
         if mode not in ("reference", "fp32"):
             raise ValueError("attention numerics must be 'reference' or 'fp32'")
         self._attn_numerics = 1 if mode == "reference" else 0
@@ -1208,6 +1284,7 @@ class InternVLChatModel(nn.Module):
         """GEMM tile choice of this model's context (aigv_set_gemm_mode): -1 process default, 0 per-clip / per-frame row plans (the
         default: batch-invariant bits), 1 every row on the 128x128 kernel, 2 the 256x256 kernel wherever it applies (both full K: test
         aliases), 3 the batch-level cost-model dispatch of rounds 1-3 (A/B only)."""
+        self._drop_graphs()
         self._gemm_mode = int(mode)
         lib, ctx = self._native()
         native.check(lib.aigv_set_gemm_mode(ctx, int(mode)), ctx)
@@ -1217,13 +1294,37 @@ class InternVLChatModel(nn.Module):
 
     def tune(self, knob: str, value: int = -1):
         """Experiment knobs of THIS model's context (aigv_ctx_tune; -1 = follow the process default): tests and A/B runs only."""
+        self._drop_graphs()
         lib, ctx = self._native()
         native.check(lib.aigv_ctx_tune(ctx, self.TUNE_KNOBS[knob], int(value)), ctx)
+
+    def capture_forward(self, **forward_kwargs):
+        """One scoring pass captured into a HIP graph (torch.cuda.CUDAGraph: every launch ``forward`` makes through the C ABI on torch's
+        current stream, the SlowFast branch on its side stream, the small index uploads) -> ``(replay, outputs)``: ``replay()`` re-runs the
+        ~1000 launches of the pass with ONE host call and refreshes ``outputs`` (the dict ``forward`` returned, static tensors) from the
+        CURRENT contents of the input tensors' device memory; host-side arguments (token ids, labels, masks) are frozen at capture time.
+        For callers whose host cannot keep up with the launch stream (a CPU-throttled container): same kernels, same bits.  The context
+        must be warm (one eager ``forward`` of the same shapes first); profiling brackets must be off."""
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        self._capture_keep = []
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+                outputs = self.forward(**forward_kwargs)
+            keep = self._capture_keep
+        finally:
+            self._capture_keep = None
+
+        def replay(_graph=graph, _keep=keep):
+            _graph.replay()
+            return outputs
+        return replay, outputs
 
     def set_row_trimming(self, on: bool = True):
         """Last-layer row trimming (default on): the last decoder layer finishes only the rows whose hidden state is
         consumed (score row + answer rows; stage2_eval.py:940-941, modeling_internvl_chat.py:469-481).  Off = every row
         through every layer, as the reference computes it; the returned values are the same."""
+        self._drop_graphs()
         self._row_trim = bool(on)
         lib, ctx = self._native()
         native.check(lib.aigv_set_row_trimming(ctx, int(on)), ctx)
@@ -1231,6 +1332,8 @@ class InternVLChatModel(nn.Module):
 
     # ---- measurement ---------------------------------------------------------------------------------------
     def prof_enable(self, on: bool = True):
+        self._drop_graphs()
+        self._prof_on = bool(on)        # (per-launch HIP events: such passes are not replayed from a graph)
         lib, ctx = self._native()
         native.check(lib.aigv_prof_enable(ctx, int(on)), ctx)
 

@@ -557,6 +557,60 @@ def test_reference_eval_loop_shape_batch_1_with_ingest(rig):
     assert len(rows) == 3 and 0.0 <= stats["acc"] <= 1.0
 
 
+def test_graph_replay_scores_like_the_eager_pass():
+    """enable_graph_replay: forward calls whose host-side arguments repeat (the reference's eval loop: every clip behind the same prompt,
+    stage2_eval.py:908-941) are captured into a HIP graph on their second occurrence and replayed afterwards - one host call per pass.
+    Same kernels, same bits: scores and level tokens of different clips through the replayed graph equal the eager pass exactly, with the
+    SlowFast branch (its side stream forks and joins inside the capture) and with the motion feature as an input; a second prompt gets
+    its own graph; a mode change drops the graphs; outputs of one call survive the next."""
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    from aigv_assessor_amd.slowfast import SlowFastR50
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    model = InternVLChatModel(cfg)
+    model.load_state_dict(synth.make_state_dict(cfg, seed=71, rich=True))
+    model.eval().cuda()
+    B, T = 2, 8                                                             # (the SlowFast branch needs >= 8 frames per clip)
+    toks = synth.canonical_tokens(cfg, B, T, seed=71)
+    model.img_context_token_id = toks["img_context_token_id"]
+    flags = torch.ones(B * T, 1, dtype=torch.long)
+    frames = [synth.synthetic_frames(B * T, 224, seed=100 + i).cuda() for i in range(5)]
+    motions = [synth.synthetic_motion(B, cfg.motion_dim, seed=100 + i).cuda() for i in range(5)]
+    labels2 = toks["labels"].clone()
+    ans = (labels2[0] != -100).nonzero().flatten()
+    labels2[:, int(ans[0]) - 3:int(ans[0])] = toks["input_ids"][:, int(ans[0]) - 3:int(ans[0])]     # a second "prompt": three more consumed rows
+
+    def run(i, labels, motion):
+        o = model(mos=None, pixel_values=frames[i], input_ids=toks["input_ids"], attention_mask=toks["attention_mask"], image_flags=flags, labels=labels,
+                  motion_feature=motions[i] if motion else None)
+        torch.cuda.synchronize()
+        return o["score1"].clone(), o["logit"].clone()
+
+    for with_slowfast in (False, True):
+        model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=3)) if with_slowfast else None
+        motion = not with_slowfast
+        model.enable_graph_replay(False)
+        eager = [run(i, toks["labels"], motion) for i in range(5)]
+        eager2 = [run(i, labels2, motion) for i in range(3)]
+        model.enable_graph_replay(True)
+        got = [run(i, toks["labels"], motion) for i in range(5)]          # call 0 eager, call 1 captures, calls 2-4 replay
+        assert len(model._graphs) == 1 and isinstance(next(iter(model._graphs.values())), tuple)
+        got2 = [run(i, labels2, motion) for i in range(3)]                # another key: its own graph
+        assert len(model._graphs) == 2
+        for (s, l), (es, el) in zip(got + got2, eager + eager2):
+            assert torch.equal(s, es) and torch.equal(l, el)
+        held = model(mos=None, pixel_values=frames[0], input_ids=toks["input_ids"], attention_mask=toks["attention_mask"], image_flags=flags, labels=toks["labels"],
+                     motion_feature=motions[0] if motion else None)
+        run(1, toks["labels"], motion)                                    # the next replay must not overwrite what the caller holds
+        assert torch.equal(held["score1"], eager[0][0]) and torch.equal(held["logit"], eager[0][1])
+        model.set_gemm_mode(2)                                            # any mode change drops the graphs ...
+        assert not model._graphs
+        a = run(2, toks["labels"], motion)
+        model.set_gemm_mode(-1)
+        b = run(2, toks["labels"], motion)                                # ... and the default mode scores as before
+        assert torch.equal(b[0], eager[2][0]) and torch.equal(b[1], eager[2][1]) and torch.isfinite(a[0].float()).all()
+    model.enable_graph_replay(False)
+
+
 def test_experiment_knobs_live_in_the_context(rig):
     """aigv_ctx_tune: the kernel-form knobs are per context - a second model of the same process keeps its own forms -
     and every form computes the same scores up to fp32 summation order (tiny configuration: identical level tokens, score within one
