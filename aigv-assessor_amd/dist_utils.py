@@ -168,18 +168,26 @@ def score_clips_dp(model, pixel_values: torch.Tensor, input_ids: torch.Tensor, a
     fl = slice(clo * fpc, chi * fpc)
     # 0. the motion branch of this rank's CLIPS (it needs all frames of a clip) depends on the frames only: start it first - on the
     #    product model it runs on a side stream beside the ViT shard and the all-gather, and is joined where its result is consumed
-    motion_l = None
-    if chi > clo:
-        motion_l = motion_feature[sl] if motion_feature is not None else \
-            getattr(model, "motion_feature_async", model.motion_feature)(pixel_values[fl], chi - clo)
-    # 1-2. frame shard -> ViT tokens
     fsplit = even_split(F_total, world)
     lo, hi = fsplit[rank]
-    if hi > lo:
-        local = model.vit_tokens(pixel_values[lo:hi])
+    motion_l = None
+    if hasattr(model, "dp_front") and hi > lo:
+        # the product model: SlowFast of this rank's clips beside the ViT of its frame shard, as ONE call - a captured HIP graph when the model
+        # replays graphs (InternVLChatModel.enable_graph_replay), else exactly the two eager steps below
+        need_motion = chi > clo and motion_feature is None
+        local, motion_l = model.dp_front(pixel_values[lo:hi], pixel_values[fl] if need_motion else None, chi - clo)
+        if chi > clo and motion_feature is not None:
+            motion_l = motion_feature[sl]
     else:
-        probe = model.vit_tokens(pixel_values[:1])     # keeps shapes/dtypes uniform on idle ranks
-        local = probe[:0]
+        if chi > clo:
+            motion_l = motion_feature[sl] if motion_feature is not None else \
+                getattr(model, "motion_feature_async", model.motion_feature)(pixel_values[fl], chi - clo)
+        # 1-2. frame shard -> ViT tokens
+        if hi > lo:
+            local = model.vit_tokens(pixel_values[lo:hi])
+        else:
+            probe = model.vit_tokens(pixel_values[:1])     # keeps shapes/dtypes uniform on idle ranks
+            local = probe[:0]
     # 3. all-gather of pre-projector tokens: started here, completed where its result is first needed.  RCCL runs it on its own
     #    stream, so whatever this rank enqueues in between overlaps with it.
     finish_tokens = all_gather_rows_begin(local, [h - l for l, h in fsplit], group)

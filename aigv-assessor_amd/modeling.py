@@ -684,17 +684,11 @@ class InternVLChatModel(nn.Module):
         if getattr(self, "_graphs", None):
             self._graphs = {}
 
-    def _forward_through_graph(self, mos, pixel_values, input_ids, attention_mask, image_flags, labels, motion_feature, visual_tokens, full_logits):
-        """The replay path of ``forward``; returns None when the call does not qualify (the eager path then runs)."""
-        if (mos is not None or visual_tokens is not None or pixel_values is None or not pixel_values.is_cuda or self._dirty or self._ctx is None or getattr(self, "_prof_on", False)
-                or (motion_feature is not None and not motion_feature.is_cuda)):
-            return None
-        host = lambda t: None if t is None else t.detach().to("cpu").contiguous()
-        parts = [host(input_ids), host(attention_mask), host(labels), host(image_flags)]
-        key = (tuple(pixel_values.shape), pixel_values.dtype, None if motion_feature is None else tuple(motion_feature.shape), bool(full_logits),
-               int(self.img_context_token_id), id(self.slowfast_model), bool(getattr(self, "overlap_motion_branch", True)),
-               bool(getattr(self, "drop_dead_tail", True)),
-               tuple(None if t is None else (tuple(t.shape), t.dtype, t.numpy().tobytes()) for t in parts))
+    def _graph_call(self, host_key, dev_inputs, fn, clone_outputs=True):
+        """Graph-cached call of ``fn(*dev_inputs)`` (launches on torch's current stream only; device tensors in, a tensor / tuple / dict of
+        device tensors out): first occurrence of (host_key, input shapes) -> None (the caller runs eager); second -> capture on static copies
+        of the inputs; afterwards copy the inputs in, replay, hand the outputs back (cloned unless the caller consumes them at once)."""
+        key = (host_key, tuple(None if t is None else (tuple(t.shape), t.dtype) for t in dev_inputs))
         graphs = self.__dict__.setdefault("_graphs", {})
         ent = graphs.get(key)
         if ent is None:                      # first occurrence: eager (sizes the context, warms every kernel); remember the key
@@ -702,27 +696,78 @@ class InternVLChatModel(nn.Module):
                 graphs.pop(next(iter(graphs)))
             graphs[key] = "seen"
             return None
-        if ent == "seen":                    # second occurrence: capture, on static copies of the device inputs
-            pv_static = pixel_values.clone()
-            mf_static = None if motion_feature is None else motion_feature.clone()
-            try:
-                replay, outputs = self.capture_forward(mos=None, pixel_values=pv_static, input_ids=input_ids, attention_mask=attention_mask, image_flags=image_flags,
-                                                       labels=labels, motion_feature=mf_static, full_logits=full_logits)
-            except Exception:                # a pass that does not capture (an allocation or a synchronisation inside it) stays eager for good
-                graphs[key] = "eager"
-                torch.cuda.synchronize(self.device)
-                return None
-            ent = graphs[key] = (replay, outputs, pv_static, mf_static)
-            replay()
-            return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in outputs.items()}
         if ent == "eager":
             return None
-        replay, outputs, pv_static, mf_static = ent
-        pv_static.copy_(pixel_values)
-        if mf_static is not None:
-            mf_static.copy_(motion_feature)
-        replay()
-        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in outputs.items()}   # (the graph's own output tensors are overwritten by the next replay)
+        if ent == "seen":                    # second occurrence: capture, on static copies of the device inputs
+            statics = [None if t is None else t.clone() for t in dev_inputs]
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            self._capture_keep = []
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+                    outputs = fn(*statics)
+                keep = self._capture_keep
+            except Exception:                # a pass that does not capture (an allocation or a synchronisation inside it) stays eager for good
+                graphs[key] = "eager"
+                self._capture_keep = None
+                torch.cuda.synchronize(self.device)
+                return None
+            finally:
+                self._capture_keep = None
+            ent = graphs[key] = (graph, outputs, statics, keep)
+        graph, outputs, statics, _keep = ent
+        for st, t in zip(statics, dev_inputs):
+            if st is not None:
+                st.copy_(t)
+        graph.replay()
+        if not clone_outputs:
+            return outputs
+        cl = lambda v: v.clone() if torch.is_tensor(v) else v      # (the graph's own output tensors are overwritten by the next replay)
+        if isinstance(outputs, dict):
+            return {k: cl(v) for k, v in outputs.items()}
+        if isinstance(outputs, (tuple, list)):
+            return tuple(cl(v) for v in outputs)
+        return cl(outputs)
+
+    def _forward_through_graph(self, mos, pixel_values, input_ids, attention_mask, image_flags, labels, motion_feature, visual_tokens, full_logits):
+        """The replay path of ``forward``; returns None when the call does not qualify (the eager path then runs)."""
+        src = visual_tokens if visual_tokens is not None else pixel_values
+        if (mos is not None or src is None or not src.is_cuda or self._dirty or self._ctx is None or getattr(self, "_prof_on", False)
+                or (motion_feature is not None and not motion_feature.is_cuda) or (visual_tokens is not None and motion_feature is None)):
+            return None
+        host = lambda t: None if t is None else t.detach().to("cpu").contiguous()
+        parts = [host(input_ids), host(attention_mask), host(labels), host(image_flags)]
+        host_key = ("forward", visual_tokens is not None, bool(full_logits), int(self.img_context_token_id), id(self.slowfast_model),
+                    bool(getattr(self, "overlap_motion_branch", True)), bool(getattr(self, "drop_dead_tail", True)),
+                    tuple(None if t is None else (tuple(t.shape), t.dtype, t.numpy().tobytes()) for t in parts))
+        self._join_side_stream()             # (a motion feature started by motion_feature_async: joined BEFORE the graph copies it in)
+
+        def fn(src_static, mf_static):
+            return self.forward(mos=None, pixel_values=None if visual_tokens is not None else src_static, input_ids=input_ids, attention_mask=attention_mask,
+                                image_flags=image_flags, labels=labels, motion_feature=mf_static, full_logits=full_logits,
+                                visual_tokens=src_static if visual_tokens is not None else None)
+        return self._graph_call(host_key, [src, motion_feature], fn)
+
+    def dp_front(self, frames_local: torch.Tensor, frames_clips: Optional[torch.Tensor], n_clips: int):
+        """The data-parallel scorer's front half on this rank (dist_utils.score_clips_dp): the SlowFast feature of its own clips (side
+        stream) beside the InternViT tokens of its frame shard -> (tokens [F_local, ntok, 4 Hv], motion feature [n_clips, motion_dim] or
+        None).  With graph replay enabled the two run as ONE captured graph (joined at its end); the token all-gather and the projector +
+        InternLM2 half (``forward(visual_tokens=...)``, a graph of its own) follow on the host's side of the collective."""
+        def fn(fl, fc):
+            mf = self._motion_feature(fc, n_clips, None) if fc is not None else None
+            tok = self.vit_tokens(fl)
+            self._join_side_stream()
+            return tok, mf
+        if (self._graph_replay_enabled and self._capture_keep is None and frames_local.is_cuda and not self._dirty and self._ctx is not None
+                and not getattr(self, "_prof_on", False) and (frames_clips is None or (frames_clips.is_cuda and hasattr(self.slowfast_model, "features")))):
+            out = self._graph_call(("dp_front", int(n_clips), id(self.slowfast_model), bool(getattr(self, "overlap_motion_branch", True))),
+                                   [frames_local, frames_clips], fn, clone_outputs=False)
+            if out is not None:
+                return out
+        if frames_clips is None:
+            return self.vit_tokens(frames_local), None
+        mf = self.motion_feature_async(frames_clips, n_clips)       # eager: joined where forward() consumes it
+        return self.vit_tokens(frames_local), mf
 
     def _plan(self, input_ids, attention_mask, labels, image_flags, n_frames, full_logits=False, drop_dead_tail=None):
         """Host-side token bookkeeping of one pass: packed ids, which packed row takes which visual / motion token

@@ -451,7 +451,7 @@ def main():
     ap.add_argument("--serial-motion", action="store_true", help="A/B: run the SlowFast branch on the launch stream in front of the ViT instead of on a side stream beside it")
     ap.add_argument("--attn-numerics", default="fp32", choices=["reference", "fp32"],
                     help="prefill attention: 'fp32' keeps the score matrix in fp32 (default since round 5); 'reference' rounds it to bf16 where the reference's eager path does (A/B)")
-    ap.add_argument("--no-graph", action="store_true", help="A/B: launch every kernel of a step from the host (eager) instead of replaying the step's captured HIP graph (N = 1 only; N > 1 is always eager)")
+    ap.add_argument("--no-graph", action="store_true", help="A/B: launch every kernel of a step from the host (eager) instead of replaying the step's captured HIP graph(s)")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settling batches in front of the timed region")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode measurement appended after the timed region")
     ap.add_argument("--no-parity", action="store_true", help="skip the score / level comparison with the reference's recorded outputs (tests/golden/e2e_8b_r3.pt; ~1.5 min of CPU weight generation)")
@@ -581,7 +581,9 @@ def main():
     # N = 1: the step is captured into a HIP graph (InternVLChatModel.enable_graph_replay: first call eager, second captured, then replayed -
     # one host call per step instead of ~1000 launches; same kernels, same bits).  Three untimed priming steps make sure that the W warm-up
     # steps and everything behind them are replays whatever W is.  The per-launch roofline pass below runs eager (its HIP events are per launch).
-    graph_mode = (not dry) and world == 1 and not args.force_dp and not args.no_graph
+    # N > 1 (and --force-dp): the same per rank in two graphs - the front half (ViT shard + SlowFast of the rank's clips) and the projector +
+    # InternLM2 half - with the RCCL token all-gather between them launched from the host (score_clips_dp / InternVLChatModel.dp_front).
+    graph_mode = (not dry) and not args.no_graph
     if graph_mode:
         model.enable_graph_replay(True)
         for _ in range(3):
@@ -716,12 +718,14 @@ def main():
             "algorithmic_tflop_per_clip": fl["total"] / 1e12,
             "executed_tflop_per_clip": (fl["total"] if args.all_rows else fl["executed"]) / 1e12,
             "host_enqueue_ms_per_step": host_enqueue_ms,
-            "launch": ({"mode": "HIP graph replay: the step (InternViT, projector, SlowFast side stream, InternLM2, heads: ~1000 launches) captured once, one hipGraphLaunch "
-                                "per step; same kernels and bits as the eager step (InternVLChatModel.enable_graph_replay; --no-graph = eager)",
+            "launch": ({"mode": ("HIP graph replay: the step (InternViT, projector, SlowFast side stream, InternLM2, heads: ~1000 launches) captured once, one hipGraphLaunch "
+                                 "per step" if world == 1 and not args.force_dp else
+                                 "HIP graph replay: per rank two captured graphs per step (InternViT shard + SlowFast | projector + InternLM2 + heads) around the RCCL token "
+                                 "all-gather, which the host launches between them") + "; same kernels and bits as the eager step (InternVLChatModel.enable_graph_replay; --no-graph = eager)",
                         "eager_ms_per_step": eager_ms,
                         "eager_note": "the same step with every kernel launched from the host, 5 steps after the timed region; equal on a quiet host, up to 3x slower "
                                       "where the container's CPU quota throttles the launching thread (profiles/r5_graph_replay.txt)"} if graph_mode else
-                       {"mode": "eager: every kernel launched from the host" + (" (N > 1: the token all-gather sits between the launches)" if world > 1 else "")}),
+                       {"mode": "eager: every kernel launched from the host"}),
             "ms_per_step_by_rank": rank_ms,
             "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist.is_initialized() else None),
             "ranks_share_one_device": bool(os.environ.get("AIGV_BENCH_SHARE_DEVICE")),

@@ -43,6 +43,14 @@ def main():
             torch.cuda.synchronize()
             assert torch.equal(dp["score1"], plain["score1"]), (rank, B, T, prefer, dp["score1"], plain["score1"])
             assert torch.equal(dp["logit"], plain["logit"]) and torch.equal(dp["label"], plain["label"]), (rank, B, T, prefer)
+        # the same passes with HIP-graph replay (front half and projector + LLM half as captured graphs around the all-gather): ranks with
+        # and without clips, ragged frame shards - every call still the one-process forward, bit for bit
+        model.enable_graph_replay(True)
+        for i in range(4):
+            dp = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion, prefer_gathered=False)
+            torch.cuda.synchronize()
+            assert torch.equal(dp["score1"], plain["score1"]) and torch.equal(dp["logit"], plain["logit"]), (rank, B, T, "graph", i)
+        model.enable_graph_replay(False)
     dist.barrier()
     dist.destroy_process_group()
     print(f"DP_OK rank={rank}/{world} backend=gloo device={torch.cuda.get_device_name(dev)}")

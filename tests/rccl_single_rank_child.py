@@ -55,6 +55,15 @@ def main():
     torch.cuda.synchronize()
     assert torch.equal(dp["score1"], plain["score1"]) and torch.equal(dp["logit"], plain["logit"]) and torch.equal(dp["label"], plain["label"])
     assert torch.equal(dpg["score1"], plain["score1"]) and torch.equal(dpg["logit"], plain["logit"])
+    # 2b. the same with HIP-graph replay: the front half (ViT shard [+ SlowFast]) and the projector + InternLM2 half are each ONE captured graph,
+    #     the RCCL all-gather runs between them on the host's side (calls 1-2 eager / capture, then replays) - still the plain forward's bits
+    model.enable_graph_replay(True)
+    for i in range(4):
+        d2 = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion, prefer_gathered=bool(i & 1))
+        torch.cuda.synchronize()
+        assert torch.equal(d2["score1"], plain["score1"]) and torch.equal(d2["logit"], plain["logit"]), i
+    assert sum(1 for v in model._graphs.values() if isinstance(v, tuple)) >= 2, list(model._graphs.values())
+    model.enable_graph_replay(False)
     # 3. a rank-0-style reduction the driver uses (bench.py: all_reduce(MAX) of the step time)
     t = torch.tensor([1.5], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
