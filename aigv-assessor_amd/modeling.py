@@ -380,6 +380,7 @@ class InternVLChatModel(nn.Module):
         geom = (v.image_size if cfg.force_image_size is None else cfg.force_image_size, v.hidden_size, l.vocab_size,
                 self.select_layer)
         if self._ctx is None or want != key or geom != self._ctx_key:
+            self._drop_graphs()                  # captured graphs hold the old workspaces' addresses
             # same model, larger capacities: only the workspaces are re-allocated (aigv_ctx_resize), the weights stay on the device
             grow = self._ctx is not None and geom == self._ctx_key and not self._dirty
             if self._ctx is not None and not grow:
@@ -422,6 +423,7 @@ class InternVLChatModel(nn.Module):
             ntk = self._rope_seq_len(seq_len)
             if ntk != getattr(self, "_rope_ntk", 0):
                 self._rope_ntk = ntk
+                self._drop_graphs()              # (the rotary tables a captured pass reads are replaced)
                 if not self._dirty:
                     self._upload_rope()
         if self._dirty:

@@ -602,6 +602,18 @@ def test_graph_replay_scores_like_the_eager_pass():
                      motion_feature=motions[0] if motion else None)
         run(1, toks["labels"], motion)                                    # the next replay must not overwrite what the caller holds
         assert torch.equal(held["score1"], eager[0][0]) and torch.equal(held["logit"], eager[0][1])
+        # a larger batch grows the context's workspaces (aigv_ctx_resize): graphs captured on the old addresses must go, and the small pass
+        # scores as before afterwards (first call eager, then captured again)
+        if not with_slowfast:
+            B3 = 3
+            toks3 = synth.canonical_tokens(cfg, B3, T, seed=71)
+            model(mos=None, pixel_values=synth.synthetic_frames(B3 * T, 224, seed=9).cuda(), input_ids=toks3["input_ids"], attention_mask=toks3["attention_mask"],
+                  image_flags=torch.ones(B3 * T, 1, dtype=torch.long), labels=toks3["labels"], motion_feature=synth.synthetic_motion(B3, cfg.motion_dim, seed=9).cuda())
+            assert not any(isinstance(v, tuple) for v in model._graphs.values())
+            again = [run(i, toks["labels"], motion) for i in range(4)]
+            assert any(isinstance(v, tuple) for v in model._graphs.values())
+            for (s, l), (es, el) in zip(again, eager[:4]):
+                assert torch.equal(s, es) and torch.equal(l, el)
         model.set_gemm_mode(2)                                            # any mode change drops the graphs ...
         assert not model._graphs
         a = run(2, toks["labels"], motion)
