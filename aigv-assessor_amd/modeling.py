@@ -430,6 +430,19 @@ class InternVLChatModel(nn.Module):
             self._upload()
         return lib, self._ctx
 
+    def _rope_for_decode(self, kv_seq_len: int):
+        """Dynamic-NTK rope scaling during decode: the reference's rotary module rebuilds its tables, with the base of the CURRENT
+        ``kv_seq_len`` (cached keys + the new token, the padded width of the batch), whenever that exceeds what it has cached - i.e.
+        at every decode step past ``max_position_embeddings`` - and rotates only the new token's q / k with them; cached keys keep the
+        base they were rotated with (modeling_internlm2.py:187-194,227-243).  Here: the tables are rebuilt and swapped before such a step
+        (a host computation and two H2D copies per token - this far out, decode is not a throughput path)."""
+        ntk = self._rope_seq_len(kv_seq_len)
+        if ntk != getattr(self, "_rope_ntk", 0):
+            self._rope_ntk = ntk
+            self._drop_graphs()
+            torch.cuda.current_stream(self.device).synchronize()     # the previous step still reads the tables being replaced
+            self._upload_rope()
+
     def _upload_rope(self):
         """(Re)build the rotary tables: rows = the context's position capacity, base = the dynamic-NTK base of the current call."""
         lib, ctx = native.load(), self._ctx
@@ -966,10 +979,6 @@ class InternVLChatModel(nn.Module):
         b = len(cu) - 1
         longest = max(cu[i + 1] - cu[i] for i in range(b))
         last_rows = [cu[i + 1] - 1 for i in range(b)]
-        if self._rope_seq_len(longest + max_new_tokens):
-            # the reference recomputes the dynamic-NTK base at every decode step past max_position_embeddings
-            # (modeling_internlm2.py:227-235) while its cached keys keep the base they were rotated with
-            raise NotImplementedError("decoding past max_position_embeddings with dynamic-NTK rope scaling is not implemented")
         nb = beams["num_beams"] if beams else 1
         self._native(seq_len=longest, n_clips=b * nb, out_rows=b * nb)       # (beam search: room for every beam before the prompt pass)
         _, nxt = self._prefill(ids_packed, slot, cu, vis, n_vis, motion, None, last_rows, keep_kv=True,
@@ -977,6 +986,7 @@ class InternVLChatModel(nn.Module):
         lib, ctx = native.load(), self._ctx
         if beams:
             return self._beam_decode(b, [cu[i + 1] - cu[i] for i in range(b)], max_new_tokens, eos_ids, pad_id, processors or [], **beams)
+        ntk_decode = self._rope_seq_len(longest + max_new_tokens) != 0
         eos_a = (C.c_int64 * max(len(eos_ids), 1))(*[int(e) for e in eos_ids]) if eos_ids else None
         state = torch.zeros(b + 1, dtype=torch.int32, device=self.device)     # finished flags + live-column count (aigv_amd.h)
         # aigv_decode_eos takes at most 8 end ids (kernel-argument array): longer lists keep HF's bookkeeping in torch ops on the device -
@@ -1015,6 +1025,8 @@ class InternVLChatModel(nn.Module):
             if eos_ids and (step + 1) % self.EOS_CHECK_EVERY == 0 and bool(state[:b].all()):
                 break
             new = torch.empty_like(tok)
+            if ntk_decode:
+                self._rope_for_decode(longest + step + 1)
             native.check(lib.aigv_decode_step(ctx, tok.data_ptr(), new.data_ptr(), native.stream_ptr()), ctx)
             tok = pick(new).contiguous()
         out = torch.stack(outs, dim=1)
@@ -1045,9 +1057,13 @@ class InternVLChatModel(nn.Module):
             lens = [prompt_lens[s % b] + fed[0] for s in range(n)]
             native.check(lib.aigv_kv_reorder(ctx, native.i32_array(src), native.i32_array(lens), n, native.stream_ptr()), ctx)
 
+        ntk_decode = self._rope_seq_len(max(prompt_lens) + max_new_tokens) != 0
+
         def step(tok: torch.Tensor) -> torch.Tensor:
             t = tok.t().contiguous().view(-1)      # [b, nb] -> cache order
             new = torch.empty_like(t)
+            if ntk_decode:
+                self._rope_for_decode(max(prompt_lens) + fed[0] + 1)
             native.check(lib.aigv_decode_step(ctx, t.data_ptr(), new.data_ptr(), native.stream_ptr()), ctx)
             fed[0] += 1
             return self._row_logits(n).view(num_beams, b, V).transpose(0, 1)

@@ -411,14 +411,66 @@ def test_dynamic_ntk_rope_is_keyed_on_the_sequence_length_not_the_packed_batch(m
                            motion, toks["img_context_token_id"], stage=2, return_intermediates=True)
     same = torch.equal(plain["score1"], ref["score1"]) and torch.equal(plain["logit"], ref["logit"])
     assert same == (max_pos == 256)
-    with pytest.raises(NotImplementedError):      # decoding past max_pos with dynamic scaling is refused, not silently different
-        if max_pos == 128:
-            cfg.llm_config.rope_scaling = {"type": "dynamic", "factor": 2.0}
-            ids = toks["input_ids"][:, :200].clone()
-            ids[ids == toks["img_context_token_id"]] = 7
-            model._greedy(ids.reshape(-1), torch.full((400,), -1, dtype=torch.int32), [0, 200, 400], None, 0, 4, [], 0)
-        else:
-            raise NotImplementedError
+
+
+@pytest.mark.parametrize("case", ["cross", "beyond"])
+def test_decode_past_max_positions_with_dynamic_ntk(golden_dir, case):
+    """Decoding past max_position_embeddings with rope_scaling = dynamic (real checkpoints ship it): at every such step the reference
+    rebuilds its rotary tables with the base of the current kv_seq_len and rotates only the NEW token with them; cached keys keep the base
+    they were written with (modeling_internlm2.py:187-194,227-243).  Tokens recorded from the reference's own InternLM2 cache path
+    (tests/golden/ntk_decode.pt; the oracle reproduces them exactly: tests/test_oracle_golden.py) are fed back step by step (teacher
+    forcing through the logits-processor hook of the decode loop), so every step is checked on the reference's own history: its logits
+    against the oracle's, its choice against the reference's wherever the reference's top-2 gap is not a near-tie.  The same decode
+    with plain tables, or with tables frozen at the prompt's base, is far outside the tolerance (the check has power)."""
+    g = torch.load(os.path.join(golden_dir, "ntk_decode.pt"), weights_only=True)
+    c, L = g["cases"][case], g["llm_config"]
+    cfg = pkg.tiny(image_size=224, llm_hidden=L["hidden_size"], llm_heads=L["num_attention_heads"], llm_kv_heads=L["num_key_value_heads"],
+                   llm_layers=L["num_hidden_layers"], llm_inter=L["intermediate_size"], vocab=L["vocab_size"])
+    cfg.llm_config.max_position_embeddings = L["max_position_embeddings"]
+    cfg.llm_config.rope_scaling = dict(L["rope_scaling"])
+    sd = synth.make_state_dict(cfg, seed=g["seed"], rich=True)
+    b, n, new = c["b"], c["prompt"], c["new"]
+    ref_tok = c["tokens"]
+
+    def oracle_logits(scaling):
+        """per-step logits of the oracle's cache path on the reference's token history"""
+        cfg.llm_config.rope_scaling = scaling
+        mask = torch.ones(b, n, dtype=torch.long)
+        hidden, past, _ = O.llm_forward(sd, cfg, torch.nn.functional.embedding(c["ids"], O.embed_weight(sd)), mask.bool(), mask.cumsum(-1) - 1)
+        rows = []
+        for t in range(new):
+            rows.append(O.lm_logits(sd, hidden[:, -1:, :])[:, -1, :].float())
+            mask = torch.cat([mask, torch.ones(b, 1, dtype=torch.long)], 1)
+            hidden, past, _ = O.llm_forward(sd, cfg, torch.nn.functional.embedding(ref_tok[:, t:t + 1], O.embed_weight(sd)), mask.bool(),
+                                            (mask.cumsum(-1) - 1)[:, -1:], past)
+        cfg.llm_config.rope_scaling = dict(L["rope_scaling"])
+        return torch.stack(rows, 1)                              # [b, new, V]
+
+    want = oracle_logits(dict(L["rope_scaling"]))
+    assert torch.equal(want.argmax(-1), ref_tok)                  # the oracle IS the reference here
+    plain = oracle_logits(None)
+    model = make_model(cfg, sd)
+    seen = []
+
+    def force(hist, logits):                                      # record the step's logits, then continue on the reference's token
+        t = hist.shape[1]
+        seen.append(logits.float().cpu())
+        out = torch.full_like(logits, float("-inf"))
+        out[torch.arange(b), ref_tok[:, t].to(logits.device)] = 0
+        return out
+
+    cu = [i * n for i in range(b + 1)]
+    got = model._greedy(c["ids"].reshape(-1), torch.full((b * n,), -1, dtype=torch.int32), cu, None, 0, new, [], 0, processors=[force])
+    assert torch.equal(got.cpu(), ref_tok)
+    have = torch.stack(seen, 1)
+    assert model._rope_ntk == n + new - 1                         # the tables were rebuilt for the last decoded position's kv length
+    scale = want.abs().max().item()
+    err = (have - want).abs().max().item()
+    power = (plain - want).abs().max().item()
+    print(f"{case}: max |hip - oracle| logit {err:.4f} (logit scale {scale:.2f}); plain-table decode differs by {power:.4f}")
+    assert err <= 0.02 * scale and power >= 5 * err
+    clear = c["top2_gap"] >= 8 * err                              # the reference's choice is no near-tie at the path's own accuracy
+    assert torch.equal(have.argmax(-1)[clear], ref_tok[clear]) and int(clear.sum()) >= new // 3
 
 
 def test_greedy_generate_matches_oracle_cache_path():

@@ -366,3 +366,32 @@ def test_llama_weights_repack_to_the_internlm2_layout_and_back(e2e_llama):
     bad["language_model.model.layers.0.self_attn.q_proj.bias"] = torch.zeros(4096)
     with pytest.raises(NotImplementedError):
         weights.llama_to_internlm2(bad, cfg.llm_config)
+
+
+def _ntk_cfg(g):
+    L = g["llm_config"]
+    cfg = pkg.tiny(llm_hidden=L["hidden_size"], llm_heads=L["num_attention_heads"], llm_kv_heads=L["num_key_value_heads"],
+                   llm_layers=L["num_hidden_layers"], llm_inter=L["intermediate_size"], vocab=L["vocab_size"])
+    cfg.llm_config.max_position_embeddings = L["max_position_embeddings"]
+    cfg.llm_config.rope_scaling = dict(L["rope_scaling"])
+    return cfg
+
+
+@pytest.mark.parametrize("case", ["cross", "beyond"])
+def test_decode_past_max_positions_with_dynamic_ntk(golden_dir, case):
+    """Decoding past max_position_embeddings under rope_scaling = dynamic: the reference's rotary module rebuilds its tables with the base
+    of the current kv_seq_len at every such step and rotates only the new token with them (modeling_internlm2.py:187-194,227-243).  The
+    oracle's cache path against tokens recorded from the reference's own InternLM2 (tests/golden/make_golden_ntk.py): a decode that
+    crosses the limit, and one whose prompt is already beyond it - token for token, and the last table row the module ended with."""
+    g = torch.load(os.path.join(golden_dir, "ntk_decode.pt"), weights_only=True)
+    c, cfg = g["cases"][case], _ntk_cfg(g)
+    sd = synth.make_state_dict(cfg, seed=g["seed"], rich=True)
+    emb = torch.nn.functional.embedding(c["ids"], O.embed_weight(sd))
+    got = O.greedy_generate(sd, cfg, emb, torch.ones_like(c["ids"]), max_new_tokens=c["new"])
+    assert torch.equal(got, c["tokens"])
+    l = cfg.llm_config
+    cos, sin = O.rope_tables(l.head_dim, l.rope_theta, c["cached_len"], torch.float32, l.max_position_embeddings, l.rope_scaling)
+    assert torch.equal(cos[-1], c["cos_last"]) and torch.equal(sin[-1], c["sin_last"])
+    plain = O.rope_tables(l.head_dim, l.rope_theta, c["cached_len"], torch.float32, l.max_position_embeddings, None)[0]
+    assert not torch.equal(plain[-1], c["cos_last"])          # (the rescaled base really is another table)
+
