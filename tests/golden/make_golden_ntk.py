@@ -4,10 +4,11 @@ Real checkpoints ship rope_scaling = {"type": "dynamic", "factor": 2.0}.  The re
 with the base of the current kv_seq_len whenever that exceeds what it has cached (internvl/model/internlm2/modeling_internlm2.py:187-194,
 227-243): during a KV-cache decode that is EVERY step past max_position_embeddings, and only the new token's q / k are rotated with the new
 tables - cached keys keep the base they were written with.  This script runs the reference's own cache path (InternLM2ForCausalLM,
-prepare_inputs_for_generation: LM:1126-1163) on a small seeded decoder whose limit is 48 positions:
+prepare_inputs_for_generation: LM:1126-1163) on a small seeded decoder whose limit is 32 positions:
 
-* ``cross``: two prompts of 40 tokens, 24 new tokens - the decode crosses the limit at its 9th step;
-* ``beyond``: one prompt of 56 tokens (the prompt pass itself is rescaled), 12 new tokens.
+* ``cross``: two prompts of 24 tokens, 72 new tokens - the decode crosses the limit at its 9th step and ends at three times the limit (the
+  rotary base is then 5.1x the plain one);
+* ``beyond``: one prompt of 80 tokens (the prompt pass itself is rescaled), 16 new tokens.
 
 Outputs only are recorded (tokens, the top-2 logit gap of every step, the rotary tables the module ended with); weights come from
 ``aigv_assessor_amd.synth.make_state_dict`` with the recorded seed.  Run (build container only):
@@ -29,12 +30,12 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
-MAX_POS = 48
+MAX_POS = 32
 LLM = dict(hidden_size=512, intermediate_size=768, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2, vocab_size=1024,
            rms_norm_eps=1e-5, rope_theta=1000000, max_position_embeddings=MAX_POS, rope_scaling={"factor": 2.0, "type": "dynamic"}, bias=False,
            hidden_act="silu", attn_implementation="eager", pad_token_id=2)
 SEED = 77
-CASES = {"cross": dict(b=2, prompt=40, new=24), "beyond": dict(b=1, prompt=56, new=12)}
+CASES = {"cross": dict(b=2, prompt=24, new=72), "beyond": dict(b=1, prompt=80, new=16)}
 
 
 def quiet():
