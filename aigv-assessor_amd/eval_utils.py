@@ -42,3 +42,32 @@ def save_and_evaluate(rows: Sequence[Sequence], output_file: Optional[str] = Non
         out[f"{name}_plcc"] = pearsonr(mos, vals)[0]
         out[f"{name}_krcc"] = kendalltau(mos, vals)[0]
     return out
+
+
+def lookahead(items, model, frames, n_clips: int = 1):
+    """Iterate an eval loop one item ahead: yields ``(item, ahead)`` where ``ahead`` is ``model.prefetch(...)`` of THAT item's frames, started
+    while the previous item was still being scored - the next clip's frame ingest, InternViT pass and SlowFast branch run beside the
+    current clip's InternLM2 pass.  ``frames(item)`` returns the item's frames: uint8 [F, H, W, 3] (ingested on the GPU) or normalised
+    [F, 3, S, S] ``pixel_values``.  The reference's loop (stage2_eval.py:908-941) changes by two lines:
+
+        for item, ahead in eval_utils.lookahead(dataloader, model, frames=lambda it: it["pixel_values"][0]):
+            output = model(pixel_values=ahead, input_ids=..., ...)            # instead of pixel_values=item["pixel_values"][0].to(...).cuda()
+
+    Scores and level tokens are those of the plain loop, bit for bit."""
+    import torch
+
+    def start(item):
+        f = frames(item)
+        return model.prefetch(frames_u8=f, n_clips=n_clips) if f.dtype == torch.uint8 else model.prefetch(pixel_values=f, n_clips=n_clips)
+    it = iter(items)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    ahead = start(cur)
+    for nxt in it:
+        nxt_ahead = start(nxt)          # enqueued BEFORE the caller scores `cur`: the two then run side by side
+        yield cur, ahead
+        cur, ahead = nxt, nxt_ahead
+    yield cur, ahead
+

@@ -155,6 +155,15 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor):
 
 
 # ------------------------------------------------------------------------------------------------------
+class VisualAhead:
+    """The visual front of a LATER ``forward`` call, started ahead of time by ``InternVLChatModel.prefetch``: pre-projector tokens
+    [F, ntok, 4 Hv], the SlowFast feature of the clips (or None) and the event the consuming stream waits for.  Pass it as ``pixel_values``."""
+    __slots__ = ("tokens", "motion", "event", "n_clips")
+
+    def __init__(self, tokens, motion, event, n_clips):
+        self.tokens, self.motion, self.event, self.n_clips = tokens, motion, event, n_clips
+
+
 class InternVLChatModel(nn.Module):
     main_input_name = "pixel_values"
 
@@ -529,10 +538,19 @@ class InternVLChatModel(nn.Module):
         if tuple(pixel_values.shape[1:]) != (self.config.vision_config.num_channels, S, S):
             raise ValueError(f"pixel_values must be [F,{self.config.vision_config.num_channels},{S},{S}], got {tuple(pixel_values.shape)}")
         lib, ctx = self._native(n_frames=nf)
+        self._wait_for_prefetch()
         pv = pixel_values.to(device=self.device, dtype=torch.bfloat16).contiguous()
         out = torch.empty((nf, self.num_image_token, self.config.proj_in), dtype=torch.bfloat16, device=self.device)
         native.check(lib.aigv_vit_forward(ctx, pv.data_ptr(), nf, out.data_ptr(), native.stream_ptr()), ctx)
         return out
+
+    def _wait_for_prefetch(self):
+        """The InternViT workspaces of the context serve ONE visual front at a time: a pass that runs the ViT on the caller's stream (eager or
+        as a replayed graph) first waits for whatever ``prefetch`` still has in flight on its own stream."""
+        look = getattr(self, "_look_stream", None)
+        cur = torch.cuda.current_stream(self.device)
+        if look is not None and cur != look:
+            cur.wait_stream(look)
 
     def project(self, tokens: torch.Tensor) -> torch.Tensor:
         """mlp1 on pre-projector tokens [..., 4*Hv] -> [..., H] (modeling_internvl_chat.py:529)."""
@@ -661,6 +679,13 @@ class InternVLChatModel(nn.Module):
             raise NotImplementedError("the eval pass takes default positions and no cache, like the reference drivers")
         if self.img_context_token_id is None:
             raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
+        if isinstance(pixel_values, VisualAhead):    # the visual front was started ahead of time (prefetch): wait for it, continue behind the projector
+            torch.cuda.current_stream(self.device).wait_event(pixel_values.event)
+            if motion_feature is None:
+                motion_feature = pixel_values.motion
+            visual_tokens, pixel_values = pixel_values.tokens, None
+        elif pixel_values is not None:
+            self._wait_for_prefetch()
         if self._graph_replay_enabled and self._capture_keep is None:
             out = self._forward_through_graph(mos, pixel_values, input_ids, attention_mask, image_flags, labels, motion_feature, visual_tokens, full_logits)
             if out is not None:
@@ -768,6 +793,8 @@ class InternVLChatModel(nn.Module):
         stream) beside the InternViT tokens of its frame shard -> (tokens [F_local, ntok, 4 Hv], motion feature [n_clips, motion_dim] or
         None).  With graph replay enabled the two run as ONE captured graph (joined at its end); the token all-gather and the projector +
         InternLM2 half (``forward(visual_tokens=...)``, a graph of its own) follow on the host's side of the collective."""
+        self._wait_for_prefetch()
+
         def fn(fl, fc):
             mf = self._motion_feature(fc, n_clips, None) if fc is not None else None
             tok = self.vit_tokens(fl)
@@ -783,6 +810,40 @@ class InternVLChatModel(nn.Module):
             return self.vit_tokens(frames_local), None
         mf = self.motion_feature_async(frames_clips, n_clips)       # eager: joined where forward() consumes it
         return self.vit_tokens(frames_local), mf
+
+    def prefetch(self, pixel_values: Optional[torch.Tensor] = None, frames_u8: Optional[torch.Tensor] = None, n_clips: int = 1) -> VisualAhead:
+        """Start the visual front of a LATER ``forward`` call NOW, on a stream of its own: frame ingest (when ``frames_u8`` [F, H, W, 3] is
+        given: H2D copy + Pillow-exact resize + normalise), InternViT + pixel-shuffle, and the SlowFast branch of the ``n_clips`` clips -
+        everything that depends on the frames only.  The returned handle is passed to ``forward`` as ``pixel_values``; that call waits for
+        the handle's event and runs projector + InternLM2 + heads.  In an eval loop that scores one clip per call (stage2_eval.py:908-941)
+        the next clip's visual front then runs BESIDE the current clip's InternLM2 pass, whose wo / w2 launches leave half the CUs idle at
+        one clip (``eval_utils.lookahead`` wraps a loop that way).  Same kernels, same bits as the plain call; the InternViT workspaces of
+        the context serve one visual front at a time, so a prefetch waits for the previous one.  (HIP deals a process's streams round-robin onto a
+        few hardware queues: should the prefetch stream land on the queue of the caller's stream, the two serialise and the loop runs at the plain
+        loop's speed - with the same results.)"""
+        if (pixel_values is None) == (frames_u8 is None):
+            raise ValueError("prefetch takes pixel_values or frames_u8")
+        cur = torch.cuda.current_stream(self.device)
+        look = getattr(self, "_look_stream", None)
+        if look is None:
+            look = self._look_stream = torch.cuda.Stream(device=self.device)
+        look.wait_stream(cur)                       # inputs produced on the caller's stream; the previous prefetch is ordered by the stream itself
+        with torch.cuda.stream(look):
+            pv = self.ingest_frames(frames_u8) if frames_u8 is not None else pixel_values.to(device=self.device, dtype=torch.bfloat16)
+            need_motion = self.slowfast_model is not None and hasattr(self.slowfast_model, "features")
+            tok, mf = self.dp_front(pv, pv if need_motion else None, n_clips)
+            self._join_side_stream()                # (the eager SlowFast branch forks from and joins back into this stream)
+            tok = tok.clone()                       # (a replayed graph hands out its own output buffers: the next prefetch overwrites them)
+            mf = None if mf is None else mf.clone()
+            ev = torch.cuda.Event()
+            ev.record(look)
+        for t in (pixel_values, frames_u8):
+            if t is not None and t.is_cuda:
+                t.record_stream(look)
+        tok.record_stream(cur)
+        if mf is not None:
+            mf.record_stream(cur)
+        return VisualAhead(tok, mf, ev, n_clips)
 
     def _plan(self, input_ids, attention_mask, labels, image_flags, n_frames, full_logits=False, drop_dead_tail=None):
         """Host-side token bookkeeping of one pass: packed ids, which packed row takes which visual / motion token

@@ -445,7 +445,22 @@ def reference_loop_metric(model, cfg, toks, dev, T, n_clips=6):
         scores.append((score, int(pred.numel())))
     times = sorted(times[2:])
     ms = times[len(times) // 2]
+    # the same loop with the NEXT clip's visual front (H2D, resize, InternViT, SlowFast) started one clip ahead on a stream of its own
+    # (aigv_assessor_amd.eval_utils.lookahead: a two-line change of the driver; same kernels, same bits) - clip-to-clip wall time
+    marks, ahead_scores = [], []
+    torch.cuda.synchronize()
+    for c, ahead in eval_utils.lookahead([clips[i % 2] for i in range(n_clips + 3)], model, frames=lambda c: c):
+        out = model(mos=None, pixel_values=ahead, input_ids=ids, attention_mask=am, image_flags=flags, labels=labels, motion_feature=motion)
+        ahead_scores.append(out["score1"].item())
+        eval_utils.answer_ids(labels[0], out["logit"].cpu())
+        marks.append(time.perf_counter())
+    gaps = sorted((b - a) * 1e3 for a, b in zip(marks[2:-1], marks[3:]))
+    ahead_ms = gaps[len(gaps) // 2]
+    same = all(a == scores[i][0] for i, a in enumerate(ahead_scores[: len(scores)]))
     return {"latency_ms_per_clip": ms, "clips_per_s": 1e3 / ms, "clips_timed": n_clips, "ms_min_max": [times[0], times[-1]],
+            "lookahead": {"ms_per_clip": ahead_ms, "clips_per_s": 1e3 / ahead_ms, "ms_min_max": [gaps[0], gaps[-1]], "scores_equal_the_plain_loop": same,
+                          "what": "the same loop through eval_utils.lookahead (a two-line change of the driver): the next clip's H2D + resize + InternViT + SlowFast run on their own "
+                                  "stream beside the current clip's InternLM2 pass; median clip-to-clip wall time"},
             "shape": (f"the reference's eval loop (stage2_eval.py:908-941): batch 1, per clip {T} uint8 720p frames from pinned host memory -> H2D -> BICUBIC "
                       "resize + normalise -> forward -> score1.item() + answer-token slice on the host; median of the timed clips after two warm-up clips")}
 

@@ -623,6 +623,52 @@ def test_graph_replay_scores_like_the_eager_pass():
     model.enable_graph_replay(False)
 
 
+def test_lookahead_loop_scores_like_the_plain_loop():
+    """eval_utils.lookahead / InternVLChatModel.prefetch: the next clip's frame ingest, InternViT pass and SlowFast branch run on a stream
+    of their own beside the current clip's InternLM2 pass (the reference's loop scores one clip per call, stage2_eval.py:908-941).  Same
+    kernels, same bits: scores and level tokens of six clips equal the plain loop's exactly - from uint8 frames (ingested on the GPU) and
+    from pixel_values, eager and with graph replay, with the native SlowFast branch and with the motion feature as an input; a plain
+    forward between two prefetched ones (it shares the InternViT workspaces) is still right."""
+    from aigv_assessor_amd import eval_utils
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    from aigv_assessor_amd.slowfast import SlowFastR50
+    cfg = pkg.tiny(image_size=224, vit_layers=2, llm_layers=2)
+    model = InternVLChatModel(cfg)
+    model.load_state_dict(synth.make_state_dict(cfg, seed=73, rich=True))
+    model.eval().cuda()
+    T = 8
+    toks = synth.canonical_tokens(cfg, 1, T, seed=73)
+    model.img_context_token_id = toks["img_context_token_id"]
+    flags = torch.ones(T, 1, dtype=torch.long)
+    g = torch.Generator().manual_seed(5)
+    clips_u8 = [torch.randint(0, 256, (T, 300, 400, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(6)]
+    motions = [synth.synthetic_motion(1, cfg.motion_dim, seed=200 + i).cuda() for i in range(6)]
+
+    def fwd(pv, i, with_sf):
+        o = model(mos=None, pixel_values=pv, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"], image_flags=flags, labels=toks["labels"],
+                  motion_feature=None if with_sf else motions[i])
+        return float(o["score1"].item()), o["logit"].cpu().clone()
+
+    for with_sf in (True, False):
+        model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=3)) if with_sf else None
+        for graph in (False, True):
+            model.enable_graph_replay(graph)
+            plain = [fwd(model.ingest_frames(c.cuda()), i, with_sf) for i, c in enumerate(clips_u8)]
+            got = [fwd(ahead, i, with_sf) for i, (c, ahead) in enumerate(eval_utils.lookahead(clips_u8, model, frames=lambda c: c))]
+            assert len(got) == len(plain)
+            for (s, l), (es, el) in zip(got, plain):
+                assert s == es and torch.equal(l, el), (with_sf, graph)
+            # normalised pixel_values as the loop's input, and a plain call in between two prefetched ones
+            pvs = [model.ingest_frames(c.cuda()) for c in clips_u8[:3]]
+            a0 = model.prefetch(pixel_values=pvs[0])
+            a2 = model.prefetch(pixel_values=pvs[2])
+            mid = fwd(pvs[1], 1, with_sf)
+            assert fwd(a0, 0, with_sf)[0] == plain[0][0] and mid[0] == plain[1][0] and fwd(a2, 2, with_sf)[0] == plain[2][0]
+    model.enable_graph_replay(False)
+    with pytest.raises(ValueError):
+        model.prefetch()
+
+
 def test_experiment_knobs_live_in_the_context(rig):
     """aigv_ctx_tune: the kernel-form knobs are per context - a second model of the same process keeps its own forms -
     and every form computes the same scores up to fp32 summation order (tiny configuration: identical level tokens, score within one
