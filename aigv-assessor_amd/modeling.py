@@ -516,7 +516,8 @@ class InternVLChatModel(nn.Module):
         if self.device.type != "cuda":
             raise native.NativeError("the scorer hot path runs on an MI355X only (no CPU fallback)")
         S = int(size or self.config.image_size)
-        f = frames_u8.to(self.device).contiguous()
+        # (pinned host frames go up without blocking the host: the copy is ordered on the current stream like the kernels that read it)
+        f = frames_u8.to(self.device, non_blocking=not frames_u8.is_cuda and frames_u8.is_pinned()).contiguous()
         n, h, w, _ = f.shape
         out = torch.empty((n, 3, S, S), dtype=torch.bfloat16, device=self.device)
         m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
