@@ -545,6 +545,16 @@ class InternVLChatModel(nn.Module):
         native.check(lib.aigv_vit_forward(ctx, pv.data_ptr(), nf, out.data_ptr(), native.stream_ptr()), ctx)
         return out
 
+    def _take_ahead(self, pixel_values, visual_tokens, motion_feature):
+        """``pixel_values`` may be the handle of a visual front started ahead of time (``prefetch``): wait for it on the caller's stream and continue
+        from its tokens / SlowFast feature; a plain ``pixel_values`` first waits for any prefetch in flight (one visual front at a time)."""
+        if isinstance(pixel_values, VisualAhead):
+            torch.cuda.current_stream(self.device).wait_event(pixel_values.event)
+            return None, pixel_values.tokens, pixel_values.motion if motion_feature is None else motion_feature
+        if pixel_values is not None:
+            self._wait_for_prefetch()
+        return pixel_values, visual_tokens, motion_feature
+
     def _wait_for_prefetch(self):
         """The InternViT workspaces of the context serve ONE visual front at a time: a pass that runs the ViT on the caller's stream (eager or
         as a replayed graph) first waits for whatever ``prefetch`` still has in flight on its own stream."""
@@ -680,13 +690,7 @@ class InternVLChatModel(nn.Module):
             raise NotImplementedError("the eval pass takes default positions and no cache, like the reference drivers")
         if self.img_context_token_id is None:
             raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
-        if isinstance(pixel_values, VisualAhead):    # the visual front was started ahead of time (prefetch): wait for it, continue behind the projector
-            torch.cuda.current_stream(self.device).wait_event(pixel_values.event)
-            if motion_feature is None:
-                motion_feature = pixel_values.motion
-            visual_tokens, pixel_values = pixel_values.tokens, None
-        elif pixel_values is not None:
-            self._wait_for_prefetch()
+        pixel_values, visual_tokens, motion_feature = self._take_ahead(pixel_values, visual_tokens, motion_feature)
         if self._graph_replay_enabled and self._capture_keep is None:
             out = self._forward_through_graph(mos, pixel_values, input_ids, attention_mask, image_flags, labels, motion_feature, visual_tokens, full_logits)
             if out is not None:
@@ -976,6 +980,7 @@ class InternVLChatModel(nn.Module):
             raise AssertionError("img_context_token_id must be set by the caller (stage2_eval.py:810)")
         if not prompts:
             return []
+        pixel_values, visual_tokens, motion_feature = self._take_ahead(pixel_values, visual_tokens, motion_feature)
         n_frames = visual_tokens.shape[0] if visual_tokens is not None else pixel_values.shape[0]
         plans = [self._plan(ids, am, lab, image_flags, n_frames) for (ids, am, lab) in prompts]
         B = prompts[0][0].shape[0]

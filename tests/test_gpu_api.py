@@ -667,6 +667,12 @@ def test_lookahead_loop_scores_like_the_plain_loop():
     model.enable_graph_replay(False)
     with pytest.raises(ValueError):
         model.prefetch()
+    # the shared-prefix pass (four perspectives behind one video) takes the handle too
+    pv0 = model.ingest_frames(clips_u8[0].cuda())
+    prompts = [(toks["input_ids"], toks["attention_mask"], toks["labels"])] * 2
+    want = model.forward_shared_prefix(prompts, pixel_values=pv0, image_flags=flags, motion_feature=motions[0])
+    got = model.forward_shared_prefix(prompts, pixel_values=model.prefetch(pixel_values=pv0), image_flags=flags, motion_feature=motions[0])
+    assert all(torch.equal(a["score1"], b["score1"]) and torch.equal(a["logit"], b["logit"]) for a, b in zip(got, want))
 
 
 def test_experiment_knobs_live_in_the_context(rig):
