@@ -2,7 +2,7 @@
 
     python scripts/step_ab.py knob=value[,knob=value...] [...]      e.g.  tiny_side=0 tiny_side=1
 
-Every argument is one arm (InternVLChatModel.tune); arms are interleaved over four rounds in ONE process, each visit = 2 untimed + 8 timed eager
+Every argument is one arm (InternVLChatModel.tune knobs, or attr.NAME=value for a Python-side switch of the model); arms are interleaved over four rounds in ONE process, each visit = 2 untimed + 8 timed eager
 steps between HIP events.  Per arm: median / min ms per step, and whether scores and level tokens equal the first arm's bit for bit."""
 import sys
 sys.path.insert(0, ".")
@@ -36,7 +36,11 @@ outs = {}
 for rnd in range(4):
     for ai, arm in enumerate(arms):
         for k, v in arm.items():
-            model.tune(k, v)
+            if k.startswith("attr."):           # a Python-side switch of the model (e.g. attr.gate_motion_branch=1)
+                setattr(model, k[5:], v)
+                model._drop_graphs()
+            else:
+                model.tune(k, v)
         for _ in range(2):
             o = step()
         torch.cuda.synchronize()
@@ -49,7 +53,11 @@ for rnd in range(4):
         res[ai].append(e0.elapsed_time(e1) / 8)
         outs[ai] = (o["score1"].clone(), o["logit"].clone())
         for k in arm:
-            model.tune(k, -1)
+            if k.startswith("attr."):
+                setattr(model, k[5:], 0)
+                model._drop_graphs()
+            else:
+                model.tune(k, -1)
 for ai, arm in enumerate(arms):
     v = sorted(res[ai])
     same = torch.equal(outs[ai][0], outs[0][0]) and torch.equal(outs[ai][1], outs[0][1])
