@@ -395,3 +395,28 @@ def test_decode_past_max_positions_with_dynamic_ntk(golden_dir, case):
     plain = O.rope_tables(l.head_dim, l.rope_theta, c["cached_len"], torch.float32, l.max_position_embeddings, None)[0]
     assert not torch.equal(plain[-1], c["cos_last"])          # (the rescaled base really is another table)
 
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_layers_at_config4_widths_match_the_reference(golden_dir, dt):
+    """BASELINE config 4's widths (InternViT-6B: hidden 3200, 25 heads, RMSNorm + QK-norm; InternLM2-20B: hidden 6144, 48 / 8 heads): the oracle's
+    encoder and decoder layer against outputs recorded from the reference's own layer classes at exactly those widths
+    (tests/golden/make_golden_26b_layers.py) - the reference cannot run the 26B model end to end (score head hard-wired to 4096), so the full-depth
+    config-4 fixture is oracle-only and this is what pins the oracle there."""
+    g = torch.load(os.path.join(golden_dir, "layers_26b.pt"), weights_only=True)
+    cfg = pkg.internvl2_26b()                      # one layer each, a small vocabulary: the generator's configuration (cfg_26b_one_layer)
+    cfg.vision_config.num_hidden_layers = 1
+    cfg.llm_config.num_hidden_layers = 1
+    cfg.llm_config.vocab_size = g["vocab"]
+    sd = synth.make_state_dict(cfg, seed=g["seed"], dtype=dt, rich=True)
+    v = g["cases"][f"vit_layer/{dt}"]
+    x = (torch.randn(*v["x_shape"], generator=torch.Generator().manual_seed(v["x_seed"])) * v["x_scale"]).to(dt)
+    y = O.vit_layer(sd, cfg, 0, x)
+    assert y.dtype == dt and close(y[..., ::4], v["y_sub"], dt)
+    c = g["cases"][f"llm_layer/{dt}"]
+    x = (torch.randn(*c["x_shape"], generator=torch.Generator().manual_seed(c["x_seed"])) * c["x_scale"]).to(dt)
+    n = x.shape[1]
+    cfg.llm_config.rope_scaling = {"factor": 2.0, "type": "dynamic"}
+    mask = O.additive_mask(torch.ones(2, n, dtype=torch.bool), n, 0, dt)
+    y, _ = O.llm_layer(sd, cfg, 0, x, mask, torch.arange(n).unsqueeze(0))
+    assert close(y[..., ::4], c["y_sub"], dt)
+
