@@ -1237,6 +1237,11 @@ class InternVLChatModel(nn.Module):
         """One multinomial draw per row after HF's logits warpers in HF's order (TemperatureLogitsWarper, TopKLogitsWarper,
         TopPLogitsWarper with min_tokens_to_keep = 1; transformers/generation/logits_process.py).  Host-side glue of generate():
         a handful of torch ops on [B, vocab], not part of the scoring hot path."""
+        return torch.multinomial(InternVLChatModel._warp(logits, temperature, top_k, top_p).softmax(-1), 1, generator=generator).squeeze(1)
+
+    @staticmethod
+    def _warp(logits: torch.Tensor, temperature: float, top_k: int, top_p: float) -> torch.Tensor:
+        """HF's three logits warpers in HF's order (pinned against transformers' own classes in tests/test_host.py)."""
         x = logits / temperature if temperature != 1.0 else logits
         if top_k > 0:
             kth = torch.topk(x, min(top_k, x.shape[-1]))[0][..., -1, None]
@@ -1246,7 +1251,7 @@ class InternVLChatModel(nn.Module):
             remove = srt.softmax(-1).cumsum(-1) <= (1.0 - top_p)
             remove[..., -1:] = False
             x = x.masked_fill(remove.scatter(1, idx, remove), float("-inf"))
-        return torch.multinomial(x.softmax(-1), 1, generator=generator).squeeze(1)
+        return x
 
     @torch.no_grad()
     def generate(self, pixel_values: Optional[torch.Tensor] = None, input_ids: Optional[torch.Tensor] = None,

@@ -436,6 +436,30 @@ def test_build_inputs_and_get_index_match_the_reference(golden_dir):
     assert bool((b["labels"][0][~b["attention_mask"][0]] == -100).all()) and bool((b["input_ids"][0][~b["attention_mask"][0]] == 2).all())
 
 
+@pytest.mark.parametrize("temperature,top_k,top_p", [(1.0, 50, 1.0), (0.7, 5, 0.9), (1.3, 0, 0.5), (1.0, 1, 1.0), (0.5, 1000, 0.05), (1.0, 0, 0.999)])
+def test_sampling_warpers_match_transformers(temperature, top_k, top_p):
+    """generate(do_sample=True) warps the logits like HF's multinomial sampling does (the reference hands its generation_config to HF,
+    modeling_internvl_chat.py:798-809): temperature, top-k, top-p in HF's order - against transformers' own warper classes, on logits with
+    ties and a dominant token."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    g = torch.Generator().manual_seed(int(temperature * 10) + top_k)
+    logits = torch.randn(5, 300, generator=g) * 3
+    logits[1, :40] = logits[1, 0]            # ties across the top-k boundary
+    logits[2, 7] = 40.0                      # one token holds nearly all the mass
+    ids = torch.zeros(5, 1, dtype=torch.long)
+    want = logits.clone()
+    if temperature != 1.0:
+        want = TemperatureLogitsWarper(temperature)(ids, want)
+    if top_k > 0:
+        want = TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=1)(ids, want)
+    if top_p < 1.0:
+        want = TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=1)(ids, want)
+    got = InternVLChatModel._warp(logits.clone(), temperature, top_k, top_p)
+    assert torch.equal(got, want)
+    assert torch.isfinite(got).sum(-1).min() >= 1
+
+
 def test_generation_logits_processors_match_transformers():
     """The host glue of generate(): HF's RepetitionPenaltyLogitsProcessor and NoRepeatNGramLogitsProcessor (the reference's generate()
     hands its generation_config to HF, modeling_internvl_chat.py:798-809).  The processors here are checked against transformers'
