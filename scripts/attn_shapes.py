@@ -19,7 +19,7 @@ def run(name, d, causal, h, hk, lens, secs=1.0):
     pre = d ** -0.5 if not causal else 1.0
     post = 1.0 if not causal else math.sqrt(d)
     call = lambda: native.check(lib.aigv_op_attention(base, ld, base + g * d * 2, ld, base + (g + 1) * d * 2, ld, ptr(out), h * d, ptr(cu), len(lens), max(lens), h, hk,
-                                                      (g + 2) * d, (g + 2) * d, d, int(causal), pre, post, native.stream_ptr()))
+                                                      (g + 2) * d, (g + 2) * d, d, int(causal), post, pre, native.stream_ptr()))
     t0 = time.time()
     while time.time() - t0 < secs:
         for _ in range(20): call()
