@@ -52,7 +52,6 @@ struct ProfRec {
 //   tiny: tails of <= TINY_TAIL rows (InternViT: 1025 = 4 * 256 + 1) -> the weight-streaming skinny kernel in its fixed 4-slice form.
 struct RowPlan {
   struct Tiny { int row0, stride_rows, count; };   // rows row0 + i * stride_rows, i < count
-  std::vector<int32_t> key;     // the cu_seqlens the plan was made from (cache key)
   std::vector<Tiny> tiny;
   int rows = 0, body_halves = 0, tail_halves = 0, tail_rows = 0;
   int32_t* d_tab = nullptr;     // device: (base row, valid rows) per half, body halves first
@@ -94,16 +93,21 @@ struct aigv_ctx {
   std::vector<LlmLayerFp8> llm8;
   uint8_t* q8 = nullptr;       // [max_tokens, max(H, I)] e4m3 activations of the GEMM about to run
   float* q8_scale = nullptr;   // [max_tokens]
-  RowPlan rp_vit, rp_llm;           // row plans of the InternViT frames (cached per chunk size) and of the current prefill's clips
+  RowPlan rp_vit, rp_llm;           // row plans of the InternViT frames of the current chunk and of the current prefill's clips
   const RowPlan* cur_rp = nullptr;  // plan the InternLM2 layer helpers run under (null: batch-level dispatch, aigv_llm_extend)
   bool trim_last_layer = true;
-  int attn_round_scores = 0;   // prefill attention: 1 = the reference's bf16 rounding points of the score matrix, 0 = fp32 scores (default since round 5: profiles/r5_parity_stats.txt)
+  int attn_round_scores = AIGV_ATTENTION_NUMERICS_DEFAULT;   // prefill attention: 1 = the reference's bf16 rounding points of the score matrix, 0 = fp32 scores (default since round 5: profiles/r5_parity_stats.txt)
   int gemm_mode = -1;          // GEMM tile choice of this context: -1 = the process default (aigv_tune_gemm), else 0 / 1 / 2 / 3 / 4
   // the other experiment knobs of this context (aigv_ctx_tune): -1 = follow the process default (aigv_tune_*)
   int t_order = -1, t_variant = -1, t_attn_waves = -1, t_skinny_p = -1, t_body_tile = -1, t_co_kmax = -1;
   int t_tail_slices = -1, t_lead_key = -1, t_decode_fused = -1, t_decode_fp8 = -1, t_skinny_p8 = -1, t_fuse_tails = -1, t_lone_body = -1;
   size_t splitk_floats = 0;
-  float* splitk_ws = nullptr;  // fp32 slabs of the split-K row bands: owned by the context (one launch stream per context at a time)
+  // fp32 slabs of the split-K row bands, owned by the context.  Two of them: aigv_vit_forward launches on `splitk_ws_vit`, every other entry
+  // point on `splitk_ws` - so ONE visual front (InternViT on a stream of its own: InternVLChatModel.prefetch) may run beside ONE
+  // projector / InternLM2 pass of the same context.  Within each half the rule stays: one launch stream at a time.
+  float* splitk_ws = nullptr;
+  float* splitk_ws_vit = nullptr;
+  bool on_vit_front = false;   // host-side: set while aigv_vit_forward enqueues (SplitkVitScope)
   bf16_t* l_trim = nullptr;   // last-layer row trimming: compact [64, H] x 2 (attention out, normed) + [64, I], reused per 64 consumed rows
   bf16_t* l_trim_h = nullptr; // ... and the consumed rows' hidden states [max_out_rows + max_seqs + 64, H]
   bf16_t* l_score_ws = nullptr;
@@ -212,6 +216,12 @@ struct RowPlanScope {   // the InternLM2 layer helpers run under `rp` inside the
   ~RowPlanScope() { c->cur_rp = nullptr; }
 };
 
+struct SplitkVitScope {   // split-K launches inside the scope use the InternViT half of the context's scratch
+  aigv_ctx* c;
+  explicit SplitkVitScope(aigv_ctx* c_) : c(c_) { c->on_vit_front = true; }
+  ~SplitkVitScope() { c->on_vit_front = false; }
+};
+
 struct GemmClassScope {   // GEMM launches inside the scope are booked under `cls` (per-class roofline entries of bench.py)
   aigv_ctx* c;
   int keep;
@@ -299,7 +309,7 @@ int splitk_scratch(aigv_ctx* c, size_t need_floats, float** out) {
   if (need_floats > SPLITK_MAX_FLOATS) return fail(c, AIGV_ERR_ARG, "split-K scratch: %zu floats exceed the planner's cap", need_floats);
   if (c) {
     if (need_floats > c->splitk_floats) return fail(c, AIGV_ERR_STATE, "split-K scratch: %zu floats exceed the context's %zu", need_floats, c->splitk_floats);
-    *out = c->splitk_ws;
+    *out = c->on_vit_front ? c->splitk_ws_vit : c->splitk_ws;
     return 0;
   }
   int dev = 0;
@@ -507,10 +517,10 @@ int run_gemm(aigv_ctx* c, const GemmArgs& a, int epi, hipStream_t s) {
 constexpr int TINY_TAIL = 4;
 
 // cu[0..n_seq]: row offsets of the sequences inside the activation matrices.  Builds the plan and uploads its table (kernel-argument
-// writes on `s`: no host synchronisation); a plan made from the same cu is reused as it is.
+// writes on `s`: no host synchronisation).  The table is written by EVERY pass, never skipped for a plan "already on the device": a pass
+// captured into a HIP graph must carry its own table writes (a replay after a pass of another shape would otherwise run on that pass's table),
+// and a replayed graph rewrites the device table behind the host's back - so there is no host-side notion of what the device table holds.
 int build_row_plan(aigv_ctx* c, RowPlan& rp, const int32_t* cu, int n_seq, hipStream_t s) {
-  if ((int)rp.key.size() == n_seq + 1 && std::equal(rp.key.begin(), rp.key.end(), cu)) return 0;
-  rp.key.clear();
   rp.tiny.clear();
   std::vector<int32_t> body, tail;
   bool uniform = true;
@@ -537,7 +547,6 @@ int build_row_plan(aigv_ctx* c, RowPlan& rp, const int32_t* cu, int n_seq, hipSt
     return fail(c, AIGV_ERR_STATE, "row plan: %d half tiles exceed the table's %d", rp.body_halves + rp.tail_halves, rp.cap_halves);
   body.insert(body.end(), tail.begin(), tail.end());
   if (!body.empty()) HIPCHK(c, aigv_launch_write_ints(body.data(), (int)body.size(), rp.d_tab, s));
-  rp.key.assign(cu, cu + n_seq + 1);
   return 0;
 }
 
@@ -851,6 +860,10 @@ static int alloc_workspaces(aigv_ctx* c) {
       if (hipMalloc(&p, c->splitk_floats * sizeof(float)) != hipSuccess) { rc = fail(c, AIGV_ERR_ALLOC, "hipMalloc(split-K scratch) failed"); break; }
       c->ws_allocs.push_back(p);
       c->splitk_ws = (float*)p;
+      // the InternViT half (same size: `rows` / `widest` above cover its GEMMs)
+      if (hipMalloc(&p, c->splitk_floats * sizeof(float)) != hipSuccess) { rc = fail(c, AIGV_ERR_ALLOC, "hipMalloc(split-K scratch, InternViT) failed"); break; }
+      c->ws_allocs.push_back(p);
+      c->splitk_ws_vit = (float*)p;
     }
     if (hipMemset(c->l_neg1, 0xFF, (size_t)k.max_tokens * sizeof(int32_t)) != hipSuccess) { rc = fail(c, AIGV_ERR_HIP, "hipMemset failed"); break; }
     {
@@ -1183,6 +1196,7 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
   GemmClassScope gcls(c, AIGV_PROF_GEMM_VIT);
+  SplitkVitScope svs(c);
   const int Hv = k.vit_hidden, Iv = k.vit_inter;
   int n_layers = k.vit_layers;
   if (k.select_layer != -1) n_layers = k.select_layer < 0 ? k.vit_layers + 1 + k.select_layer : k.select_layer;
@@ -1772,6 +1786,8 @@ int aigv_ctx_tune(aigv_ctx* c, int knob, int value) {
   return fail(c, AIGV_ERR_ARG, "aigv_ctx_tune: value %d out of range for knob %d", value, knob);
 }
 
+int aigv_get_attention_numerics(const aigv_ctx* c) { return c ? c->attn_round_scores : AIGV_ATTENTION_NUMERICS_DEFAULT; }
+
 int aigv_set_attention_numerics(aigv_ctx* c, int mode) {
   if (!c) return fail(c, AIGV_ERR_ARG, "aigv_set_attention_numerics: null context");
   if (mode != 0 && mode != 1) return fail(c, AIGV_ERR_ARG, "aigv_set_attention_numerics: 0 (fp32 scores) or 1 (the reference's bf16 score matrix)");
@@ -2187,7 +2203,7 @@ int aigv_tune_default(int knob, int value) {
   switch (knob) {
     case AIGV_TUNE_TAIL_SLICES: if (value < 0 || value > 16) break; g_tune.tail_slices = value; return 0;
     case AIGV_TUNE_FUSE_TAILS: if (value < 0 || value > 2) break; g_tune.fuse_tails = value; return 0;
-    case AIGV_TUNE_LONE_BODY: if (value < 0 || value > 2) break; g_tune.lone_body = value; return 0;
+    case AIGV_TUNE_LONE_BODY: if (value < 0 || value > 4) break; g_tune.lone_body = value; return 0;   // (same range as aigv_ctx_tune)
     case AIGV_TUNE_ATTN_LEAD_KEY: if (value < 0 || value > 1) break; g_tune.lead_key = value; return 0;
     case AIGV_TUNE_CO_KMAX: return aigv_tune_co_gemm(value);
     default: return fail(nullptr, AIGV_ERR_ARG, "aigv_tune_default: knob %d has no process default here (aigv_tune_gemm / _attention / _skinny set the others)", knob);

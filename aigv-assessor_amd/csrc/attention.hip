@@ -17,9 +17,9 @@
 //                              V tile, in the accumulator's permuted key order
 //                              (key = 16s + 8(j>>2) + 4h + (j&3), guide §3 "accumulator tile as operand").
 //
-// Numerics: the q pre-scale rounds to bf16 (exact for d^-1/2 = 2^-3); the score matrix rounds to bf16 where the reference's
-// eager path rounds it (RS, the default since round 4: once after q k^T, InternLM2 again after / sqrt(d)) or stays fp32
-// (aigv_set_attention_numerics 0); the softmax runs in fp32, P rounds to bf16 before P·V (un-normalised; the row is divided at
+// Numerics: the q pre-scale rounds to bf16 (exact for d^-1/2 = 2^-3); the score matrix stays fp32 up to the softmax
+// (aigv_set_attention_numerics 0, the default since round 5) or rounds to bf16 where the reference's eager path rounds it
+// (RS, mode 1: once after q k^T, InternLM2 again after / sqrt(d)); the softmax runs in fp32, P rounds to bf16 before P·V (un-normalised; the row is divided at
 // the end), the output rounds to bf16.  With RS the kernel sits ~4x closer to the eager bf16 result than that result sits to
 // fp64 truth; without it, it is at least as accurate against fp64 truth as the eager path (tests/test_gpu_ops.py).
 #include <cstdlib>

@@ -504,20 +504,24 @@ class InternVLChatModel(nn.Module):
             pass
 
     # ---- hot path -----------------------------------------------------------------------------------------
-    def ingest_frames(self, frames_u8: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+    def ingest_frames(self, frames_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
                       size: Optional[int] = None) -> torch.Tensor:
-        """uint8 [F, H, W, 3] RGB frames -> normalised bf16 NCHW ``pixel_values`` on the GPU: the reference's per-frame
+        """uint8 [F, H, W, 3] RGB frames (one tensor, or a list of per-clip tensors) -> normalised bf16 NCHW ``pixel_values`` on the GPU: the reference's per-frame
         ``image.resize((448, 448))`` (PIL BICUBIC; dataset.py:702-738 with max_num = 1, stage2_eval.py:453-456) when the
         frames are not at the model resolution yet, then ToTensor + Normalize + the bf16 cast of its eval transform
         (dataset.py:267-274, stage2_eval.py:932).  The resize is bit-exact with Pillow (include/aigv_amd.h)."""
-        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
-            raise ValueError("frames must be uint8 [F, H, W, 3]")
+        parts = list(frames_u8) if isinstance(frames_u8, (list, tuple)) else [frames_u8]
+        for t in parts:
+            if t.dtype != torch.uint8 or t.dim() != 4 or t.shape[-1] != 3 or t.shape[1:] != parts[0].shape[1:]:
+                raise ValueError("frames must be uint8 [F, H, W, 3] (or a list of such tensors of one frame size)")
         lib = native.load()
         if self.device.type != "cuda":
             raise native.NativeError("the scorer hot path runs on an MI355X only (no CPU fallback)")
         S = int(size or self.config.image_size)
-        # (pinned host frames go up without blocking the host: the copy is ordered on the current stream like the kernels that read it)
-        f = frames_u8.to(self.device, non_blocking=not frames_u8.is_cuda and frames_u8.is_pinned()).contiguous()
+        # (pinned host frames go up without blocking the host: the copy is ordered on the current stream like the kernels that read it.  A list -
+        # the clips of one group, each in its own host buffer - is copied clip by clip and joined on the device: no host-side concatenation)
+        parts = [t.to(self.device, non_blocking=not t.is_cuda and t.is_pinned()) for t in parts]
+        f = (torch.cat(parts) if len(parts) > 1 else parts[0]).contiguous()
         n, h, w, _ = f.shape
         out = torch.empty((n, 3, S, S), dtype=torch.bfloat16, device=self.device)
         m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
@@ -558,6 +562,9 @@ class InternVLChatModel(nn.Module):
     def _wait_for_prefetch(self):
         """The InternViT workspaces of the context serve ONE visual front at a time: a pass that runs the ViT on the caller's stream (eager or
         as a replayed graph) first waits for whatever ``prefetch`` still has in flight on its own stream."""
+        if self._capture_keep is not None:
+            return      # inside a graph capture: the caller (forward / dp_front) already waited before _graph_call; an event recorded on a
+                        # non-capturing stream must not be waited on from the capture stream
         look = getattr(self, "_look_stream", None)
         cur = torch.cuda.current_stream(self.device)
         if look is not None and cur != look:
@@ -752,7 +759,9 @@ class InternVLChatModel(nn.Module):
                 with torch.cuda.graph(graph, capture_error_mode="relaxed"):
                     outputs = fn(*statics)
                 keep = self._capture_keep
-            except Exception:                # a pass that does not capture (an allocation or a synchronisation inside it) stays eager for good
+            except Exception as e:           # a pass that does not capture (an allocation or a synchronisation inside it) stays eager for good - and
+                import warnings              # says so; the eager run that follows raises whatever was a real error rather than a capture-illegal call
+                warnings.warn(f"graph replay: capture of {host_key[0]!r} failed ({type(e).__name__}: {e}); this call shape stays eager")
                 graphs[key] = "eager"
                 self._capture_keep = None
                 torch.cuda.synchronize(self.device)
@@ -842,7 +851,7 @@ class InternVLChatModel(nn.Module):
             mf = None if mf is None else mf.clone()
             ev = torch.cuda.Event()
             ev.record(look)
-        for t in (pixel_values, frames_u8):
+        for t in ([pixel_values] + (list(frames_u8) if isinstance(frames_u8, (list, tuple)) else [frames_u8])):
             if t is not None and t.is_cuda:
                 t.record_stream(look)
         tok.record_stream(cur)

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "aigv_set_row_trimming": (_I, [_P, _I]),
     "aigv_set_gemm_mode": (_I, [_P, _I]),
     "aigv_set_attention_numerics": (_I, [_P, _I]),
+    "aigv_get_attention_numerics": (_I, [_P]),
     "aigv_ctx_tune": (_I, [_P, _I, _I]),
     "aigv_decode_step": (_I, [_P, _P, _P, _P]),
     "aigv_out_row_logits": (_I, [_P, _I, _I, _P, _I, _P]),

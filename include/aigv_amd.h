@@ -14,8 +14,13 @@
  * (:1141-1147).
  *
  * Threading: the intended deployment is one process per GPU (the reference's eval loop is single-threaded too).  A context is
- * not re-entrant - calls on ONE context must not overlap, whatever their streams - but it owns all the device state it uses
- * (weights, workspaces, split-K slab scratch), so several contexts, also on different devices of one process, are independent.
+ * not re-entrant - HOST calls on one context must not overlap - but it owns all the device state it uses (weights, workspaces,
+ * split-K slab scratch), so several contexts, also on different devices of one process, are independent.
+ * Streams: a context's device state comes in two halves.  aigv_vit_forward uses the InternViT workspaces, the InternViT row-plan
+ * table and an InternViT split-K scratch of its own; every other entry point (aigv_project, aigv_motion_project, aigv_llm_prefill /
+ * _extend, decode) uses the rest.  So ONE aigv_vit_forward may be in flight on one stream beside ONE pass of the other half on another
+ * stream (the next clip's visual front beside this clip's InternLM2 pass); within a half, work must be stream-ordered (one launch
+ * stream at a time, or the caller's events between them).
  * The context-free aigv_op_* entry points share one split-K scratch per DEVICE (created on first use, never regrown): overlap
  * them only from one stream per device.  Frame-resize coefficient tables are cached per (device, size pair) and immutable.
  */
@@ -162,12 +167,17 @@ int aigv_set_row_trimming(aigv_ctx* ctx, int on);
  * imported reference was recorded on, it is NOT closer to the reference's scores (3.09 against 2.80 bf16 ulps mean; the reference moves
  * 2.56 against itself with the host's thread count), it is farther from the reference's fp32 scores (3.59 against 2.01) and it costs
  * 1.9 ms of a 116 ms step: profiles/r5_parity_stats.txt.  P is rounded un-normalised in both forms (no measurable effect). */
+#define AIGV_ATTENTION_NUMERICS_DEFAULT 0
 int aigv_set_attention_numerics(aigv_ctx* ctx, int mode);
+/* The mode in force for `ctx`; ctx == NULL: the mode a fresh context starts in (AIGV_ATTENTION_NUMERICS_DEFAULT; needs no GPU - the host
+ * tests hold INTEGRATION.md's "default" sentence against it). */
+int aigv_get_attention_numerics(const aigv_ctx* ctx);
 /* GEMM tile choice of THIS context: -1 = follow the process default set by aigv_tune_gemm (the state after aigv_ctx_create),
  * 0 = the per-sequence row plan (aigv_op_gemm_rows: the default; a clip's / frame's bits do not depend on its batch mates),
  * 1 = every row on the 128x128 kernel, 2 = every row on the 256x256 kernel wherever its shape rules allow, 4 = every row on the
- * co-resident 256x128 kernel (all three in full K, so batch-invariant too and bit-identical with one another: test aliases).  In modes
- * 0 and 3 the GEMMs with K <= AIGV_TUNE_CO_KMAX (InternViT's K = 1024 linears, the patch embedding) run on the co-resident kernel.  Split-K scratch is per context too.  aigv_llm_extend (continuations of a kept
+ * co-resident 256x128 kernel (all three in full K, so batch-invariant too and bit-identical with one another: test aliases).  The
+ * co-resident kernel is otherwise NOT used: AIGV_TUNE_CO_KMAX defaults to 0 (it lost the in-step A/B, profiles/r5_gemmco.txt); an experiment
+ * that raises the knob sends the GEMMs with K <= its value there in modes 0 and 3.  Split-K scratch is per context too.  aigv_llm_extend (continuations of a kept
  * prefix) still uses the batch-level cost-model dispatch of aigv_op_gemm. */
 int aigv_set_gemm_mode(aigv_ctx* ctx, int mode);
 
@@ -286,7 +296,7 @@ int aigv_op_frame_resize_ingest(const void* hwc_u8, int n_frames, int in_h, int 
 enum aigv_tune_knob {
   AIGV_TUNE_GEMM_MODE = 0,       /* = aigv_set_gemm_mode */
   AIGV_TUNE_GEMM256_ORDER = 1,   /* tile order of the 256 kernel: 0 by weight size, 1 row groups, 1 + g groups of g column tiles */
-  AIGV_TUNE_GEMM256_VARIANT = 2, /* 0 the shipped schedule, 1 + v schedule variant v (0..3) */
+  AIGV_TUNE_GEMM256_VARIANT = 2, /* 0 the shipped schedule, 1 + v schedule variant v (0..3); 5..7: the 256x256 kernel runs its shipped schedule, the co-resident kernel a diagnostic form (AIGV_CO_DIAG builds only) */
   AIGV_TUNE_ATTN_WAVES = 3,      /* prefill attention: 0 default, 4 / 8 waves per workgroup */
   AIGV_TUNE_SKINNY_P = 4,        /* decode GEMV form: 0 per-shape default, 1 / 2 / 4; 1000 + (wqkv | wo << 3 | w1w3 << 6 | w2 << 9) = one form per GEMV */
   AIGV_TUNE_BODY_TILE = 5,       /* tile kernel of a row plan's body rows: 0 / 1 = 256x256 (shipped), 2 = 128x128 (same bits, slower) */
@@ -307,7 +317,7 @@ int aigv_ctx_tune(aigv_ctx* ctx, int knob, int value);
 int aigv_tune_gemm(int mode, double rate256);
 /* Process default of AIGV_TUNE_CO_KMAX: 0 = the co-resident 256x128 kernel is never chosen by the dispatcher, else the largest K it takes. */
 int aigv_tune_co_gemm(int kmax);
-/* Process default of AIGV_TUNE_TAIL_SLICES / _FUSE_TAILS / _LONE_BODY / _ATTN_LEAD_KEY / _CO_KMAX (value as in aigv_ctx_tune, without the -1). */
+/* Process default of AIGV_TUNE_TAIL_SLICES / _FUSE_TAILS / _LONE_BODY / _ATTN_LEAD_KEY / _CO_KMAX (same value ranges as aigv_ctx_tune, without the -1). */
 int aigv_tune_default(int knob, int value);
 /* The row bands run_gemm would cut an M x N x K problem into (host logic only, no GPU): plan[0] = row tiles (x256 rows) on the
  * 256x256 kernel in whole rounds, or -1 = the whole problem in one launch of that kernel; plan[1] = row tiles on the 256x256

@@ -675,6 +675,106 @@ def test_lookahead_loop_scores_like_the_plain_loop():
     assert all(torch.equal(a["score1"], b["score1"]) and torch.equal(a["logit"], b["logit"]) for a, b in zip(got, want))
 
 
+def _ragged_items(cfg, n_items, T, seed, frame_hw=(300, 400)):
+    """Dataloader-shaped items (stage2_eval.py:908-911: batch_size = 1) with ragged prompts: item i carries i % 3 more question tokens."""
+    g = torch.Generator().manual_seed(seed)
+    items = []
+    for i in range(n_items):
+        toks = synth.canonical_tokens(cfg, 1, T, seed=seed + i)
+        ids, lab = toks["input_ids"], toks["labels"]
+        extra = i % 3
+        if extra:
+            a0 = int((lab[0] != -100).nonzero()[0])
+            fill = torch.randint(3, cfg.llm_config.vocab_size - 16, (1, extra), generator=g)
+            ids = torch.cat([ids[:, :a0], fill, ids[:, a0:]], 1)
+            lab = torch.cat([lab[:, :a0], torch.full((1, extra), -100), lab[:, a0:]], 1)
+        items.append({"input_ids": ids, "labels": lab, "attention_mask": torch.ones_like(ids, dtype=torch.bool), "image_flags": torch.ones(1, T, 1, dtype=torch.long),
+                      "mos": torch.tensor([0.1 * i]), "frames": torch.randint(0, 256, (T,) + frame_hw + (3,), dtype=torch.uint8, generator=g).pin_memory(),
+                      "video_name": [f"clip{i}"]})
+    return items, toks["img_context_token_id"]
+
+
+def test_batched_lookahead_loop_scores_like_the_plain_loop():
+    """eval_utils.batched: the reference's eval loop (stage2_eval.py:908-941) with k consecutive dataloader items scored
+    in ONE forward and the next group's visual front (H2D, resize, InternViT, SlowFast) one group ahead on its own stream.  Ten clips with
+    ragged prompts, uint8 frames from pinned host memory: every clip's score1, level tokens, labels and loss equal the plain one-clip-per-call
+    loop's bit for bit - for k = 4 and k = 3 (a short last group), with and without the look-ahead, eager and under graph replay, with the
+    native SlowFast branch; and with normalised pixel_values [1, T, 3, S, S] as the loop's input."""
+    from aigv_assessor_amd import eval_utils
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    from aigv_assessor_amd.slowfast import SlowFastR50
+    cfg = pkg.tiny(image_size=224, vit_layers=2, llm_layers=2)
+    model = InternVLChatModel(cfg, max_clips=4)
+    model.load_state_dict(synth.make_state_dict(cfg, seed=91, rich=True))
+    model.eval().cuda()
+    T = 8
+    items, ctx_id = _ragged_items(cfg, 10, T, seed=91)
+    model.img_context_token_id = ctx_id
+    model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=3))
+    fr = lambda it: it["frames"]
+
+    def plain():
+        rows = []
+        for it in items:
+            out = model(mos=it["mos"][0].to(torch.bfloat16), pixel_values=model.ingest_frames(it["frames"].cuda()), input_ids=it["input_ids"],
+                        attention_mask=it["attention_mask"], image_flags=it["image_flags"][0], labels=it["labels"])
+            rows.append((out["score1"].cpu().clone(), out["logit"].cpu().clone(), out["label"].cpu().clone(), out["loss"].cpu().clone()))
+        return rows
+    want = plain()
+    assert len({w[0].item() for w in want}) > 5                             # (the clips do score differently)
+    for graph in (False, True):
+        model.enable_graph_replay(graph)
+        for k, ahead in ((4, True), (3, True), (4, False), (1, True)):
+            got = list(eval_utils.batched(items, model, k=k, frames=fr, ahead=ahead))
+            assert len(got) == len(items) and all(a is b for (a, _), b in zip(got, items))
+            for (it, out), (score, logit, label, loss) in zip(got, want):
+                assert not out["score1"].is_cuda and out["logit"].shape == (it["input_ids"].shape[1] - 1,)
+                assert torch.equal(out["score1"], score) and torch.equal(out["logit"], logit) and torch.equal(out["label"], label), (graph, k, ahead)
+                assert torch.equal(out["loss"], loss)
+                assert torch.equal(eval_utils.answer_ids(it["labels"][0], out["logit"]), eval_utils.answer_ids(it["labels"][0], logit))
+    model.enable_graph_replay(False)
+    # normalised pixel_values as the dataloader delivers them ([1, T, 3, S, S] fp32): the default `frames`
+    for it in items:
+        it["pixel_values"] = model.ingest_frames(it["frames"].cuda()).float().cpu()[None]
+    got = list(eval_utils.batched(items, model, k=4))
+    for (_, out), (score, logit, _, _) in zip(got, want):
+        assert torch.equal(out["score1"], score) and torch.equal(out["logit"], logit)
+
+
+def test_graph_replay_survives_passes_of_other_shapes_in_between():
+    """a captured pass must carry its own row-plan table writes, and a replay must not leave the host believing the device
+    table is still the last eager pass's.  Y, Y (captured), X (eager: another prompt length and clip count -> another InternLM2 row plan;
+    another frame count -> another InternViT plan), Y (replayed), X again, generate() in between: every result equals the eager model's."""
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    cfg = pkg.tiny(image_size=224, vit_layers=2, llm_layers=2)
+    model = InternVLChatModel(cfg, max_clips=3)
+    model.load_state_dict(synth.make_state_dict(cfg, seed=93, rich=True))
+    model.eval().cuda()
+    shapes = {"Y": (2, 4), "X": (3, 2), "Z": (1, 6)}                       # (clips, frames per clip): 224 px -> 257 ViT rows per frame (a ragged tail half)
+    data = {}
+    for name, (B, T) in shapes.items():
+        toks = synth.canonical_tokens(cfg, B, T, seed=93 + B)
+        model.img_context_token_id = toks["img_context_token_id"]
+        data[name] = dict(mos=None, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"], labels=toks["labels"],
+                          image_flags=torch.ones(B * T, 1, dtype=torch.long), motion_feature=synth.synthetic_motion(B, cfg.motion_dim, seed=B).cuda())
+        data[name]["frames"] = [synth.synthetic_frames(B * T, 224, seed=300 + 10 * B + i).cuda() for i in range(3)]
+
+    def run(name, i):
+        d = {k: v for k, v in data[name].items() if k != "frames"}
+        o = model(pixel_values=data[name]["frames"][i], **d)
+        torch.cuda.synchronize()
+        return o["score1"].clone(), o["logit"].clone()
+    seq = [("Y", 0), ("Y", 1), ("X", 0), ("Y", 2), ("X", 1), ("Z", 0), ("Y", 0), ("X", 2), ("X", 0), ("Z", 1), ("Y", 1), ("Z", 2), ("X", 1), ("Z", 0)]
+    model.enable_graph_replay(False)
+    eager = [run(n, i) for n, i in seq]
+    model.enable_graph_replay(True)
+    got = [run(n, i) for n, i in seq]
+    assert sum(isinstance(v, tuple) for v in model._graphs.values()) == 3   # all three shapes ended up captured
+    for j, ((s, l), (es, el)) in enumerate(zip(got, eager)):
+        assert torch.equal(s, es) and torch.equal(l, el), (j, seq[j])
+    model.enable_graph_replay(False)
+
+
 def test_experiment_knobs_live_in_the_context(rig):
     """aigv_ctx_tune: the kernel-form knobs are per context - a second model of the same process keeps its own forms -
     and every form computes the same scores up to fp32 summation order (tiny configuration: identical level tokens, score within one

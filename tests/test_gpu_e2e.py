@@ -109,6 +109,32 @@ def assert_levels(got_ids, want_ids, ref_logits_rows):
     return len(bad)
 
 
+def assert_levels_recorded(got_ids, want_ids, top_ids, top_values):
+    """assert_levels with the REFERENCE's own recorded logits (top 8 per answer row: tests/golden/e2e_anchors.pt) in place of a live
+    oracle pass: a differing HIP token must be among the reference's recorded candidates, within 2 bf16 ulps of its winner."""
+    got_ids, want_ids = got_ids.cpu(), want_ids.cpu()
+    assert torch.equal(top_ids[:, 0], want_ids)
+    bad = (got_ids != want_ids).nonzero().flatten().tolist()
+    for r in bad:
+        ids = top_ids[r].tolist()
+        assert int(got_ids[r]) in ids, f"row {r}: hip id {int(got_ids[r])} is not among the reference's top 8 {ids}"
+        a, b = top_values[r, 0].item(), top_values[r, ids.index(int(got_ids[r]))].item()
+        ulp = 2.0 ** (torch.tensor(abs(a)).clamp_min(1e-30).log2().floor().item() - 7)
+        print(f"level row {r}: reference id {want_ids[r].item()} ({a}) vs hip id {got_ids[r].item()} ({b}); gap {abs(a - b) / ulp:.2f} ulp")
+        assert abs(a - b) <= 2 * ulp, f"row {r}: argmax differs beyond a rounding tie"
+    return len(bad)
+
+
+def score_near_recorded_fp32(got, ref_bf16, f32):
+    """score_near_fp32 with the fp32 anchor recorded from the reference (its fp32 pass over the bf16-rounded weights and inputs:
+    tests/golden/make_golden_anchors.py) instead of a live fp32 oracle pass; same bar."""
+    got, ref_bf16, f32 = got.float().cpu(), ref_bf16.float().cpu(), f32.float().cpu()
+    ulp = f32.abs().clamp_min(2.0 ** -126).log2().floor().exp2() * 2.0 ** -7
+    print("score1 reference fp32", f32.tolist(), "|hip - fp32|", (got - f32).abs().tolist(), "|reference bf16 - fp32|", (ref_bf16 - f32).abs().tolist())
+    d = (got - f32).abs()
+    assert bool(((d <= 1.5 * (ref_bf16 - f32).abs() + ulp) | (d <= 4 * ulp * 1.001)).all())
+
+
 def check_levels(out, ref):
     want = ref["label"] != -100
     got = out["logit"].cpu()
@@ -528,6 +554,7 @@ def test_greedy_generate_with_many_sequences(B, T):
 def test_against_reference_golden_vectors(golden_dir):
     """The fixtures were produced by the imported REFERENCE (tests/golden/make_golden.py), not by the oracle."""
     e2e = torch.load(os.path.join(golden_dir, "e2e.pt"), weights_only=True)
+    anchors = torch.load(os.path.join(golden_dir, "e2e_anchors.pt"), weights_only=True)
     cfg = pkg.InternVLChatConfig.from_dict(dict(vision_config=e2e["vision_config"], llm_config=e2e["llm_config"],
                                                 force_image_size=448, select_layer=-1))
     for tag in ("bf16_b1", "bf16_b2"):
@@ -542,16 +569,11 @@ def test_against_reference_golden_vectors(golden_dir):
                     image_flags=torch.ones(B * T, 1, dtype=torch.long), labels=toks["labels"],
                     motion_feature=synth.synthetic_motion(B, 2304, seed=seed))
         want = g["label"] != -100
-        # reference logits for the tie rule come from the oracle (bit-pinned to the reference by test_oracle_golden)
-        ref = O.forward_eval(sd, cfg, synth.synthetic_frames(B * T, 448, seed=seed), toks["input_ids"], toks["attention_mask"],
-                             torch.ones(B * T, 1, dtype=torch.long), toks["labels"], synth.synthetic_motion(B, 2304, seed=seed),
-                             toks["img_context_token_id"], stage=2, return_intermediates=True)
-        # (the oracle re-run on THIS host's CPU may differ from the golden in non-answer rows: other BLAS kernels)
-        logits = ref["logits"][..., :-1, :].reshape(-1, ref["logits"].shape[-1])[want]
-        assert assert_levels(out["logit"].cpu()[want], g["logit"][want], logits) <= 2
+        # the tie rule and the fp32 anchor read the reference's own recorded logits / fp32 pass (e2e_anchors.pt; a live oracle pass until round 5)
+        a = anchors[f"internlm2/{seed}"]
+        assert assert_levels_recorded(out["logit"].cpu()[want], g["logit"][want], a["top_ids"], a["top_values"]) <= 2
         score_ok(out["score1"], g["score1"], ulps=4)       # 4096-wide LLM: see score_near_fp32
-        score_near_fp32(out["score1"], g["score1"], cfg, sd, toks, synth.synthetic_frames(B * T, 448, seed=seed), synth.synthetic_motion(B, 2304, seed=seed),
-                        torch.ones(B * T, 1, dtype=torch.long))
+        score_near_recorded_fp32(out["score1"], g["score1"], a["score1_fp32_of_bf16_weights"])
         del model
         torch.cuda.empty_cache()
 
@@ -562,6 +584,7 @@ def test_llama_family_against_the_reference_golden_vectors(golden_dir):
     recorded with that LLM class (tests/golden/make_golden_llama.py) - same bars as the InternLM2 fixture of the same widths."""
     from aigv_assessor_amd import weights
     g = torch.load(os.path.join(golden_dir, "e2e_llama.pt"), weights_only=True)
+    anchors = torch.load(os.path.join(golden_dir, "e2e_anchors.pt"), weights_only=True)
     cfg = pkg.InternVLChatConfig.from_dict(dict(vision_config=g["vision_config"], llm_config=g["llm_config"], force_image_size=448, select_layer=-1))
     for tag in ("bf16_b1", "bf16_b2"):
         c = g[tag]
@@ -575,12 +598,10 @@ def test_llama_family_against_the_reference_golden_vectors(golden_dir):
         out = model(mos=torch.full((B,), 0.5, dtype=BF), pixel_values=pv, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
                     image_flags=flags, labels=toks["labels"], motion_feature=motion)
         want = c["label"] != -100
-        ref = O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion, toks["img_context_token_id"],
-                             stage=2, return_intermediates=True)      # the oracle's Llama branch (bit-pinned to the reference: test_oracle_golden)
-        logits = ref["logits"][..., :-1, :].reshape(-1, ref["logits"].shape[-1])[want]
-        assert assert_levels(out["logit"].cpu()[want], c["logit"][want], logits) <= 2
+        a = anchors[f"llama/{seed}"]        # the reference's recorded answer-row logits and fp32 pass (a live oracle pass until round 5)
+        assert assert_levels_recorded(out["logit"].cpu()[want], c["logit"][want], a["top_ids"], a["top_values"]) <= 2
         score_ok(out["score1"], c["score1"], ulps=4)
-        score_near_fp32(out["score1"], c["score1"], cfg, sd, toks, pv, motion, flags)
+        score_near_recorded_fp32(out["score1"], c["score1"], a["score1_fp32_of_bf16_weights"])
         if tag == "bf16_b1":   # greedy decode through the KV cache against the reference LLM's own cache path
             n_prompt = c["greedy_prompt_len"]
             ids = toks["input_ids"][:, :n_prompt]
@@ -687,20 +708,22 @@ def test_26b_widths_and_16_frames_smoke():
     score_ok(out["score1"], ref["score1"])
 
 
-def test_config4_26b_true_widths_stage1_16_frames():
+def test_config4_26b_true_widths_stage1():
     """BASELINE config 4 at its TRUE widths, reduced only in depth and vocabulary: InternViT-6B (hidden 3200, 25 heads x 128,
     intermediate 12800, RMSNorm + QK-norm) and InternLM2-20B (hidden 6144, 48 q / 8 kv heads, intermediate 16384), two layers each,
-    stage-1 flavour (quality-level decode: no score head), one 16-frame 448-px clip -> N = 4281 tokens; against the oracle.
-    (The reference model cannot be built at these widths: its score head and motion projector hard-code 4096)"""
+    stage-1 flavour (quality-level decode: no score head), one 8-frame 448-px clip -> N = 2177 tokens; against the live oracle.
+    (16 frames / N = 4281 at these widths run at FULL depth in test_config4_26b_full_depth_matches_the_oracle and at reduced widths in
+    test_26b_widths_and_16_frames_smoke; the layers themselves are pinned on the reference by tests/golden/layers_26b.pt.  The reference
+    model cannot be built at these widths: its score head and motion projector hard-code 4096)"""
     cfg = pkg.internvl2_26b()
     cfg.vision_config.num_hidden_layers = 2
     cfg.llm_config.num_hidden_layers = 2
     cfg.llm_config.vocab_size = 4096
     assert cfg.vision_config.intermediate_size == 12800 and cfg.llm_config.intermediate_size == 16384
-    B, T, seed = 1, 16, 14
+    B, T, seed = 1, 8, 14
     sd = synth.make_state_dict(cfg, seed=seed, rich=True)
     toks = synth.canonical_tokens(cfg, B, T, seed=seed)
-    assert toks["input_ids"].shape[1] == 4281
+    assert toks["input_ids"].shape[1] == 2177
     pv = synth.synthetic_frames(B * T, 448, seed=seed)
     motion = synth.synthetic_motion(B, cfg.motion_dim, seed=seed)
     flags = torch.ones(B * T, 1, dtype=torch.long)
@@ -765,14 +788,15 @@ def test_config4_26b_full_depth_matches_the_oracle(golden_dir):
 
 def test_config5_fp8_mode_at_8b_widths():
     """BASELINE config 5's arithmetic at the 8B WIDTHS (hidden 4096, 32 q / 8 kv heads, intermediate 14336; three decoder layers, one
-    InternViT-300M layer, reduced vocabulary), two 8-frame clips: the e4m3 linears against oracle/fp8.py - the kernel form that
-    runs at full size (256-tile rounds + split-K tails at M = 4352), not the tiny-dimension instantiation of the test above."""
+    InternViT-300M layer, reduced vocabulary), two 4-frame clips (1124 rows each: four 256-row body tiles + a 100-row split-K tail per clip -
+    the kernel forms of the full-size pass; 8 frames until round 5, halved for the CPU oracle's three passes): the e4m3 linears against
+    oracle/fp8.py, not the tiny-dimension instantiation of the test above."""
     from oracle import fp8 as O8
     cfg = pkg.internvl2_8b()
     cfg.vision_config.num_hidden_layers = 1
     cfg.llm_config.num_hidden_layers = 3
     cfg.llm_config.vocab_size = 4096
-    B, T, seed = 2, 8, 15
+    B, T, seed = 2, 4, 15
     model, sd, toks, pv, motion, ref, out = run_case(cfg, B=B, T=T, seed=seed)             # bf16 pass + bf16 oracle
     check_levels(out, ref)
     flags = torch.ones(B * T, 1, dtype=torch.long)
@@ -846,7 +870,9 @@ def test_decode_at_8b_widths_bf16_and_fp8_modes(B):
     cfg.vision_config.num_hidden_layers = 1
     cfg.llm_config.num_hidden_layers = 3
     cfg.llm_config.vocab_size = 4096
-    T, seed, n_new = 8, 16, 6 if B == 1 else 4
+    # (2 frames per clip - a 599-token prompt: the decode-step forms under test depend on the widths and on B, not on the prompt length, and
+    # the CPU oracle's prefill of the prompt is what this test's wall time was: 88 s of the driver's 900 s at 8 frames, round 5)
+    T, seed, n_new = 2, 16, 6 if B == 1 else 4
     sd = synth.make_state_dict(cfg, seed=seed, rich=True)
     toks = synth.canonical_tokens(cfg, B, T, seed=seed)
     n_prompt = int((toks["labels"][0] == -100).sum())

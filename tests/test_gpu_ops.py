@@ -8,6 +8,7 @@ the kernel must be at least as accurate as that path (flash-style accumulation c
 Byte-moving ops (im2col, pixel-shuffle) are bit-exact.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -15,6 +16,20 @@ import torch
 pytestmark = pytest.mark.gpu
 
 BF = torch.bfloat16
+
+# The families below that re-prove ``torch.equal`` between two kernel forms of the SAME arithmetic (tile kernels, tile orders, row plans,
+# fused / separate tails) run, by default, every shape ONCE and every epilogue at least once (the diagonal of shapes x epilogues); the full
+# cross product (5 epilogues x 4-9 shapes x up to 5 modes: ~190 more cases) runs under AIGV_FULL_MATRIX=1 - the driver's `-m gpu` step has
+# 900 s for the whole suite (tests/manual/README.md).  The numerics tests against the fp32 reference are not thinned.
+FULL_MATRIX = os.environ.get("AIGV_FULL_MATRIX") == "1"
+
+
+def per_epilogue(shapes, second=(0, 1, 2, 3, 4)):
+    """``shapes`` x ``second`` (epilogues, or kernel modes) as parametrize cases: the cross product under AIGV_FULL_MATRIX=1, else its diagonal."""
+    if FULL_MATRIX:
+        return [tuple(sh) + (e,) for sh in shapes for e in second]
+    n = max(len(shapes), len(second))
+    return [tuple(shapes[i % len(shapes)]) + (second[i % len(second)],) for i in range(n)]
 
 
 @pytest.fixture(scope="module")
@@ -142,10 +157,9 @@ def _run_gemm_rows(lib, A, W, bias, ls, resid, nout, lens, epi):
 
 # sequences: whole tiles only; the benched clip (2176 = 8 x 256 + 128); ragged tails of one and two halves; InternViT frames (1025 =
 # 4 x 256 + 1: tiny tails on the skinny kernel, uniform and not); sequences shorter than a half tile; N = 256 j + 128 (column split)
-@pytest.mark.parametrize("lens,N,K", [([512, 256], 256, 128), ([2176, 2176, 2176], 512, 1024), ([300, 77, 1000, 129, 511], 768, 512),
-                                      ([1025] * 5, 512, 1024), ([1025, 1027, 258, 3], 256, 256), ([40, 5, 130], 384, 192),
-                                      ([2176] * 4, 1024, 3584)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("lens,N,K,epi", per_epilogue([([512, 256], 256, 128), ([2176, 2176, 2176], 512, 1024), ([300, 77, 1000, 129, 511], 768, 512),
+                                                      ([1025] * 5, 512, 1024), ([1025, 1027, 258, 3], 256, 256), ([40, 5, 130], 384, 192),
+                                                      ([2176] * 4, 1024, 3584)]))
 def test_gemm_row_plan_epilogues(lib, lens, N, K, epi):
     """aigv_op_gemm_rows - the scoring pass's dispatch: per-sequence body tiles through the half-tile table, (ragged) tail halves as
     K slices with a factor fixed by (N, K), tiny tails on the skinny kernel - against the rounded fp32 reference."""
@@ -156,8 +170,7 @@ def test_gemm_row_plan_epilogues(lib, lens, N, K, epi):
     ulp_check(got, want, frac=0.03 if epi in (1, 4) else 0.02, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
-@pytest.mark.parametrize("N,K", [(512, 1024), (1024, 3584), (384, 256)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("N,K,epi", per_epilogue([(512, 1024), (1024, 3584), (384, 256)]))
 def test_gemm_row_plan_is_batch_invariant(lib, N, K, epi):
     """A sequence's rows give the same BITS whatever the other sequences of the call are: every sequence of a mixed
     batch alone == inside the batch, for body rows, split-K tail halves (one and two, ragged) and tiny tails."""
@@ -184,8 +197,7 @@ def test_gemm_row_plan_is_batch_invariant(lib, N, K, epi):
             assert torch.equal(got[i * n:(i + 1) * n].view(torch.int16), both[sl].view(torch.int16))
 
 
-@pytest.mark.parametrize("lens,N,K", [([2176], 4096, 4096), ([2176], 6144, 4096), ([2176, 2176], 4096, 14336), ([300, 2176, 641], 1024, 3584), ([2233], 512, 2048)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("lens,N,K,epi", per_epilogue([([2176], 4096, 4096), ([2176], 6144, 4096), ([2176, 2176], 4096, 14336), ([300, 2176, 641], 1024, 3584), ([2233], 512, 2048)]))
 def test_gemm_row_plan_fused_tail_slices_change_no_bit(lib, lens, N, K, epi):
     """One or two clips leave the body's last round of CUs part empty; the tail tiles' K slices then run INSIDE the body's launch
     (gemm256_kernel<.., FUSE>; AIGV_TUNE_FUSE_TAILS 0 = by fill, 1 = never, 2 = always).  Same slices, same slabs, same finalize pass:
@@ -208,8 +220,7 @@ def test_gemm_row_plan_fused_tail_slices_change_no_bit(lib, lens, N, K, epi):
     ulp_check(outs[1], gemm_ref(A, W, epi, bias, ls, resid), frac=0.03, max_ulps=4 if epi in (1, 4) else 2, atol_rel=2.0 ** -7 if epi in (2, 3) else 2e-5)
 
 
-@pytest.mark.parametrize("lens,N,K", [([2176], 512, 1024), ([1025] * 8, 1024, 1024), ([2176, 300, 1025], 1024, 3584), ([2233], 4096, 4096)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("lens,N,K,epi", per_epilogue([([2176], 512, 1024), ([1025] * 8, 1024, 1024), ([2176, 300, 1025], 1024, 3584), ([2233], 4096, 4096)]))
 def test_gemm_row_plan_body_tile_changes_no_bit(lib, lens, N, K, epi):
     """A row plan's body rows can run on the 256x256 kernel (shipped) or on the 128x128 kernel through the same half-tile table.  Both sum
     every output element over the full K in the same order, so the two give the same BITS - the fact behind 'gemm modes 1 and 2 are
@@ -228,10 +239,10 @@ def test_gemm_row_plan_body_tile_changes_no_bit(lib, lens, N, K, epi):
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)) and torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
 
 
-@pytest.mark.parametrize("mode", [1, 2 + 16, 2 + 32, 2 + 64, 0])
-@pytest.mark.parametrize("M,N,K,epi", [(1100, 512, 448, 0), (777, 256, 64, 1), (515, 768, 1024, 2), (300, 256, 192, 3),
-                                        (1029, 1024, 512, 4), (256, 256, 128, 0),
-                                        (12000, 1408, 256, 0), (12100, 1408, 320, 2), (600, 384, 256, 3)])   # N = 256 j + 128: column split on the big ones
+@pytest.mark.parametrize("M,N,K,epi,mode", per_epilogue([(1100, 512, 448, 0), (777, 256, 64, 1), (515, 768, 1024, 2), (300, 256, 192, 3),
+                                                        (1029, 1024, 512, 4), (256, 256, 128, 0),
+                                                        (12000, 1408, 256, 0), (12100, 1408, 320, 2), (600, 384, 256, 3)],   # N = 256 j + 128: column split on the big ones
+                                                       second=(1, 2 + 16, 2 + 32, 2 + 64, 0)))
 def test_gemm_tile_kernels_agree(lib, mode, M, N, K, epi):
     """mode 1 = 128x128 kernel, 2 + 16*(1+v) = 256x256 phase-interleaved kernel with schedule variant v,
     0 = cost-model split (256 main + 128/skinny tail)."""
@@ -277,9 +288,8 @@ def _op_gemm_mode(lib, mode, co_kmax, A, W, epi, bias, ls, resid, pos=None, np_=
 
 # InternViT's four linears at a few frames (qkv 3072, proj 1024, fc1 4096 out of K = 1024; fc2 K = 4096), ragged row counts (a last
 # tile with one valid half, with 1 row, with 129 rows), K-tile counts 1, 2, 3 (prologue / tail paths of the ring), odd and even, N = 128
-@pytest.mark.parametrize("M,N,K", [(2050, 3072, 1024), (1025, 1024, 1024), (1300, 4096, 1024), (1153, 1024, 4096), (256, 128, 64), (257, 256, 128),
-                                   (129, 384, 192), (4099, 512, 448), (77, 640, 1088)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K,epi", per_epilogue([(2050, 3072, 1024), (1025, 1024, 1024), (1300, 4096, 1024), (1153, 1024, 4096), (256, 128, 64), (257, 256, 128),
+                                                   (129, 384, 192), (4099, 512, 448), (77, 640, 1088)]))
 def test_gemm_co_resident_kernel_equals_the_256_kernel_bit_for_bit(lib, M, N, K, epi):
     """gemmco.hip (256 x 128 tile, two workgroups per CU) against gemm256.hip / gemm.hip: the same MFMA chain per output element and the
     same epilogue rounding points, so torch.equal - the property that lets the dispatcher move InternViT's K = 1024 linears onto it
@@ -316,8 +326,7 @@ def test_gemm_co_resident_kernel_patch_epilogue(lib):
     ulp_check(outs[0].reshape(M, N), gemm_ref(A, W, 5, bias=bias, pos=pos, np_=np_), atol_rel=2.0 ** -7)
 
 
-@pytest.mark.parametrize("lens,N,K", [([1025] * 8, 3072, 1024), ([1025, 1027, 258, 3], 256, 256), ([300, 77, 1000, 129, 511], 768, 512), ([2176, 131], 1024, 1024)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("lens,N,K,epi", per_epilogue([([1025] * 8, 3072, 1024), ([1025, 1027, 258, 3], 256, 256), ([300, 77, 1000, 129, 511], 768, 512), ([2176, 131], 1024, 1024)]))
 def test_gemm_row_plan_on_the_co_resident_kernel(lib, lens, N, K, epi):
     """aigv_op_gemm_rows with K <= the co-resident threshold (aigv_tune_co_gemm; off by default): body AND tail half tiles of every sequence in ONE launch of gemmco.hip
     through the half-tile table (ragged halves, halves of different sequences sharing a tile), tiny tails on the skinny kernel.  Every
