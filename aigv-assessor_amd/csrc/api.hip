@@ -732,45 +732,11 @@ int run_gemm_fp8(aigv_ctx* c, const bf16_t* A, int lda, int K, const uint8_t* W8
   a.A = (const bf16_t*)c->q8; a.lda = K; a.W = (const bf16_t*)W8; a.ldw = K; a.C = C; a.ldc = ldc; a.M = T; a.N = N; a.K = K;
   a.row_scale = c->q8_scale; a.col_scale = w_scale; a.resid = resid; a.ldr = ldr;
   ProfScope ps(c, AIGV_PROF_GEMM_FP8, 2.0 * T * (double)N * K, (double)T * K + (double)N * K + 2.0 * T * (epi == EPI_SWIGLU ? N / 2 : N), s);
-  // Row bands as in run_gemm: the rows that make WHOLE rounds of 256 tiles in one launch; the rest - a partial round - as K slices
-  // (scaled fp32 slabs + the bf16 path's finalize pass) when that fills the chip better, else as one more plain launch.
-  auto rows8 = [&](int row0, int rows) {   // row_slice for byte-addressed A
-    GemmArgs b = a;
-    b.M = rows;
-    b.A = (const bf16_t*)(c->q8 + (size_t)row0 * K);
-    b.C = a.C + (size_t)row0 * a.ldc;
-    b.row_scale = a.row_scale + row0;
-    if (a.resid) b.resid = a.resid + (size_t)row0 * a.ldr;
-    return b;
-  };
-  const int tn = N / 256, rt = (T + 255) / 256, nk = K / 128;
-  int unit = 256;   // row tiles per whole number of rounds: 256 / gcd(256, tn)
-  for (int g2 = 256; g2 >= 1; g2 >>= 1)
-    if (tn % g2 == 0) { unit = 256 / g2; break; }
-  int R = (T / 256) / unit * unit;
-  if ((rt - R) * tn > 128) R = 0;   // a tail of more than half a round runs best inside ONE launch (measured: w1|w3 at batch 4, 14.875 rounds)
-  int row = 0;
-  if (R > 0) {
-    e = aigv_launch_gemm256_fp8(rows8(0, R * 256), epi, s);
-    if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "fp8 gemm (M=%d N=%d K=%d epi=%d): %s", T, N, K, epi, hipGetErrorString(e));
-    row = R * 256;
-  }
-  if (row < T) {
-    const GemmArgs b = rows8(row, T - row);
-    const int tail_tiles = (rt - R) * tn;
-    int S = 1;
-    if (tail_tiles <= 128 && R > 0)
-      for (int cand : {8, 6, 4, 3, 2})
-        if (nk % cand == 0 && nk / cand >= 4 && tail_tiles * cand <= 288 && (size_t)cand * b.M * N <= SPLITK_MAX_FLOATS) { S = cand; break; }
-    if (S >= 2) {
-      float* ws = nullptr;
-      TRY(splitk_scratch(c, (size_t)S * b.M * N, &ws));
-      e = aigv_launch_gemm_splitk_fp8(b, epi, S, ws, s);
-    } else {
-      e = aigv_launch_gemm256_fp8(b, epi, s);
-    }
-    if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "fp8 gemm tail (M=%d N=%d K=%d epi=%d): %s", b.M, N, K, epi, hipGetErrorString(e));
-  }
+  // ONE launch over all rows, every row in full K on the one e4m3 tile kernel: an output element's sum then runs over K in the same order
+  // wherever its row sits, so a clip's bits do not depend on its batch mates - in this mode too (round 6; until round 5 the partial last
+  // round of a batch ran as K slices, which tied a row's summation order to the size of the batch).
+  e = aigv_launch_gemm256_fp8(a, epi, s);
+  if (e != hipSuccess) return fail(c, e == hipErrorInvalidValue ? AIGV_ERR_ARG : AIGV_ERR_HIP, "fp8 gemm (M=%d N=%d K=%d epi=%d): %s", T, N, K, epi, hipGetErrorString(e));
   return 0;
 }
 
@@ -1435,7 +1401,7 @@ int aigv_llm_prefill(aigv_ctx* c, const int64_t* ids, const int32_t* slot, const
   HIPCHK(c, aigv_launch_seqpos(cu, B, c->l_pos, c->l_seq, c->l_cu, T, s));
   // every clip is a sequence: the kernel form of a row follows from its place in its own clip (struct RowPlan)
   TRY(build_row_plan(c, c->rp_llm, cu, B, s));
-  RowPlanScope rps(c, c->fp8_llm ? nullptr : &c->rp_llm);
+  RowPlanScope rps(c, &c->rp_llm);   // (fp8 mode: its bf16 GEMMs - the post-attention half of the last layer - follow the per-clip plan too)
 
   HIPCHK(c, aigv_launch_embed(ids, slot, c->tok_emb, (const bf16_t*)vis, (const bf16_t*)motion, n_vis, c->l_h, T, H, s));
   TRY(upload_out_rows(c, score_rows, score != nullptr, B, logit_rows, R, T, s));

@@ -84,6 +84,19 @@ __device__ __forceinline__ void wait_vm(int n) {   // n in {0,2,4,6,8}, wave-uni
 //      the table: fp32 slabs, as EPI_PARTIAL) - for launches whose body does not fill its last round of CUs (one or two clips), where a
 //      separate slice launch would run behind a half-empty chip.  Same slices, same slabs, same finalize pass: not one bit differs from the
 //      two-launch form.
+// The 16-byte row-segment store of the staged epilogues.  Product build: a plain global_store_dwordx4.  A/B build (-DAIGV_STORE_POLICY_AB,
+// scripts/store_policy_ab.py): GemmArgs::variant_sel 5 / 6 / 7 pick the cache policy of that store - nt / sc1 / sc1 nt -
+// per launch, so that one process can interleave the arms (the schedule is variant 1, the shipped one, in all of them).  Same bits.
+__device__ __forceinline__ void store_row_segment(bf16_t* dst, const u16x8& val, int policy) {
+#ifdef AIGV_STORE_POLICY_AB
+  if (policy == 5) { asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(val) : "memory"); return; }
+  if (policy == 6) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(val) : "memory"); return; }
+  if (policy == 7) { asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(val) : "memory"); return; }
+#endif
+  (void)policy;
+  *(u16x8*)dst = val;
+}
+
 template <int EPI, int VAR, bool FP8 = false, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   static_assert(!FP8 || ((VAR & 4) != 0 && EPI != EPI_PATCH), "the fp8 form uses the LDS-staged epilogue (or writes split-K slabs)");
@@ -468,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           const int r = i * 8 + (lane >> 3), ch = lane & 7;
           const int m = hb + mh * 64 + mt * 16 + r;
           const u16x8 val = *(const u16x8*)(st + r * STAGE_ROWP + ch * 16);
-          if (m < hend) *(u16x8*)(p.C + (size_t)m * p.ldc + n0 + wc * 64 + ch * 8) = val;
+          if (m < hend) store_row_segment(p.C + (size_t)m * p.ldc + n0 + wc * 64 + ch * 8, val, p.variant_sel);
         }
       }
     }
@@ -583,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) val[e] = f2bf(bf2f(rs[e]) + bf2f(val[e]));
           }
-          *(u16x8*)(p.C + orow * p.ldc + n) = val;
+          store_row_segment(p.C + orow * p.ldc + n, val, p.variant_sel);
         }
       }
     }

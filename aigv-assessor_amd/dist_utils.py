@@ -29,6 +29,21 @@ timeout = timedelta(minutes=60)
 # A one-rank group needs no collective.  Set to True to run them anyway (a one-rank RCCL all-gather is a device copy through RCCL's own
 # stream and work handle): how the collective path is exercised on a single MI355X (tests/test_gpu_dist.py, bench.py --force-dp).
 force_single_rank_collectives = False
+# Measurement hook (bench.py's roofline pass only): a list -> every device all-gather issued through all_gather_rows_begin is completed AT
+# ONCE (no overlap with compute in that pass) between two events on the compute stream and booked here as (receive-buffer bytes, start, end);
+# read_collective_timing() turns the list into milliseconds.  None (the default, and always inside a timed region): nothing is recorded.
+collective_timing = None
+
+
+def read_collective_timing():
+    """[(bytes of the gathered buffer, milliseconds)] of the all-gathers booked since ``collective_timing`` was set to a list; clears it."""
+    global collective_timing
+    if not collective_timing:
+        return []
+    torch.cuda.synchronize()
+    out = [(n, a.elapsed_time(b)) for n, a, b in collective_timing]
+    collective_timing = []
+    return out
 
 
 def init_dist(launcher: str, backend: str = "nccl", **kwargs):
@@ -134,6 +149,13 @@ def all_gather_rows_begin(local: torch.Tensor, counts: List[int], group=None):
         out = out_h.to(local.device)
         return lambda: GatheredRows(out, counts)
     out = torch.empty((world * m,) + tail, dtype=local.dtype, device=local.device)
+    if collective_timing is not None and local.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dist.all_gather_into_tensor(out, send, group=group, async_op=True).wait()
+        e1.record()
+        collective_timing.append((out.numel() * out.element_size(), e0, e1))
+        return lambda: GatheredRows(out, counts)
     work = dist.all_gather_into_tensor(out, send, group=group, async_op=True)
 
     def finish():

@@ -140,6 +140,22 @@ def make_state_dict(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16
     return dict(make_state_dict_iter(cfg, seed=seed, dtype=dtype, device=device, rich=rich))
 
 
+def condition_state_dict(sd: Dict[str, torch.Tensor], cfg: InternVLChatConfig) -> Dict[str, torch.Tensor]:
+    """In place: make a seeded iid weight set look like a TRAINED checkpoint where that matters for how rounding noise travels through the
+    depth: InternViT's layer scales ``ls1`` / ``ls2`` x 0.1 (trained InternViT checkpoints hold ~0.1; config.json's
+    ``initializer_factor`` only sets the init) and every InternLM2 ``wo`` / ``w2`` x 1 / sqrt(2 L) (the depth-scaled residual-branch
+    init of GPT-2-style training; 0.125 at L = 32: exact in bf16), so that each block ADDS a small update to the residual stream
+    instead of replacing it.  Deterministic (fp32 multiply, one rounding back to the tensor's dtype)."""
+    L = cfg.llm_config.num_hidden_layers
+    down = 1.0 / (2.0 * L) ** 0.5
+    for k, v in sd.items():
+        if k.startswith("vision_model.encoder.layers.") and (k.endswith(".ls1") or k.endswith(".ls2")):
+            sd[k] = (v.float() * 0.1).to(v.dtype)
+        elif k.startswith("language_model.model.layers.") and (k.endswith("attention.wo.weight") or k.endswith("feed_forward.w2.weight")):
+            sd[k] = (v.float() * down).to(v.dtype)
+    return sd
+
+
 def canonical_tokens(cfg: InternVLChatConfig, n_clips: int, n_frames: int, seed: int = 0,
                      answer_len: int = 9) -> Dict[str, torch.Tensor]:
     """input_ids / labels / attention_mask in the canonical layout of SURVEY.md §8d."""

@@ -248,6 +248,7 @@ def parity_vs_reference(model, cfg, dev):
                     s = c5[f"batch4/seed{seed}/t{t}"]["score1"].float()
                     d += [abs(float(s[i] - base[i])) / 2.0 ** (torch.tensor(abs(float(base[i]))).clamp_min(1e-30).log2().floor().item() - 7) for i in range(len(s))]
         if d:
+            res.setdefault("reference_vs_itself", {})
             res["reference_vs_itself"]["benched_shape_threads_1_2_4_vs_8_ulps"] = {"n": len(d), "mean": sum(d) / len(d), "max": max(d)}
             res["reference_vs_itself"]["all_37_clip_sample"] = "profiles/r5_parity_stats.txt: reference against itself 2.56 mean / 8.0 max bf16 ulps over 44 pairs; this path 2.80 mean / 9.0 max over 37 clips"
     res["parity_note"] = ("one pass per recorded batch (4 clips x 8 frames; seed-0 inputs = the benched batch, seed-1 = a second batch of the shape; motion_feature "
@@ -457,10 +458,29 @@ def reference_loop_metric(model, cfg, toks, dev, T, n_clips=6):
     gaps = sorted((b - a) * 1e3 for a, b in zip(marks[2:-1], marks[3:]))
     ahead_ms = gaps[len(gaps) // 2]
     same = all(a == scores[i][0] for i, a in enumerate(ahead_scores[: len(scores)]))
+    # the same loop through eval_utils.batched: k = 4 consecutive dataloader items (batch-1 ids / labels / flags, each clip's uint8 720p frames in its
+    # own pinned host buffer) scored by ONE forward, the next group's visual front one group ahead, ONE host synchronisation per group
+    k, n_groups = 4, 5
+    item = lambda i: {"input_ids": ids, "attention_mask": am, "labels": labels, "image_flags": flags[None], "frames": clips[i % 2],
+                      **({} if motion is None else {"motion_feature": motion})}
+    marks, group_scores = [], []
+    torch.cuda.synchronize()
+    for j, (_, o) in enumerate(eval_utils.batched((item(i) for i in range(k * (n_groups + 3))), model, k=k, frames=lambda it: it["frames"])):
+        group_scores.append(o["score1"].item())
+        eval_utils.answer_ids(labels[0], o["logit"])
+        if j % k == k - 1:
+            marks.append(time.perf_counter())
+    bgaps = sorted((b - a) * 1e3 / k for a, b in zip(marks[2:-1], marks[3:]))
+    batched_ms = bgaps[len(bgaps) // 2]
+    bsame = all(a == scores[i % 2][0] for i, a in enumerate(group_scores))
     return {"latency_ms_per_clip": ms, "clips_per_s": 1e3 / ms, "clips_timed": n_clips, "ms_min_max": [times[0], times[-1]],
             "lookahead": {"ms_per_clip": ahead_ms, "clips_per_s": 1e3 / ahead_ms, "ms_min_max": [gaps[0], gaps[-1]], "scores_equal_the_plain_loop": same,
                           "what": "the same loop through eval_utils.lookahead (a two-line change of the driver): the next clip's H2D + resize + InternViT + SlowFast run on their own "
                                   "stream beside the current clip's InternLM2 pass; median clip-to-clip wall time"},
+            "batched": {"ms_per_clip": batched_ms, "clips_per_s": 1e3 / batched_ms, "k": k, "ms_min_max": [bgaps[0], bgaps[-1]], "scores_equal_the_plain_loop": bsame,
+                        "what": f"the same loop through eval_utils.batched(k = {k}) (a two-line change of the driver): {k} consecutive batch-1 dataloader items - each clip's uint8 720p "
+                                "frames in its own pinned host buffer - scored by ONE forward, the next group's H2D + resize + InternViT + SlowFast one group ahead on their own "
+                                f"stream, ONE host synchronisation per group; median group-to-group wall time / {k}"},
             "shape": (f"the reference's eval loop (stage2_eval.py:908-941): batch 1, per clip {T} uint8 720p frames from pinned host memory -> H2D -> BICUBIC "
                       "resize + normalise -> forward -> score1.item() + answer-token slice on the host; median of the timed clips after two warm-up clips")}
 
@@ -618,6 +638,22 @@ def main():
         if not dry:
             torch.cuda.synchronize()
 
+    # first contact (the driver's 8-GPU run is the only N > 1 run on hardware there is): which device every rank really sits on, gathered
+    # through the process group itself - N ranks must report N distinct devices, or the run stops here instead of producing a number
+    pg_devices = None
+    if dist.is_initialized():
+        if dry:
+            me = {"rank": rank, "local_rank": local_rank, "device": f"cpu:{os.getpid()}"}
+        else:
+            pr = torch.cuda.get_device_properties(dev)
+            ident = str(getattr(pr, "uuid", "")) or "pci " + ":".join(str(getattr(pr, a, "?")) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+            me = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "device": ident, "name": pr.name}
+        pg_devices = [None] * world
+        dist.all_gather_object(pg_devices, me)
+        shared = bool(os.environ.get("AIGV_BENCH_SHARE_DEVICE"))
+        if len({d["device"] for d in pg_devices}) != world and not shared:
+            raise SystemExit(f"bench.py: {world} ranks report {len({d['device'] for d in pg_devices})} distinct devices: {pg_devices}")
+
     # N = 1: the step is captured into a HIP graph (InternVLChatModel.enable_graph_replay: first call eager, second captured, then replayed -
     # one host call per step instead of ~1000 launches; same kernels, same bits).  Three untimed priming steps make sure that the W warm-up
     # steps and everything behind them are replays whatever W is.  The per-launch roofline pass below runs eager (its HIP events are per launch).
@@ -705,6 +741,9 @@ def main():
     # the per-launch durations themselves are unaffected (they agree with the rocprofv3 kernel trace in profiles/).
     prof = rank == 0 and not args.no_prof and not dry
     dt_prof = None
+    from aigv_assessor_amd import dist_utils as _dist_utils
+    if dist.is_initialized() and not dry and not args.no_prof and dist.get_backend() == "nccl":
+        _dist_utils.collective_timing = []      # this pass only (every rank alike: same schedule): each all-gather completed at once, between two events
     if prof:
         model.prof_enable(True)
         fence()
@@ -721,6 +760,8 @@ def main():
         for _ in range(args.steps):
             out = step()
         fence()
+    coll = _dist_utils.read_collective_timing() if _dist_utils.collective_timing is not None else []
+    _dist_utils.collective_timing = None
     rank_ms = [1e3 * dt / args.steps]
     if world > 1:
         mine = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -767,7 +808,8 @@ def main():
                                       "where the container's CPU quota throttles the launching thread (profiles/r5_graph_replay.txt)"} if graph_mode else
                        {"mode": "eager: every kernel launched from the host"}),
             "ms_per_step_by_rank": rank_ms,
-            "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist.is_initialized() else None),
+            "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": pg_devices,
+                               "distinct_devices": len({d["device"] for d in pg_devices})} if dist.is_initialized() else None),
             "ranks_share_one_device": bool(os.environ.get("AIGV_BENCH_SHARE_DEVICE")),
             "protocol": (f"{args.warmup} warmup steps; {min(5, args.steps)} untimed-but-reported steps (presettle_ms_per_step); "
                          + ("no settling; " if args.no_settle else "untimed settling batches of 5 steps until two agree within 3 %, at most 30 s (settle_ms_per_step); ")
@@ -790,8 +832,17 @@ def main():
                     traffic = tj["all_gemm"]["traffic_bytes_per_launch"]
                     tnote = (f"NOT measured in this run: a committed constant - L2<->fabric bytes per GEMM launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                              f"passes of this command (profiles/{os.path.basename(tf)}, scripts/pmc_summary.py); a PMC pass cannot run inside the timed process")
+                # the ceiling this chip SUSTAINS on a bare LDS-fed MFMA loop of the kernel's wave tile (it lowers its clock under MFMA load: 2.5 PF assumes
+                # 2.4 GHz): scripts/mfma_lds_probe.hip, re-measured per round on this pool's MI355X class (a committed constant, not measured in this run)
+                sp = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_mfma_lds_probe.json") for r in (6,)) if os.path.exists(f)), None)
+                sustained = None
+                if sp:
+                    sj = json.load(open(sp))
+                    sustained = {"value": sj["sustained_peak_tflops"], "unit": "TFLOP/s", "frac": ach / sj["sustained_peak_tflops"], "in_kernel_clock_mhz": sj["in_kernel_clock_mhz"],
+                                 "note": f"NOT measured in this run: the bare ds_read_b128 + v_mfma_f32_16x16x32_bf16 loop of the shipped 128x64 wave tile on an MI355X of this pool "
+                                         f"(profiles/{os.path.basename(sp)}, scripts/mfma_lds_probe.hip); `frac` above stays achieved / the 2500 TFLOP/s spec peak"}
                 line["roofline"] = {
-                    "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                    "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "sustained_peak": sustained,
                     "traffic": traffic, "traffic_note": tnote, "algorithmic_bytes_per_launch": gm["bytes"] / gm["launches"],
                     "kernel": "bf16 MFMA GEMM (gemm256_kernel 256x256x64 phase-interleaved + gemm_bf16_kernel 128x128x64 / skinny tails, all epilogues)",
                     "measured": f"HIP events on the launch stream around every launch, second pass of {args.steps} steps ({1e3 * dt_prof / args.steps:.1f} ms/step with the events)",
@@ -814,6 +865,14 @@ def main():
                     "attn_vit": cls("attn_vit", "InternViT attention (non-causal, d = 64, 1025 rows per frame)"),
                     "attn_llm": cls("attn_llm", "InternLM2 prefill attention (causal GQA, d = 128)"),
                 }
+        if coll:   # the RCCL token all-gather as rank 0 saw it in the roofline pass (completed at once there; overlapped in the timed steps)
+            big = max(n for n, _ in coll)
+            ms_ = sorted(t for n, t in coll if n == big)
+            med = ms_[len(ms_) // 2]
+            line["token_all_gather"] = {"gathered_bytes": big, "launches": len(ms_), "ms_median": med, "ms_min_max": [ms_[0], ms_[-1]],
+                                        "GB_per_s_received_per_rank": big * (world - 1) / max(world, 1) / (med * 1e-3) / 1e9 if world > 1 else None,
+                                        "note": "all_gather_into_tensor of the pre-projector visual tokens, issue -> completion between two events on the compute stream, "
+                                                "roofline pass only (there it is waited for at once; in the timed steps it overlaps the InternLM2 pass where the clip split allows)"}
         if prof and args.precision == "fp8":
             g8 = p["gemm_fp8"]   # (prof_read consumes the records: `p` is the one read of this run)
             if g8["launches"]:

@@ -13,7 +13,11 @@ Every (numerics, mode) pair is a CORRECT evaluation of the same arithmetic defin
 the score matrix rounds).  Printed per arm: mean / 95th percentile / max of |hip - ref bf16| and of |hip - ref fp32| in bf16 ulps of the score, the
 number of clips with the identical bf16 score, level tokens differing; then the same statistics of the reference against itself.
 
-    python tests/manual/parity_stats.py [out.json] [--modes]
+Round 6: the TASK-LEVEL agreement - SRCC / PLCC / KRCC, the reference's own quality metric (stage2_eval.py:652-688) - of the
+HIP scores against the reference's bf16 and fp32 scores over the 37 clips, next to the same statistics of the reference's bf16 pass against its fp32
+pass and of the reference against itself under other host thread counts; for bf16 and, with --fp8, for set_precision("fp8").
+
+    python tests/manual/parity_stats.py [out.json] [--modes] [--fp8]
 """
 import json
 import os
@@ -42,6 +46,15 @@ def stats(v):
 
 def fmt(s):
     return f"mean {s['mean']:.2f}  p95 {s['p95']:.1f}  max {s['max']:.1f}  (n = {s['n']})"
+
+
+def corr(a, b):
+    from scipy.stats import kendalltau, pearsonr, spearmanr
+    return dict(srcc=float(spearmanr(a, b)[0]), plcc=float(pearsonr(a, b)[0]), krcc=float(kendalltau(a, b)[0]), n=len(a))
+
+
+def fmtc(c):
+    return f"SRCC {c['srcc']:.4f}  PLCC {c['plcc']:.4f}  KRCC {c['krcc']:.4f}  (n = {c['n']})"
 
 
 def reference_cases():
@@ -97,6 +110,7 @@ def reference_self_pairs(cases):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     modes = (0, 1, 2) if "--modes" in sys.argv else (0,)
+    precisions = ("bf16", "fp8") if "--fp8" in sys.argv else ("bf16",)
     g, cases = reference_cases()
     cfg = pkg.InternVLChatConfig.from_dict(dict(vision_config=g["vision_config"], llm_config=g["llm_config"], force_image_size=448, select_layer=-1))
     dev = torch.device("cuda", 0)
@@ -110,11 +124,13 @@ def main():
     n_clips = sum(c[1] for c in cases)
     print(f"{n_clips} reference-pinned clips in {len(cases)} recorded passes", flush=True)
     out = {}
-    for numerics in ("reference", "fp32"):
+    for precision in precisions:
+      model.set_precision(precision)
+      for numerics in ("reference", "fp32"):
         model.set_attention_numerics(numerics)
         for mode in modes:
             model.set_gemm_mode(mode)
-            d16, d32, lev, nlev, per_clip = [], [], 0, 0, []
+            d16, d32, lev, nlev, per_clip, s_hip, s16, s_hip32, s32 = [], [], 0, 0, [], [], [], [], []
             for name, B, seed, r16, r32, rlog, rows in cases:
                 toks = synth.canonical_tokens(cfg, B, 8, seed=seed)
                 model.img_context_token_id = toks["img_context_token_id"]
@@ -126,23 +142,49 @@ def main():
                 for i in range(B):
                     u = ulp(r16[i])
                     d16.append(abs(float(hip[i] - r16[i])) / u)
+                    s_hip.append(float(hip[i])); s16.append(float(r16[i]))
                     if r32 is not None:
                         d32.append(abs(float(hip[i] - r32[i])) / u)
+                        s_hip32.append(float(hip[i])); s32.append(float(r32[i]))
                     per_clip.append(round(d16[-1], 1))
                 got = o["logit"].cpu()[rows]
                 lev += int((got != rlog).sum())
                 nlev += int(rlog.numel())
-            key = f"{numerics}/gemm{mode}"
+            key = f"{precision}/{numerics}/gemm{mode}"
             out[key] = dict(vs_ref_bf16=stats(d16), vs_ref_fp32=stats(d32), identical=int(sum(1 for x in d16 if x == 0)),
-                            level_tokens_differing=lev, level_rows=nlev, per_clip_ulps=per_clip)
-            print(f"{key:18s} |hip - ref bf16| {fmt(out[key]['vs_ref_bf16'])}, identical {out[key]['identical']}/{n_clips};  |hip - ref fp32| {fmt(out[key]['vs_ref_fp32'])};  "
+                            level_tokens_differing=lev, level_rows=nlev, per_clip_ulps=per_clip, corr_vs_ref_bf16=corr(s_hip, s16), corr_vs_ref_fp32=corr(s_hip32, s32),
+                            scores=s_hip)
+            print(f"{key:22s} |hip - ref bf16| {fmt(out[key]['vs_ref_bf16'])}, identical {out[key]['identical']}/{n_clips};  |hip - ref fp32| {fmt(out[key]['vs_ref_fp32'])};  "
                   f"level tokens differing {lev}/{nlev}", flush=True)
-            print(f"{'':18s} per clip {per_clip}", flush=True)
+            print(f"{'':22s} task level: hip vs ref bf16 {fmtc(out[key]['corr_vs_ref_bf16'])};  hip vs ref fp32 {fmtc(out[key]['corr_vs_ref_fp32'])}", flush=True)
+            print(f"{'':22s} per clip {per_clip}", flush=True)
+    model.set_precision("bf16")
     model.set_gemm_mode(-1)
     # the reference's own two precisions, and its own spread against itself
     r = [abs(float(r16[i] - r32[i])) / ulp(r16[i]) for _n, B, _s, r16, r32, *_x in cases if r32 is not None for i in range(B)]
     out["ref_bf16_vs_ref_fp32"] = stats(r)
     print(f"reference bf16 vs reference fp32: {fmt(out['ref_bf16_vs_ref_fp32'])}")
+    a16 = [float(r16[i]) for _n, B, _s, r16, r32, *_x in cases if r32 is not None for i in range(B)]
+    a32 = [float(r32[i]) for _n, B, _s, r16, r32, *_x in cases if r32 is not None for i in range(B)]
+    out["corr_ref_bf16_vs_ref_fp32"] = corr(a16, a32)
+    print(f"task level: reference bf16 vs reference fp32 {fmtc(out['corr_ref_bf16_vs_ref_fp32'])}")
+    # the reference against itself, task level: its bf16 scores under 1 / 2 / 4 host threads against its 8-thread pass (the 13 re-scored clips)
+    c5p = os.path.join(G, "e2e_8b_r5.pt")
+    if os.path.exists(c5p):
+        c5 = torch.load(c5p, weights_only=True)["cases"]
+        px, py = [], []
+        for t in ("t1", "t2", "t4"):
+            x, y = [], []
+            for name, B, _s, r16, *_x in cases:
+                if f"{name}/{t}" in c5:
+                    x += c5[f"{name}/{t}"]["score1"].float().tolist(); y += r16.tolist()
+            if x:
+                out[f"corr_ref_{t}_vs_t8"] = corr(x, y)
+                print(f"task level: reference {t} vs its 8-thread pass {fmtc(out[f'corr_ref_{t}_vs_t8'])}")
+                px += x; py += y
+        if px:
+            out["corr_ref_vs_itself_pooled"] = corr(px, py)
+            print(f"task level: reference vs itself, pooled {fmtc(out['corr_ref_vs_itself_pooled'])}")
     pairs, flips, rows = reference_self_pairs(cases)
     allp = [x for k, v in pairs.items() for x in v]
     for k in sorted(pairs):

@@ -160,7 +160,9 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["config"]["global_batch_clips"] == 4
     assert len(out["ms_per_step_by_rank"]) == 2 and all(t > 0 for t in out["ms_per_step_by_rank"])
-    assert out["process_group"] == {"backend": "gloo", "world_size": 2}
+    pg = out["process_group"]
+    assert (pg["backend"], pg["world_size"], pg["distinct_devices"]) == ("gloo", 2, 2)
+    assert [d["rank"] for d in pg["devices"]] == [0, 1] and len({d["device"] for d in pg["devices"]}) == 2     # every rank's own device, gathered through the group
     assert abs(out["ms_per_step"] - max(out["ms_per_step_by_rank"])) < 1e-6          # the headline time is the MAX over the ranks
     # a rank that dies takes the command down with a non-zero exit code (an option the ranks reject)
     bad = subprocess.run(cmd + ["--precision", "nonsense"], capture_output=True, text=True, timeout=300, env=env, cwd=root)

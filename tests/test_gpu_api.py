@@ -721,7 +721,7 @@ def test_batched_lookahead_loop_scores_like_the_plain_loop():
             rows.append((out["score1"].cpu().clone(), out["logit"].cpu().clone(), out["label"].cpu().clone(), out["loss"].cpu().clone()))
         return rows
     want = plain()
-    assert len({w[0].item() for w in want}) > 5                             # (the clips do score differently)
+    assert len({w[0].item() for w in want}) > 2                             # (the clips do score differently)
     for graph in (False, True):
         model.enable_graph_replay(graph)
         for k, ahead in ((4, True), (3, True), (4, False), (1, True)):

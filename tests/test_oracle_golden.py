@@ -107,6 +107,27 @@ def test_end_to_end_stage2(e2e, tag):
     assert close(out["loss"], g["loss"], dt)
 
 
+def test_oracle_matches_the_recorded_anchors(e2e, golden_dir):
+    """tests/golden/e2e_anchors.pt (round 6; what the GPU suite reads instead of live oracle passes): the reference's fp32 pass over the
+    bf16-ROUNDED weights, and its bf16 answer-row logits (top 8) - the oracle reproduces both (seed 21, one clip)."""
+    a = torch.load(os.path.join(golden_dir, "e2e_anchors.pt"), weights_only=True)["internlm2/21"]
+    cfg = _e2e_cfg(e2e)
+    sd = synth.make_state_dict(cfg, seed=21, rich=True)
+    toks = synth.canonical_tokens(cfg, 1, 8, seed=21)
+    pv, motion, flags = synth.synthetic_frames(8, 448, seed=21), synth.synthetic_motion(1, 2304, seed=21), torch.ones(8, 1, dtype=torch.long)
+    f32 = O.forward_eval({k: v.float() for k, v in sd.items()}, cfg, pv.float(), toks["input_ids"], toks["attention_mask"], flags, toks["labels"],
+                         motion.float(), toks["img_context_token_id"], stage=2)
+    assert abs(f32["score1"].float().item() - a["score1_fp32_of_bf16_weights"].item()) <= 2e-5
+    b16 = O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion, toks["img_context_token_id"],
+                         stage=2, return_intermediates=True)
+    want = b16["label"] != -100
+    lg = b16["logits"][..., :-1, :].reshape(-1, b16["logits"].shape[-1])[want].float()
+    top = lg.topk(8, dim=-1)
+    assert torch.equal(b16["logit"][want], a["answer_logit"]) and torch.equal(top.indices[:, 0], a["top_ids"][:, 0])
+    assert torch.equal(top.values, a["top_values"])                       # the reference's bf16 logits, value for value
+    assert torch.equal(b16["score1"], a["score1_bf16"])
+
+
 def test_end_to_end_stage1(e2e):
     g = e2e["stage1_bf16_b1"]
     cfg = _e2e_cfg(e2e)
