@@ -30,7 +30,9 @@ def main():
     model = InternVLChatModel(cfg)
     model.load_state_dict(sd)
     model.eval().cuda()
-    for B, T in ((3, 2), (1, 4), (4, 2)):               # ragged clip / frame splits; one clip over all ranks (latency mode); even split
+    # ragged clip / frame splits; one clip over all ranks (latency mode); even split; one 8-frame clip (3 + 3 + 2 frames on three ranks: the
+    # ragged latency split of SURVEY 8e)
+    for B, T in ((3, 2), (1, 4), (4, 2), (1, 8)):
         toks = synth.canonical_tokens(cfg, B, T, seed=73 + B)
         model.img_context_token_id = toks["img_context_token_id"]
         pv = synth.synthetic_frames(B * T, 224, seed=73 + B).to(dev)
@@ -46,10 +48,11 @@ def main():
         # the same passes with HIP-graph replay (front half and projector + LLM half as captured graphs around the all-gather): ranks with
         # and without clips, ragged frame shards - every call still the one-process forward, bit for bit
         model.enable_graph_replay(True)
-        for i in range(4):
-            dp = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion, prefer_gathered=False)
-            torch.cuda.synchronize()
-            assert torch.equal(dp["score1"], plain["score1"]) and torch.equal(dp["logit"], plain["logit"]), (rank, B, T, "graph", i)
+        for prefer in (False, True):                    # (prefer_gathered: the projector + LLM graph is fed from the all-gathered buffer on every rank)
+            for i in range(4):
+                dp = dist_utils.score_clips_dp(model, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion, prefer_gathered=prefer)
+                torch.cuda.synchronize()
+                assert torch.equal(dp["score1"], plain["score1"]) and torch.equal(dp["logit"], plain["logit"]), (rank, B, T, "graph", prefer, i)
         model.enable_graph_replay(False)
     dist.barrier()
     dist.destroy_process_group()

@@ -78,7 +78,8 @@ def _worker(rank, world, port, q, use_branch=False, n_clips=3, n_frames=2, prefe
 # frames: every rank's clips lie inside its own frame shard, so the LLM pass overlaps the token all-gather), a clip count the
 # ranks do not divide (5 clips, 10 frames -> 3+3+2+2 frames, 2+1+1+1 clips), and fewer clips than ranks (2 clips on 4 ranks)
 @pytest.mark.parametrize("world,use_branch,n_clips,n_frames", [(2, False, 3, 2), (2, True, 3, 2), (2, True, 1, 2), (2, False, 4, 2),
-                                                                (4, True, 8, 16), (4, False, 5, 2), (4, True, 2, 4), (2, False, -4, 2)])
+                                                                (4, True, 8, 16), (4, False, 5, 2), (4, True, 2, 4), (2, False, -4, 2),
+                                                                (3, True, 1, 8), (3, False, -1, 8)])     # one 8-frame clip over three ranks: 3 + 3 + 2 frames
 def test_frame_dp_equals_single_process(world, use_branch, n_clips, n_frames):
     """use_branch: motion_feature=None - every rank runs the model's own motion branch on the frames of ITS clips (the native SlowFast
     branch in the product; a frame-dependent stand-in here)."""

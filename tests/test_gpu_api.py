@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import aigv_assessor_amd as pkg
-from aigv_assessor_amd import synth
+from aigv_assessor_amd import native, synth
 from aigv_assessor_amd.conversation import get_conv_template
 from oracle import oracle as O
 
@@ -675,6 +675,37 @@ def test_lookahead_loop_scores_like_the_plain_loop():
     assert all(torch.equal(a["score1"], b["score1"]) and torch.equal(a["logit"], b["logit"]) for a, b in zip(got, want))
 
 
+def test_lookahead_with_split_k_tails_in_the_vit_frames():
+    """prefetch() runs aigv_vit_forward on its own stream beside the InternLM2 pass of the same context.  At 336 px a
+    frame has 577 rows - two body tiles and a 65-row tail that InternViT's K = 1024 linears run as split-K slices through fp32 scratch.
+    That scratch is the InternViT half's own since round 6 (include/aigv_amd.h, "Streams"): the look-ahead loop's scores equal the plain
+    loop's, bit for bit, also when the two streams really overlap (six clips, InternViT-300M widths, repeated)."""
+    from aigv_assessor_amd import eval_utils
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    cfg = pkg.tiny(vit_hidden=1024, vit_heads=16, vit_layers=2, vit_inter=4096, llm_layers=2, image_size=336)
+    model = InternVLChatModel(cfg)
+    model.load_state_dict(synth.make_state_dict(cfg, seed=95, rich=True))
+    model.eval().cuda()
+    T = 4
+    toks = synth.canonical_tokens(cfg, 1, T, seed=95)
+    model.img_context_token_id = toks["img_context_token_id"]
+    flags = torch.ones(T, 1, dtype=torch.long)
+    clips = [synth.synthetic_frames(T, 336, seed=400 + i).cuda() for i in range(6)]
+    motions = [synth.synthetic_motion(1, cfg.motion_dim, seed=400 + i).cuda() for i in range(6)]
+
+    def fwd(pv, i):
+        o = model(mos=None, pixel_values=pv, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"], image_flags=flags, labels=toks["labels"],
+                  motion_feature=motions[i])
+        return o["score1"].clone(), o["logit"].clone()
+    plain = [fwd(c, i) for i, c in enumerate(clips)]
+    torch.cuda.synchronize()
+    for _rep in range(3):
+        got = [fwd(ahead, i) for i, (c, ahead) in enumerate(eval_utils.lookahead(clips, model, frames=lambda c: c))]
+        torch.cuda.synchronize()
+        for (s, l), (es, el) in zip(got, plain):
+            assert torch.equal(s, es) and torch.equal(l, el)
+
+
 def _ragged_items(cfg, n_items, T, seed, frame_hw=(300, 400)):
     """Dataloader-shaped items (stage2_eval.py:908-911: batch_size = 1) with ragged prompts: item i carries i % 3 more question tokens."""
     g = torch.Generator().manual_seed(seed)
@@ -773,6 +804,23 @@ def test_graph_replay_survives_passes_of_other_shapes_in_between():
     for j, ((s, l), (es, el)) in enumerate(zip(got, eager)):
         assert torch.equal(s, es) and torch.equal(l, el), (j, seq[j])
     model.enable_graph_replay(False)
+
+
+def test_a_fresh_context_reports_the_documented_attention_numerics(rig):
+    """aigv_get_attention_numerics: a fresh context is in the mode the header documents as the default (tests/test_host.py holds the docs
+    against aigv_get_attention_numerics(NULL)); the setter is what the getter reads back."""
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    _model, cfg, sd, _tok = rig
+    lib = native.load()
+    m = InternVLChatModel(cfg)
+    m.load_state_dict(sd)
+    m.eval().cuda()
+    _lib, ctx = m._native()
+    assert lib.aigv_get_attention_numerics(ctx) == lib.aigv_get_attention_numerics(None) == 0
+    m.set_attention_numerics("reference")
+    assert lib.aigv_get_attention_numerics(ctx) == 1
+    m.set_attention_numerics("fp32")
+    assert lib.aigv_get_attention_numerics(ctx) == 0
 
 
 def test_experiment_knobs_live_in_the_context(rig):

@@ -1124,8 +1124,8 @@ def test_full_size_8b_fp8_mode_keeps_the_planted_margin_levels(full_8b, golden_d
     """BASELINE config 5's arithmetic (set_precision('fp8'): e4m3 InternLM2 linears, per-row / per-channel scales) at FULL DEPTH against the
     bf16 REFERENCE, on the thing the mode is for - quality levels: with the planted-margin lm-head rows (winners by
     0.79-1.85 sigma in the reference's own pass) a usable fp8 mode picks the reference's token on EVERY answer row.  The score
-    is a regression on a 4096-wide hidden state and drifts with 32 layers of e4m3 rounding: printed against the reference's bf16 value, with
-    a loose recorded bar (the mode is opt-in and never the headline; DESIGN.md 'fp8 mode')."""
+    is a regression on a 4096-wide hidden state and drifts with 32 layers of e4m3 rounding: measured at TASK level (SRCC / PLCC over the 37
+    pinned clips, second half of this test) and found not usable - the mode is opt-in, experimental and never the headline."""
     model, cfg, g = full_8b
     key = [k for k in g["cases"] if k.startswith("planted/")][0]
     rec = g["cases"][key]
@@ -1152,7 +1152,26 @@ def test_full_size_8b_fp8_mode_keeps_the_planted_margin_levels(full_8b, golden_d
         flips = (got != rec["logit"]).nonzero().flatten().tolist()
         print("fp8 mode: flipped rows", flips, "their margins (sigma)", [round(float(rec["margin_sigma"][i]), 2) for i in flips])
         assert len(flips) <= 1 and all(float(rec["margin_sigma"][i]) < 0.85 for i in flips), flips
-        assert abs(hip - ref) <= 0.35, (hip, ref)          # the builder's study (profiles/r1_fp8_accuracy_study.txt): 0.10 mean / 0.28 max drift
+        # (no bar on this one score: until round 5 a `<= 0.35` on a [0, 1] score stood here, which said nothing.  What the mode does to SCORES is
+        # measured at task level below - and it is not usable.)
+        # TASK LEVEL (round 6): SRCC / PLCC of the fp8-mode scores against the reference's bf16 scores over the 37 pinned clips -
+        # with the plain (un-planted) lm-head the scores do not depend on it.  MEASURED: SRCC 0.71-0.73, PLCC 0.75-0.78, mean |d| 17 bf16 ulps
+        # (profiles/r6_parity_stats.txt), against 0.985 / 0.995 / 2.8 for the bf16 path and 0.984 / 0.9975 / 2.56 for the reference against itself:
+        # on this evidence (iid random weights, 32 layers of e4m3 rounding) the mode's scores are NOT usable, and README / DESIGN.md say so.  The
+        # assert below is a regression guard on the measured level, not a usability claim.
+        s_hip, s_ref = [], []
+        for B, seed, r16 in _pinned_cases(g, golden_dir):
+            toks = synth.canonical_tokens(cfg, B, 8, seed=seed)
+            model.img_context_token_id = toks["img_context_token_id"]
+            o = model(mos=None, pixel_values=synth.synthetic_frames(B * 8, 448, seed=seed).to(model.device), input_ids=toks["input_ids"],
+                      attention_mask=toks["attention_mask"], image_flags=torch.ones(B * 8, 1, dtype=torch.long), labels=toks["labels"],
+                      motion_feature=synth.synthetic_motion(B, cfg.motion_dim, seed=seed).to(model.device))
+            s_hip += o["score1"].float().cpu().tolist(); s_ref += r16["score1"].float().tolist()
+        c8 = _corr(s_hip, s_ref)
+        d8 = sum(_ulps(a - b, b) for a, b in zip(s_hip, s_ref)) / len(s_ref)
+        print(f"fp8 mode, task level over {len(s_ref)} clips vs the reference's bf16 scores: SRCC {c8[0]:.4f} PLCC {c8[1]:.4f} KRCC {c8[2]:.4f}, mean |d| {d8:.1f} bf16 ulps "
+              f"- NOT usable as scores (the bf16 path: 0.985 / 0.995; the reference against itself: 0.984 / 0.9975)")
+        assert len(s_ref) == 37 and c8[0] >= 0.55 and c8[1] >= 0.6, c8
     finally:
         model.set_precision("bf16")
         w.data[rec["level_ids"]] = keep
@@ -1373,6 +1392,16 @@ def test_full_size_8b_pooled_score_distance_is_the_references_own_spread(full_8b
           f"SRCC {self32[0]:.4f} PLCC {self32[1]:.4f}")
     assert hip16[0] >= self16[0] - 0.01 and hip16[1] >= self16[1] - 0.01, (hip16, self16)
     assert hip32[0] >= self32[0] - 0.01 and hip32[1] >= self32[1] - 0.01, (hip32, self32)
+
+
+def _pinned_cases(g, golden_dir):
+    """(B, input seed, the reference's bf16 record) of the 13 recorded passes = 37 clips (e2e_8b_full.pt, e2e_8b_r3.pt / _r3b.pt, e2e_8b_r5.pt)."""
+    cases = [(1, s, g["cases"][f"bf16/{s}"]) for s in sorted({int(k.split("/")[1]) for k in g["cases"] if k.startswith("bf16/")})]
+    for f in ("e2e_8b_r3.pt", "e2e_8b_r3b.pt"):
+        r = torch.load(os.path.join(golden_dir, f), weights_only=True)["cases"]["batch4/bf16"]
+        cases.append((r["B"], r["seed"], r))
+    c5 = torch.load(os.path.join(golden_dir, "e2e_8b_r5.pt"), weights_only=True)["cases"]
+    return cases + [(4, seed, c5[f"batch4/seed{seed}/bf16"]) for seed in range(2, 8)]
 
 
 def _corr(a, b):

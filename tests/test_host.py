@@ -48,6 +48,27 @@ def test_no_cpu_fallback_and_loud_errors(built):
             model.extract_feature(torch.zeros(1, 3, 224, 224))
 
 
+def test_documented_default_of_attention_numerics_is_the_librarys(built):
+    """A boundary doc that contradicts the header is a boundary bug (INTEGRATION.md once said "1 (default)" while code and
+    header had moved to 0).  aigv_get_attention_numerics(NULL) = the mode a fresh context starts in, read without a GPU; header, INTEGRATION.md
+    and the Python mirror must all name that value as the default."""
+    import inspect
+    lib = native.load()
+    d = lib.aigv_get_attention_numerics(None)
+    assert d in (0, 1)
+    header = open(os.path.join(ROOT, "include", "aigv_amd.h")).read()
+    assert f"#define AIGV_ATTENTION_NUMERICS_DEFAULT {d}\n" in header
+    words = {0: "the score matrix stays fp32", 1: "it carries"}
+    assert re.search(rf"{d} \(default\) = {words[d]}", header), "the header's description of aigv_set_attention_numerics names another default"
+    assert not re.search(rf"{1 - d} \(default", header[header.index("Numerics of the prefill attention"):header.index("int aigv_get_attention_numerics")])
+    row = next(ln for ln in open(os.path.join(ROOT, "INTEGRATION.md")) if ln.startswith("| `aigv_set_attention_numerics`"))
+    assert re.search(rf"\(new\) {d} \(default", row) and not re.search(rf"\b{1 - d} \(default", row), row
+    py_default = inspect.signature(InternVLChatModel.set_attention_numerics).parameters["mode"].default
+    assert {"fp32": 0, "reference": 1}[py_default] == d
+    src = inspect.getsource(InternVLChatModel._upload)
+    assert f'getattr(self, "_attn_numerics", {d})' in src       # what a freshly uploaded context is set to
+
+
 def test_gemm_row_band_planner(built):
     """Host logic of the GEMM dispatch (no GPU): the bands cover every row exactly once, split factors divide the K-tile
     count, forced modes are honoured, and the headline LLM shapes get whole rounds on the 256 kernel."""
