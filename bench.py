@@ -826,7 +826,7 @@ def main():
                 ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
                 traffic, tnote = None, None
                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (scripts/pmc_summary.py); newest round's file first
-                tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(f)), None)
+                tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(f)), None)
                 if tf:
                     tj = json.load(open(tf))
                     traffic = tj["all_gemm"]["traffic_bytes_per_launch"]

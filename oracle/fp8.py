@@ -33,11 +33,30 @@ def quant_rows(x: Tensor):
     return (x * inv).to(torch.float8_e4m3fn), scale.reshape(-1)
 
 
+_WEIGHT_CACHE = None          # inside fp8_llm(): {id of the weight's storage: (dequantised e4m3 weight as fp32, channel scales)}
+_WEIGHT_CACHE_CAP = 6 << 30   # bytes of cached fp32 copies (a 3-layer 8B-width test: 2.6 GB; a full-depth run exceeds it and recomputes)
+
+
+def _quant_weight(w: Tensor):
+    """The weight side of fp8_linear.  The quantised copy of a weight is a function of the weight alone, so inside one fp8_llm() context it
+    is computed once per tensor (a KV-cache decode loop calls every linear once per token: re-quantising 218 M parameters per layer and
+    token was most of tests/test_gpu_e2e.py::test_decode_at_8b_widths's wall time)."""
+    global _WEIGHT_CACHE
+    key = (w.data_ptr(), tuple(w.shape))
+    if _WEIGHT_CACHE is not None and key in _WEIGHT_CACHE:
+        return _WEIGHT_CACHE[key][:2]
+    qw, sw = quant_rows(w)
+    qf = qw.float()
+    if _WEIGHT_CACHE is not None and sum(v[2] for v in _WEIGHT_CACHE.values()) + qf.numel() * 4 <= _WEIGHT_CACHE_CAP:
+        _WEIGHT_CACHE[key] = (qf, sw, qf.numel() * 4, w)       # (holds `w` so that the address cannot be recycled while cached)
+    return qf, sw
+
+
 def fp8_linear(x: Tensor, w: Tensor) -> Tensor:
     shp = x.shape
     qa, sa = quant_rows(x.reshape(-1, shp[-1]))
-    qw, sw = quant_rows(w)
-    acc = qa.float() @ qw.float().t()
+    qf, sw = _quant_weight(w)
+    acc = qa.float() @ qf.t()
     return ((acc * sa[:, None]) * sw[None, :]).to(x.dtype).reshape(*shp[:-1], w.shape[0])
 
 
@@ -49,9 +68,12 @@ def fp8_llm(n_layers: int):
             return F.linear(x, w)
         return fp8_linear(x, w)
 
-    prev = O.LLM_LINEAR_HOOK
+    global _WEIGHT_CACHE
+    prev, prev_cache = O.LLM_LINEAR_HOOK, _WEIGHT_CACHE
     O.LLM_LINEAR_HOOK = hook
+    _WEIGHT_CACHE = {}
     try:
         yield
     finally:
         O.LLM_LINEAR_HOOK = prev
+        _WEIGHT_CACHE = prev_cache
