@@ -770,6 +770,16 @@ def test_batched_lookahead_loop_scores_like_the_plain_loop():
     got = list(eval_utils.batched(items, model, k=4))
     for (_, out), (score, logit, _, _) in zip(got, want):
         assert torch.equal(out["score1"], score) and torch.equal(out["logit"], logit)
+    # the stage-1 driver's loop is the same loop (stage1_eval.py:905-929) around the model without a score head: {'label', 'logit'} per item
+    m1 = InternVLChatModel(cfg, stage=1, max_clips=4)
+    m1.load_state_dict(synth.make_state_dict(cfg, seed=91, rich=True))
+    m1.eval().cuda()
+    m1.img_context_token_id = ctx_id
+    m1.slowfast_model = model.slowfast_model
+    plain1 = [m1(mos=None, pixel_values=m1.ingest_frames(it["frames"].cuda()), input_ids=it["input_ids"], attention_mask=it["attention_mask"],
+                 image_flags=it["image_flags"][0], labels=it["labels"])["logit"].cpu() for it in items[:6]]
+    got1 = list(eval_utils.batched(items[:6], m1, k=4, frames=fr))
+    assert all("score1" not in o and torch.equal(o["logit"], w) for (_, o), w in zip(got1, plain1)) and len(got1) == 6
 
 
 def test_graph_replay_survives_passes_of_other_shapes_in_between():

@@ -1226,6 +1226,73 @@ def test_full_size_8b_properties(full_8b):
     assert torch.equal(dp["score1"], both["score1"]) and torch.equal(dp["logit"], both["logit"])
 
 
+def test_full_size_8b_conditioned_weights_against_the_reference(full_8b, golden_dir):
+    """the same seeded weights made to look like a trained checkpoint (synth.condition_state_dict: InternViT layer scales
+    x 0.1, InternLM2 wo / w2 x 1 / sqrt(2 L)), eight clips recorded from the imported reference in bf16 under 8 / 4 (/ 1) host threads and in
+    fp32 (tests/golden/make_golden_8b_conditioned.py).  The question was whether the reference is then stable against itself to <= 1 bf16 ulp,
+    so that HIP could be held to a hard per-clip bar.  MEASURED: it is not - its 4-thread pass sits 3.8 bf16 ulps (mean; max 10) from its
+    8-thread pass on these weights, no better than on the iid weights (2.56 / 8.0) - so the bar here is the statistical one, read from the
+    fixture: |hip - ref| mean and max <= 1.3 x the reference's own against itself, and as close to its fp32 scores as its bf16 pass is."""
+    path = os.path.join(golden_dir, "e2e_8b_conditioned.pt")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/e2e_8b_conditioned.pt not generated")
+    model, cfg, g = full_8b
+    c = torch.load(path, weights_only=True)
+    assert c["w_seed"] == g["w_seed"] and c["overrides"] == g["overrides"] and c["conditioned"] is True
+    cases = c["cases"]
+    dev = model.device
+    L = cfg.llm_config.num_hidden_layers
+    down = 1.0 / (2.0 * L) ** 0.5
+    keep = {}
+    try:
+        with torch.no_grad():     # synth.condition_state_dict's arithmetic on the device copies (fp32 multiply, one rounding back): the same bits
+            for k, p_ in model.named_parameters():
+                f = 0.1 if (k.startswith("vision_model.encoder.layers.") and (k.endswith(".ls1") or k.endswith(".ls2"))) else \
+                    down if (k.startswith("language_model.model.layers.") and (k.endswith("attention.wo.weight") or k.endswith("feed_forward.w2.weight"))) else None
+                if f is not None:
+                    keep[k] = p_.data.clone()
+                    p_.data.copy_((p_.data.float() * f).to(p_.dtype))
+        probe = synth.condition_state_dict({"vision_model.encoder.layers.0.ls1": keep["vision_model.encoder.layers.0.ls1"].cpu().clone()}, cfg)
+        assert torch.equal(probe["vision_model.encoder.layers.0.ls1"], dict(model.named_parameters())["vision_model.encoder.layers.0.ls1"].data.cpu())
+        model._invalidate()
+        d_hip, d_self, d32_hip, d32_ref, lev_bad, lev_rows = [], [], [], [], 0, 0
+        for seed in (0, 1):
+            r8 = cases[f"batch4/seed{seed}/bf16/t8"]
+            toks = synth.canonical_tokens(cfg, 4, 8, seed=seed)
+            model.img_context_token_id = toks["img_context_token_id"]
+            out = model(mos=None, pixel_values=synth.synthetic_frames(32, 448, seed=seed).to(dev), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+                        image_flags=torch.ones(32, 1, dtype=torch.long), labels=toks["labels"], motion_feature=synth.synthetic_motion(4, cfg.motion_dim, seed=seed).to(dev))
+            torch.cuda.synchronize()
+            hip, want = out["score1"].float().cpu(), r8["score1"].float()
+            d_hip += [_ulps(hip[i] - want[i], want[i]) for i in range(4)]
+            for t in (1, 2, 4):
+                o = cases.get(f"batch4/seed{seed}/bf16/t{t}")
+                if o is not None:
+                    d_self += [_ulps(o["score1"].float()[i] - want[i], want[i]) for i in range(4)]
+            r32 = cases.get(f"batch4/seed{seed}/fp32/t8")
+            if r32 is not None:
+                w32 = r32["score1"].float()
+                d32_hip += [_ulps(hip[i] - w32[i], want[i]) for i in range(4)]
+                d32_ref += [_ulps(want[i] - w32[i], want[i]) for i in range(4)]
+            lev_bad += _level_rows_ok(out["logit"].cpu()[r8["answer_rows"]], r8, f"conditioned weights, input seed {seed}", _level_tie_bar(golden_dir))
+            lev_rows += int(r8["answer_rows"].numel())
+        m_hip, m_self = sum(d_hip) / len(d_hip), sum(d_self) / len(d_self)
+        print(f"conditioned weights, {len(d_hip)} clips: |hip - ref bf16| mean {m_hip:.2f} max {max(d_hip):.1f} bf16 ulps {[round(x, 1) for x in d_hip]}; the reference against itself "
+              f"({len(d_self)} pairs: 4 / 1 host threads vs 8) mean {m_self:.2f} max {max(d_self):.1f}; level tokens {lev_rows - lev_bad}/{lev_rows} identical")
+        assert len(d_self) >= 8
+        assert m_hip <= REF_SELF_FACTOR * m_self and max(d_hip) <= REF_SELF_FACTOR * max(d_self), (d_hip, d_self)
+        if d32_hip:
+            a, b = sum(d32_hip) / len(d32_hip), sum(d32_ref) / len(d32_ref)
+            print(f"conditioned weights, against the reference's fp32 scores ({len(d32_hip)} clips): hip mean {a:.2f} bf16 ulps, the reference's own bf16 pass {b:.2f}")
+            assert a <= REF_SELF_FACTOR * b, (a, b)
+    finally:
+        with torch.no_grad():
+            for k, p_ in model.named_parameters():
+                if k in keep:
+                    p_.data.copy_(keep[k])
+        model._invalidate()
+
+
 def test_full_size_8b_eight_clips_per_gpu_share_of_configs_3_and_5(full_8b):
     """The per-GPU share of BASELINE config 5 (64 clips x 8 frames on 8 GPUs = 8 clips per GPU; config 3's share, 4 clips, is the headline
     itself) at full depth on the one card: 8 clips x 8 frames x 448 px = 17408 token rows in one pass.  Size-independent
