@@ -13,7 +13,7 @@ The canonical token layout is SURVEY.md §8d / Appendix A:  N = 73 + (7 + tokens
 """
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from typing import Optional, Dict, List, Tuple
 
 import torch
 
@@ -86,9 +86,58 @@ def weight_shapes(cfg: InternVLChatConfig) -> List[Tuple[str, Tuple[int, ...], s
     return out
 
 
-def make_state_dict_iter(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16, device="cpu", rich: bool = False):
+_M32 = 0xFFFFFFFF
+
+
+def hashed_uniform(shape, key: int, std: float, dtype=torch.bfloat16, device="cpu", chunk: Optional[int] = None) -> torch.Tensor:
+    """A seeded weight tensor that is the SAME BITS on every device: element e = ((h(e ^ key) >> 8) * 2^-24 - 0.5) * std * sqrt(12) with a
+    32-bit integer hash h (two xorshift-multiply rounds with the key folded in before each, every intermediate < 2^63 in int64) - integer arithmetic, one exact int -> fp32
+    conversion, two fp32 operations with exact or correctly rounded results, one rounding to ``dtype``.  Uniform with standard deviation
+    ``std``.  Unlike ``torch.randn`` from a CPU generator (one serial mt19937 stream: ~4 ns per value on one core, 111 s for the 26 G
+    parameters of InternVL2-26B) every element is a function of its own index, so a GPU fills 51 GB in seconds and a CPU can produce any
+    tensor without walking the ones before it."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if n >= 1 << 32:
+        raise ValueError("hashed_uniform: tensors of 2^32 elements or more need a wider index hash")
+    out = torch.empty(n, dtype=dtype, device=device)
+    scale = torch.tensor(std * 12.0 ** 0.5, dtype=torch.float32, device=device)
+    key2 = (int(key) * 2654435761 + 0x7F4A7C15) & _M32
+    key = int(key) & _M32
+    if chunk is None:      # (the values do not depend on it) CPU: cache-sized pieces, in place - 300 M values/s on 8 cores; GPU: few large launches
+        chunk = 1 << 20 if torch.device(device).type == "cpu" else 1 << 26
+    for e0 in range(0, n, chunk):
+        x = torch.arange(e0, min(n, e0 + chunk), dtype=torch.int64, device=device)
+        x.bitwise_xor_(key).bitwise_and_(_M32)
+        for r in range(2):
+            y = x >> 16
+            y.bitwise_xor_(x).mul_(0x45D9F3B).bitwise_and_(_M32)
+            if r == 0:
+                y.bitwise_xor_(key2)      # (a key that enters before the first round only would make two tensors index permutations of each other)
+            x = y
+        y = x >> 16
+        y.bitwise_xor_(x).bitwise_right_shift_(8)
+        u = y.to(torch.float32)
+        u.mul_(2.0 ** -24).sub_(0.5).mul_(scale)
+        out[e0:e0 + chunk] = u.to(dtype)
+    return out.view(*shape)
+
+
+def make_state_dict_iter(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16, device="cpu", rich: bool = False, method: str = "randn",
+                         big: bool = True):
     """(name, tensor) in weight_shapes order from ONE seeded generator - make_state_dict's values, one tensor alive at a time (a
-    streaming consumer, tests/golden/make_golden_26b.py, walks 26 G parameters with a few hundred MB)."""
+    streaming consumer, tests/golden/make_golden_26b.py, walks 26 G parameters with a few hundred MB).
+
+    ``method="hash"`` (round 6; the ORACLE-only InternVL2-26B fixture): Linear / Embedding matrices come from ``hashed_uniform`` (device
+    independent bits; std 0.02 like the reference's ``_init_weights``), everything else (norms, biases, layer scales, position tables, score head:
+    a few M values) from a CPU torch generator as before, then moved to ``device``.  ``big=False`` skips the matrices (the fixture generator's
+    first pass wants the small tensors only).  The fixtures recorded from the imported REFERENCE all use ``method="randn"`` on the CPU."""
+    if method == "hash":
+        yield from _hashed_state_dict_iter(cfg, seed, dtype, device, rich, big)
+        return
+    if method != "randn":
+        raise ValueError("method must be 'randn' or 'hash'")
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     n_score = len(cfg.score_dims)
@@ -135,9 +184,40 @@ def make_state_dict_iter(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfl
         yield name, t.to(dtype)
 
 
+def _hashed_state_dict_iter(cfg, seed, dtype, device, rich, big):
+    g = torch.Generator().manual_seed(seed)
+    n_score = len(cfg.score_dims)
+    for i, (name, shape, kind) in enumerate(weight_shapes(cfg)):
+        if kind in ("linear", "embed"):
+            if big:
+                yield name, hashed_uniform(shape, seed * 1000003 + i * 7919 + 12345, 0.02, dtype, device)
+            continue
+        if kind in ("cls", "pos"):
+            t = torch.randn(shape, generator=g) * (0.02 if not rich else 0.1)
+        elif kind == "norm_w":
+            t = torch.ones(shape) if not rich else 1.0 + torch.randn(shape, generator=g) * 0.1
+        elif kind == "bias":
+            t = torch.zeros(shape) if not rich else torch.randn(shape, generator=g) * 0.02
+        elif kind == "ls":
+            t = torch.full(shape, cfg.vision_config.initializer_factor) if not rich else torch.rand(shape, generator=g) + 0.5
+        elif kind == "score_w":
+            t = torch.rand(shape, generator=g) * 0.3 - 0.15
+            if rich and name == f"mlpscore.fc{n_score}.weight":
+                t = t * 0.3
+        elif kind == "score_b":
+            t = torch.zeros(shape)
+            if rich:
+                t = torch.randn(shape, generator=g) * 0.02
+                if name == f"mlpscore.fc{n_score}.bias":
+                    t = torch.full(shape, 0.5)
+        else:
+            raise AssertionError(kind)
+        yield name, t.to(dtype).to(device)
+
+
 def make_state_dict(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfloat16, device="cpu",
-                    rich: bool = False) -> Dict[str, torch.Tensor]:
-    return dict(make_state_dict_iter(cfg, seed=seed, dtype=dtype, device=device, rich=rich))
+                    rich: bool = False, method: str = "randn") -> Dict[str, torch.Tensor]:
+    return dict(make_state_dict_iter(cfg, seed=seed, dtype=dtype, device=device, rich=rich, method=method))
 
 
 def condition_state_dict(sd: Dict[str, torch.Tensor], cfg: InternVLChatConfig) -> Dict[str, torch.Tensor]:

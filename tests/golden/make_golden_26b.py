@@ -5,11 +5,17 @@ run this width and there is no stage-2 score here).  ORACLE-ONLY: the vectors co
 reference at the widths it can run: tests/test_oracle_golden.py), in bf16 AND fp32.
 
 The 26 G parameters (51 GB in bf16) do not fit beside their activations in the 62 GB build container, so the pass STREAMS: the seeded
-generator of synth.make_state_dict is walked twice - once to record its state in front of every block (ViT layer, LLM layer, the small
-tensors), once more block by block while the oracle's layer functions run - and at most one layer's weights are alive at a time.  The bf16
-and the fp32 pass advance together through each layer's weights (the fp32 pass uses the bf16 weights upcast: one model, two precisions).
+weight stream of synth.make_state_dict_iter is walked twice - once for the small tensors (mlp1 / motion_mlp are generated after the LLM
+layers and needed in front of them), once more block by block while the oracle's layer functions run - and at most one layer's weights are
+alive at a time.  The bf16 and the fp32 pass advance together through each layer's weights (the fp32 pass uses the bf16 weights upcast: one
+model, two precisions).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_26b.py        (~40 min on 8 cores, < 12 GB)
+Round 6: the weights are synth's ``method="hash"`` set (Linear / Embedding matrices from a device-independent integer hash, uniform with
+std 0.02; the small tensors from a CPU torch generator).  Until round 5 they came from ONE serial CPU generator, and the GPU test spent
+111 of its 115 s (and of the driver's 900 s for the whole suite) drawing 26 G normal deviates on one host core; the hashed set is the same
+bits on CPU and GPU, so the test fills the model on the device in seconds.  The fixture records ``w_method``.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_26b.py        (~40 min on 8 otherwise idle cores, < 12 GB)
 
 Output: tests/golden/e2e_26b_full.pt (plain tensors: loads with weights_only=True)
 """
@@ -28,6 +34,15 @@ from aigv_assessor_amd import synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 W_SEED, IN_SEED, T = 2601, 26, 16
+W_METHOD = "hash"
+
+
+def WEIGHT(cfg, name):
+    """One matrix of the hashed weight set by name (every element is a function of its index: no walk over the tensors before it)."""
+    for i, (n, shape, kind) in enumerate(synth.weight_shapes(cfg)):
+        if n == name:
+            return synth.hashed_uniform(shape, W_SEED * 1000003 + i * 7919 + 12345, 0.02)
+    raise KeyError(name)
 
 
 def block_of(name):
@@ -53,9 +68,11 @@ def main():
     # ---- one walk of the generator, consumed block by block in GENERATION order; the forward needs mlp1 / motion_mlp (generated after the
     # LLM layers) in front of the LLM, so the walk is done twice: walk 1 keeps the small tensors, walk 2 streams the layers
     small = {}
-    for name, t in synth.make_state_dict_iter(cfg, seed=W_SEED, rich=True):
-        if block_of(name).startswith("misc:") and name not in ("language_model.model.tok_embeddings.weight", "language_model.output.weight"):
-            small[name] = t
+    for name, t in synth.make_state_dict_iter(cfg, seed=W_SEED, rich=True, method=W_METHOD, big=False):      # (norms, biases, layer scales, tables)
+        small[name] = t
+    for name, shape, kind in synth.weight_shapes(cfg):                                                          # ... and the matrices outside the layers
+        if kind in ("linear", "embed") and block_of(name).startswith("misc:") and name not in ("language_model.model.tok_embeddings.weight", "language_model.output.weight"):
+            small[name] = WEIGHT(cfg, name)
     print(f"walk 1 (small tensors) {time.time() - t0:.0f} s", flush=True)
 
     def up(sd):
@@ -84,7 +101,7 @@ def main():
         x16 = O.vit_embeddings(small, cfg, pv)
         x32 = O.vit_embeddings(small32, cfg, pv.float())
     emb_w = None
-    for name, t in synth.make_state_dict_iter(cfg, seed=W_SEED, rich=True):
+    for name, t in synth.make_state_dict_iter(cfg, seed=W_SEED, rich=True, method=W_METHOD):
         b = block_of(name)
         if b != cur_block and cur:
             run_block(cur_block, cur)
@@ -124,7 +141,7 @@ def main():
             tv, ti = lg.topk(4, dim=-1)
             recs[tag] = dict(logit=lg.argmax(-1).clone(), top_values=tv.clone(), top_ids=ti.clone(), hidden_m4=n[:, -4, :].clone(), row_sigma=lg.std(-1).clone())
             print(f"{tag}: answer-row argmax {recs[tag]['logit'].tolist()}", flush=True)
-    out = dict(config="internvl2_26b", vit_layers=v.num_hidden_layers, llm_layers=l.num_hidden_layers, w_seed=W_SEED, in_seed=IN_SEED, T=T, n_tokens=N,
+    out = dict(config="internvl2_26b", vit_layers=v.num_hidden_layers, llm_layers=l.num_hidden_layers, w_seed=W_SEED, w_method=W_METHOD, in_seed=IN_SEED, T=T, n_tokens=N,
                answer_rows=rows.clone(), label=labels[0, 1:][rows].clone(), cases=recs, seconds=time.time() - t0)
     path = os.path.join(HERE, "e2e_26b_full.pt") if not os.environ.get("AIGV_GOLDEN_DRY") else "/tmp/e2e_26b_dry.pt"
     torch.save(out, path)

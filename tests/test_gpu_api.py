@@ -816,6 +816,17 @@ def test_graph_replay_survives_passes_of_other_shapes_in_between():
     model.enable_graph_replay(False)
 
 
+def test_hashed_weight_set_is_the_same_bits_on_the_device():
+    """synth's "hash" weight method (the oracle-only 26B fixture's weights since round 6): produced on the GPU, bit for bit what the CPU - where
+    the oracle recorded the fixture - produces; whole state dicts included."""
+    for shape, key in (((1000, 4099), 5), ((6144, 2048), 987654321), ((17,), 0)):
+        assert torch.equal(synth.hashed_uniform(shape, key, 0.02, device="cuda").cpu(), synth.hashed_uniform(shape, key, 0.02))
+    cfg = pkg.tiny(image_size=224)
+    a = synth.make_state_dict(cfg, seed=9, rich=True, method="hash")
+    b = synth.make_state_dict(cfg, seed=9, rich=True, method="hash", device="cuda")
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k].cpu()) for k in a)
+
+
 def test_a_fresh_context_reports_the_documented_attention_numerics(rig):
     """aigv_get_attention_numerics: a fresh context is in the mode the header documents as the default (tests/test_host.py holds the docs
     against aigv_get_attention_numerics(NULL)); the setter is what the getter reads back."""

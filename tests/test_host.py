@@ -69,6 +69,31 @@ def test_documented_default_of_attention_numerics_is_the_librarys(built):
     assert f'getattr(self, "_attn_numerics", {d})' in src       # what a freshly uploaded context is set to
 
 
+def test_hashed_weight_set_is_pinned_and_chunk_independent():
+    """synth.hashed_uniform / make_state_dict(method="hash") (round 6: the weight set of the oracle-only 26B fixture): the algorithm is pinned by
+    value - a fixture recorded with it must keep meaning the same weights -, does not depend on the chunking, gives every tensor its own values
+    (no tensor is an index permutation of another) and the documented statistics (uniform, std 0.02)."""
+    a = synth.hashed_uniform((8,), 1, 0.02, dtype=torch.float32)
+    want = [-0.019403910264372826, 0.03301652520895004, -0.007542225066572428, -0.0029996458906680346, -0.029941143468022346, 0.02123815193772316,
+            0.017400067299604416, -0.02617489919066429]
+    assert a.tolist() == want
+    b = synth.hashed_uniform((3, 5), 123456789012, 0.02)
+    assert b.float().flatten().tolist()[:5] == [-0.017578125, 0.0194091796875, -0.02685546875, 0.032958984375, 0.0281982421875]
+    big = synth.hashed_uniform((700, 3000), 77, 0.02)
+    assert torch.equal(big, synth.hashed_uniform((700, 3000), 77, 0.02, chunk=4099))
+    assert abs(big.float().std().item() - 0.02) < 2e-4 and abs(big.float().mean().item()) < 1e-4 and big.float().abs().max().item() <= 0.02 * 12 ** 0.5
+    other = synth.hashed_uniform((700, 3000), 77 + 7919, 0.02)
+    assert not torch.equal(big.flatten().sort().values, other.flatten().sort().values)       # not a permutation of one another
+    assert abs(torch.corrcoef(torch.stack([big.float().flatten(), other.float().flatten()]))[0, 1].item()) < 5e-3
+    cfg = pkg.tiny(image_size=224)
+    sd = synth.make_state_dict(cfg, seed=3, rich=True, method="hash")
+    assert list(sd) == [n for n, _s, _k in synth.weight_shapes(cfg)]
+    small_only = dict(synth.make_state_dict_iter(cfg, seed=3, rich=True, method="hash", big=False))
+    assert set(small_only) == {n for n, _s, k in synth.weight_shapes(cfg) if k not in ("linear", "embed")} and all(torch.equal(small_only[k], sd[k]) for k in small_only)
+    with pytest.raises(ValueError):
+        synth.make_state_dict(cfg, method="bogus")
+
+
 def test_gemm_row_band_planner(built):
     """Host logic of the GEMM dispatch (no GPU): the bands cover every row exactly once, split factors divide the K-tile
     count, forced modes are honoured, and the headline LLM shapes get whole rounds on the 256 kernel."""
