@@ -46,19 +46,36 @@ for s in seeds:
         ref32 += [abs(float(a[i] - f["score1"].float()[i])) / ulp(a[i]) for i in range(4)]
 print("reference vs itself (other host thread counts vs 8):", st(self_d))
 print("reference bf16 vs its fp32 pass:                    ", st(ref32))
-for numerics in ("fp32", "reference"):
-    model.set_attention_numerics(numerics)
-    d16, d32, lev, rows = [], [], 0, 0
-    for s in seeds:
-        r8 = cases[f"batch4/seed{s}/bf16/t8"]
-        toks = synth.canonical_tokens(cfg, 4, 8, seed=s)
-        model.img_context_token_id = toks["img_context_token_id"]
-        o = model(mos=None, pixel_values=synth.synthetic_frames(32, 448, seed=s).to(dev), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
-                  image_flags=torch.ones(32, 1, dtype=torch.long), labels=toks["labels"], motion_feature=synth.synthetic_motion(4, cfg.motion_dim, seed=s).to(dev))
-        hip, a = o["score1"].float().cpu(), r8["score1"].float()
-        d16 += [abs(float(hip[i] - a[i])) / ulp(a[i]) for i in range(4)]
-        f = cases.get(f"batch4/seed{s}/fp32/t8")
-        if f is not None:
-            d32 += [abs(float(hip[i] - f["score1"].float()[i])) / ulp(a[i]) for i in range(4)]
-        lev += int((o["logit"].cpu()[r8["answer_rows"]] != r8["logit"]).sum()); rows += int(r8["logit"].numel())
-    print(f"hip, attention numerics {numerics:9s}: vs ref bf16 {st(d16)};  vs ref fp32 {st(d32)};  level tokens differing {lev}/{rows}")
+def corr(a, b):
+    from scipy.stats import pearsonr, spearmanr
+    return f"SRCC {spearmanr(a, b)[0]:.4f} PLCC {pearsonr(a, b)[0]:.4f}"
+
+
+for precision in ("bf16", "fp8"):
+    model.set_precision(precision)
+    for numerics in ("fp32", "reference"):
+        model.set_attention_numerics(numerics)
+        d16, d32, lev, rows, s_hip, s_ref = [], [], 0, 0, [], []
+        for s in seeds:
+            r8 = cases[f"batch4/seed{s}/bf16/t8"]
+            toks = synth.canonical_tokens(cfg, 4, 8, seed=s)
+            model.img_context_token_id = toks["img_context_token_id"]
+            o = model(mos=None, pixel_values=synth.synthetic_frames(32, 448, seed=s).to(dev), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+                      image_flags=torch.ones(32, 1, dtype=torch.long), labels=toks["labels"], motion_feature=synth.synthetic_motion(4, cfg.motion_dim, seed=s).to(dev))
+            hip, a = o["score1"].float().cpu(), r8["score1"].float()
+            s_hip += hip.tolist(); s_ref += a.tolist()
+            d16 += [abs(float(hip[i] - a[i])) / ulp(a[i]) for i in range(4)]
+            f = cases.get(f"batch4/seed{s}/fp32/t8")
+            if f is not None:
+                d32 += [abs(float(hip[i] - f["score1"].float()[i])) / ulp(a[i]) for i in range(4)]
+            lev += int((o["logit"].cpu()[r8["answer_rows"]] != r8["logit"]).sum()); rows += int(r8["logit"].numel())
+        print(f"hip {precision}, attention numerics {numerics:9s}: vs ref bf16 {st(d16)};  vs ref fp32 {st(d32)};  level tokens differing {lev}/{rows};  task level vs ref bf16: {corr(s_hip, s_ref)}")
+# the reference against itself at task level (every recorded thread count against the 8-thread pass, pooled)
+x, y = [], []
+for s in seeds:
+    a = cases[f"batch4/seed{s}/bf16/t8"]["score1"].float().tolist()
+    for t in (1, 2, 4):
+        o = cases.get(f"batch4/seed{s}/bf16/t{t}")
+        if o is not None:
+            x += o["score1"].float().tolist(); y += a
+print(f"reference vs itself, task level ({len(x)} pairs pooled): {corr(x, y)}")

@@ -1233,15 +1233,16 @@ def test_full_size_8b_conditioned_weights_against_the_reference(full_8b, golden_
     """the same seeded weights made to look like a trained checkpoint (synth.condition_state_dict: InternViT layer scales
     x 0.1, InternLM2 wo / w2 x 1 / sqrt(2 L)), 16 clips recorded from the imported reference in bf16 under 8 / 4 (/ 2 / 1) host threads, 8+ of
     them in fp32 (tests/golden/make_golden_8b_conditioned.py).  The question was whether the reference is then stable against itself to <= 1 bf16
-    ulp, so that HIP could be held to a hard per-clip bar.  MEASURED: it is not - its passes under other thread counts sit 2.7
-    bf16 ulps (mean; max 10) from its 8-thread pass, and its bf16 pass 4.6 (max 10.2) from its OWN fp32 pass.  In absolute terms the noise is
+    ulp, so that HIP could be held to a hard per-clip bar.  MEASURED: it is not - its passes under other thread counts sit 3.1
+    bf16 ulps (mean; max 10) from its 8-thread pass, and its bf16 pass 4.7 (max 11.9) from its OWN fp32 pass.  In absolute terms the noise is
     what it is on the iid weights (~0.01); the scores are smaller here (0.2-0.7), so it counts more ulps.  Asserted, all read from the fixture:
       * as close to the reference's fp32 scores as the reference's own bf16 pass is (mean, factor 1.3) - the bar of the iid test;
       * no clip farther from the reference's bf16 score than 1.3 x the largest distance the reference shows against itself (thread counts, fp32);
       * level tokens identical up to the reference's own near-ties.
-    REPORTED, not asserted: the pooled mean |hip - ref bf16| (6.0 ulps) against the thread-count spread (2.7).  Passes of ONE implementation that
+    REPORTED, not asserted: the pooled mean |hip - ref bf16| (6.0 ulps) against the thread-count spread (3.1).  Passes of ONE implementation that
     differ in nothing but GEMM blocking share most of their rounding decisions - that spread is a correlated lower bound; two evaluations that
-    each sit ~5 ulps from the fp32 value (the reference's bf16 pass: 4.6; HIP: 5.6) are expected ~6-7 apart."""
+    each sit ~5 ulps from the fp32 value (the reference's bf16 pass: 4.7; HIP: 5.0) are expected ~6-7 apart.  The hidden-state bars below are the
+    robust form of the same comparison (HIP vs ref bf16 0.0450 against a thread-count spread of 0.0376 and a bf16-vs-fp32 distance of 0.0409)."""
     path = os.path.join(golden_dir, "e2e_8b_conditioned.pt")
     if not os.path.exists(path):
         pytest.skip("tests/golden/e2e_8b_conditioned.pt not generated")

@@ -309,12 +309,16 @@ def test_26b_fixture_structure_and_streamed_weights():
     g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_26b_full.pt"), weights_only=True)
     cfg = pkg.internvl2_26b()
     assert (g["vit_layers"], g["llm_layers"], g["T"], g["n_tokens"]) == (45, 48, 16, synth.canonical_len(cfg, 16)) == (45, 48, 16, 4281)
+    assert g["w_method"] == "hash"        # round 6: the device-independent weight set (synth.hashed_uniform; pinned by value in tests/test_host.py)
     toks = synth.canonical_tokens(cfg, 1, g["T"], seed=g["in_seed"])
     rows = g["answer_rows"]
     assert torch.equal(toks["labels"][0, 1:][rows], g["label"]) and rows.numel() == 10 and int(rows[7]) == g["n_tokens"] - 4
     for tag in ("bf16", "fp32"):
         r = g["cases"][tag]
-        assert r["hidden_m4"].shape == (1, cfg.llm_config.hidden_size) and torch.equal(r["top_ids"][:, 0], r["logit"])
+        assert r["hidden_m4"].shape == (1, cfg.llm_config.hidden_size)
+        for i in range(rows.numel()):        # the recorded argmax is the recorded top value (topk may name another token of an EXACT tie first: argmax takes the lowest id)
+            ids, vals = r["top_ids"][i].tolist(), r["top_values"][i].tolist()
+            assert int(r["logit"][i]) in ids and vals[ids.index(int(r["logit"][i]))] == vals[0]
     h16, h32 = g["cases"]["bf16"]["hidden_m4"].float(), g["cases"]["fp32"]["hidden_m4"].float()
     assert 0.01 < float((h16 - h32).norm() / h32.norm()) < 0.15
     small = pkg.tiny(image_size=224)
