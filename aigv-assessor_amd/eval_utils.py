@@ -124,7 +124,8 @@ def batched(items, model, k: int = 4, frames=None, ahead: bool = True, pad_id: i
     the reference's collator does (internvl/patch/pad_data_collator.py:60-67: pad id, IGNORE_INDEX, mask = ids != pad - here the items'
     own masks are kept), frames and flags concatenated (:93-99), ONE ``forward`` and ONE device-to-host copy of its results per group.
     With ``ahead`` the NEXT group's visual front (H2D copy, resize + normalise, InternViT, SlowFast) runs on its own stream beside this
-    group's InternLM2 pass (``InternVLChatModel.prefetch``).  The loop changes by two lines:
+    group's InternLM2 pass (``InternVLChatModel.prefetch``), and a group's results are fetched only after the next group's pass has been
+    enqueued (the GPU never waits for the host's loop body; results arrive one group late, in order).  The loop changes by two lines:
 
         for item2, output in eval_utils.batched(eval_utils.shard(train_dataloader, rank, world), model, k=4):
             score1 = output['score1'].item()          # `output = model(...)` and the `.to(model.device)` copies above it go away
@@ -160,7 +161,8 @@ def batched(items, model, k: int = 4, frames=None, ahead: bool = True, pad_id: i
     def row(t):
         return t.reshape(-1) if t.dim() <= 1 or t.shape[0] != 1 else t[0].reshape(-1)
 
-    def score(group, front):
+    def enqueue(group, front):
+        """ONE forward for the group: everything is enqueued, nothing is waited for."""
         ids = [row(it["input_ids"]) for it, _ in group]
         labels = [row(it["labels"]) for it, _ in group]
         masks = [row(it["attention_mask"]).bool() if it.get("attention_mask") is not None else torch.ones_like(i, dtype=torch.bool) for (it, _), i in zip(group, ids)]
@@ -176,7 +178,12 @@ def batched(items, model, k: int = 4, frames=None, ahead: bool = True, pad_id: i
         out = model(mos=None, pixel_values=front, input_ids=torch.stack([pad(i, pad_id) for i in ids]),
                     attention_mask=torch.stack([pad(m, False) for m in masks]), image_flags=flags,
                     labels=torch.stack([pad(l, -100) for l in labels]), **({} if motion is None else {"motion_feature": motion}))
-        # ONE host synchronisation per group (the plain loop has one per clip: score1.item(), stage2_eval.py:938)
+        return group, n, nmax, out
+
+    def collect(run):
+        """The group's results to the host - ONE synchronisation per group (the plain loop has one per clip: score1.item(), stage2_eval.py:938) - and
+        out per item."""
+        group, n, nmax, out = run
         logit = out["logit"].view(len(group), nmax - 1).cpu()
         label = out["label"].view(len(group), nmax - 1).cpu()
         score1 = out["score1"].cpu() if "score1" in out else None
@@ -194,8 +201,18 @@ def batched(items, model, k: int = 4, frames=None, ahead: bool = True, pad_id: i
     except StopIteration:
         return
     front = start(cur)
+    # Software pipeline, two deep: group g's forward is ENQUEUED before group g - 1's results are fetched, so the GPU already holds its next pass
+    # while the host copies results back and the caller's loop body (token decoding, CSV rows) runs; the results of a group therefore come
+    # out one group late - every item still comes out, in order.
+    pending = None
     for nxt in it:
         nxt_front = start(nxt) if ahead else None          # enqueued BEFORE this group's InternLM2 pass: the two run side by side
-        yield from score(cur, front)
+        run = enqueue(cur, front)
+        if pending is not None:
+            yield from collect(pending)
+        pending = run
         cur, front = nxt, nxt_front if ahead else start(nxt)
-    yield from score(cur, front)
+    run = enqueue(cur, front)
+    if pending is not None:
+        yield from collect(pending)
+    yield from collect(run)
