@@ -46,6 +46,28 @@ def test_score_clips_dp_multi_rank_on_one_card_over_gloo(world):
         assert f"DP_OK rank={r}/{world}" in out
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_batched_eval_loop_on_one_card_over_gloo(world):
+    """The reference's eval loop on N ranks as INTEGRATION.md shows it (eval_utils.shard + batched + gather_rows) with the REAL model: `world` rank
+    processes on the one MI355X, each scoring its own share in groups of three; every rank ends with the rows of the whole set in the set's order,
+    equal to the plain one-clip-per-call loop (tests/gloo_eval_loop_child.py)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gloo_eval_loop_child.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      env=env, cwd=ROOT))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        print(out[-300:], err[-1500:])
+        assert p.returncode == 0, f"rank {r}: {err[-3000:]}"
+        assert f"LOOP_OK rank={r}/{world}" in out
+
+
 def test_bench_two_ranks_on_one_card_rehearsal():
     """`python bench.py --gpus 2` as a plain command with the REAL model path (tiny dims) and the per-launch roofline pass ON, both ranks
     on the one MI355X over gloo (AIGV_BENCH_SHARE_DEVICE: RCCL refuses duplicate devices): the N > 1 control flow of the bench on hardware -
