@@ -211,6 +211,12 @@ def parity_vs_reference(model, cfg, dev):
         torch.cuda.synchronize()
         hip = out["score1"].float().cpu()
         b16, f32 = r16["score1"].float(), r32["score1"].float()
+        # the 4096-wide hidden state the score head reads (hidden[:, -4]): relative L2 distance - a vector norm, far less noisy than the scalar score
+        hid = None
+        if "hidden_m4" in r16 and "hidden_m4" in r32:
+            rel = lambda a, b: float(((a.float() - b.float()).norm(dim=-1) / b.float().norm(dim=-1)).mean())
+            h = model.last_hidden_rows(B).cpu()
+            hid = {"hip_vs_ref_bf16": rel(h, r16["hidden_m4"]), "hip_vs_ref_fp32": rel(h, r32["hidden_m4"]), "ref_bf16_vs_ref_fp32": rel(r16["hidden_m4"], r32["hidden_m4"])}
         got = out["logit"].cpu()[r16["answer_rows"]]
         diff = (got != r16["logit"]).nonzero().flatten().tolist()
         outside = 0
@@ -222,7 +228,8 @@ def parity_vs_reference(model, cfg, dev):
         return {"seed": seed, "score_delta_vs_ref": float((hip - b16).abs().max()), "score_delta_vs_ref_mean": float((hip - b16).abs().mean()),
                 "score_delta_vs_ref_fp32_mean": float((hip - f32).abs().mean()), "ref_bf16_vs_ref_fp32_mean": float((b16 - f32).abs().mean()),
                 "level_mismatches": len(diff), "level_mismatches_outside_near_ties": outside, "level_rows": int(got.numel()),
-                "level_agreement_with_ref_fp32": {"hip": int((got == r32["logit"]).sum()), "ref_bf16": int((r16["logit"] == r32["logit"]).sum())}}
+                "level_agreement_with_ref_fp32": {"hip": int((got == r32["logit"]).sum()), "ref_bf16": int((r16["logit"] == r32["logit"]).sum())},
+                "hidden_state_rel_l2": hid}
     first = one(g)
     res = dict(first)
     res.pop("seed")
@@ -251,6 +258,8 @@ def parity_vs_reference(model, cfg, dev):
             res.setdefault("reference_vs_itself", {})
             res["reference_vs_itself"]["benched_shape_threads_1_2_4_vs_8_ulps"] = {"n": len(d), "mean": sum(d) / len(d), "max": max(d)}
             res["reference_vs_itself"]["all_37_clip_sample"] = "profiles/r5_parity_stats.txt: reference against itself 2.56 mean / 8.0 max bf16 ulps over 44 pairs; this path 2.80 mean / 9.0 max over 37 clips"
+    res["hidden_state_note"] = ("hidden_state_rel_l2: mean relative L2 distance of hidden[:, -4] (the score head's 4096-wide input) per clip; the reference against ITSELF under other "
+                                "host thread counts: 0.0356 (24 clips), this path 0.0390 vs its bf16 pass / 0.0331 vs its fp32 pass over 32 clips (profiles/r6_hidden_distance.txt)")
     res["parity_note"] = ("one pass per recorded batch (4 clips x 8 frames; seed-0 inputs = the benched batch, seed-1 = a second batch of the shape; motion_feature "
                           "input) with the golden's seeded weights against the imported reference's recorded bf16 / fp32 outputs (tests/golden/e2e_8b_r3.pt, "
                           f"e2e_8b_r3b.pt); score1 is a bf16 number (ulp 0.0039 in [0.5, 1)), the reference's own bf16 pass sits {first['ref_bf16_vs_ref_fp32_mean']:.4f} "
