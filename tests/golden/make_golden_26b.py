@@ -15,7 +15,7 @@ std 0.02; the small tensors from a CPU torch generator).  Until round 5 they cam
 111 of its 115 s (and of the driver's 900 s for the whole suite) drawing 26 G normal deviates on one host core; the hashed set is the same
 bits on CPU and GPU, so the test fills the model on the device in seconds.  The fixture records ``w_method``.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_26b.py        (~40 min on 8 otherwise idle cores, < 12 GB)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_26b.py        (15 min on 8 otherwise idle cores with the hashed weights; 40 min with the serial generator of rounds 4-5; < 12 GB)
 
 Output: tests/golden/e2e_26b_full.pt (plain tensors: loads with weights_only=True)
 """
