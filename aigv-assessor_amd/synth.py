@@ -185,6 +185,8 @@ def make_state_dict_iter(cfg: InternVLChatConfig, seed: int = 0, dtype=torch.bfl
 
 
 def _hashed_state_dict_iter(cfg, seed, dtype, device, rich, big):
+    # (the small tensors follow the same distributions as the randn method above, from a CPU generator of their own that no matrix draws from; kept apart from that
+    # method's loop on purpose - ITS draw order is what every reference-recorded fixture depends on and must never change)
     g = torch.Generator().manual_seed(seed)
     n_score = len(cfg.score_dims)
     for i, (name, shape, kind) in enumerate(weight_shapes(cfg)):
