@@ -122,6 +122,36 @@ def test_batched_loop_yields_what_the_plain_loop_yields(k, ahead):
         assert "front" not in model.order
 
 
+def test_batched_loop_over_a_real_dataloader_with_the_drivers_item_layout():
+    """The driver's own plumbing (stage2_eval.py:906-941): a map-style dataset whose items are UNBATCHED tensors / strings / floats, wrapped by
+    ``DataLoader(batch_size=1)`` (default collate: leading 1 on tensors, strings into lists, floats into a [1] tensor) - sharded, batched, and
+    equal to the plain loop over the same loader."""
+    from torch.utils.data import DataLoader, Dataset
+    cfg, sd, items, ctx = _rig(n_items=6)
+
+    class DS(Dataset):
+        def __len__(self):
+            return len(items)
+
+        def __getitem__(self, i):
+            it = items[i]
+            return {"input_ids": it["input_ids"][0], "labels": it["labels"][0], "attention_mask": it["attention_mask"][0], "image_flags": it["image_flags"][0],
+                    "pixel_values": it["pixel_values"][0], "motion_feature": it["motion_feature"][0], "mos": float(it["mos"]), "video_name": it["video_name"][0],
+                    "answer": "The static quality of the video is good."}
+    want = _plain_loop(OracleLoopModel(cfg, sd, ctx), list(DataLoader(DS(), batch_size=1)))
+    for world in (1, 2):
+        rows = []
+        for rank in range(world):
+            model = OracleLoopModel(cfg, sd, ctx)
+            loader = DataLoader(eval_utils.shard(DS(), rank, world), batch_size=1)
+            got = list(eval_utils.batched(loader, model, k=2))
+            assert all(isinstance(it["video_name"], list) and it["input_ids"].dim() == 2 and it["mos"].shape == (1,) for it, _ in got)
+            rows.append([(it["video_name"][0], out["score1"], out["logit"]) for it, out in got])
+        merged = [rows[j % world][j // world] for j in range(len(items))]
+        for (name, score, logit), (wname, wscore, wlogit, _) in zip(merged, want):
+            assert name == wname and torch.equal(score, wscore) and torch.equal(logit, wlogit)
+
+
 def test_groups_break_where_the_frame_geometry_changes_and_uint8_frames_are_ingested():
     cfg, sd, items, ctx = _rig(n_items=7, ragged_geometry=True)          # items 3, 4 hold 40x40 frames, the others 56x56
     fr = lambda it: it["frames"]
