@@ -1172,7 +1172,7 @@ int aigv_vit_forward(aigv_ctx* c, const void* frames, int n_frames, void* out_to
     const int F = std::min(k.vit_chunk, n_frames - f0);
     const int rows = F * c->S;
     const bf16_t* fr = (const bf16_t*)frames + (size_t)f0 * frame_elems;
-    {   // every frame is a sequence of S rows (cached per chunk size)
+    {   // every frame is a sequence of S rows; the table is written by every pass (build_row_plan)
       std::vector<int32_t> cu(F + 1);
       for (int i = 0; i <= F; ++i) cu[i] = i * c->S;
       TRY(build_row_plan(c, c->rp_vit, cu.data(), F, s));

@@ -149,7 +149,9 @@ int aigv_kv_reorder(aigv_ctx* ctx, const int32_t* parent, const int32_t* len, in
  * prefill (a continuation scores like the same tokens inside one prefill of this mode); aigv_decode_step streams the e4m3 copies too
  * (same rule: all but the post-attention half of the last layer; the token rows are normalised and quantised inside the GEMVs) for up
  * to 4 sequences and hidden / intermediate widths of 2048 j (j = 2, 3 / 2, 3, 7, 8), else it decodes from the bf16 weights.  The reference
- * has no fp8 path: results move by the quantisation noise (oracle/fp8.py restates this mode; measured drift in DESIGN.md).  First call
+ * has no fp8 path: results move by the quantisation noise (oracle/fp8.py restates this mode).  EXPERIMENTAL: over the 37 clips recorded from the
+ * reference the mode's SCORES correlate with the reference's at SRCC 0.72 (bf16 path: 0.985) - not usable as scores on that evidence.
+ * Every e4m3 linear of a pass is ONE launch in full K (round 6), so in this mode too a clip's bits do not depend on its batch mates.  First call
  * quantises the weights (extra memory: one byte per InternLM2 linear weight).  Needs H, qkv width, 2*I multiples of 256.
  * aigv_finalize_weights after a reload of an InternLM2 linear (wqkv / wo / w1 / w3 / w2 of any layer) drops the e4m3 copies and returns the
  * context to bf16: set the mode again after it.  A finalize that follows other uploads only (the rotary tables after aigv_ctx_resize, a
