@@ -216,3 +216,25 @@ def batched(items, model, k: int = 4, frames=None, ahead: bool = True, pad_id: i
     if pending is not None:
         yield from collect(pending)
     yield from collect(run)
+
+
+def score_dataset(items, model, tokenizer, k: int = 4, frames=None, group=None, output_file: Optional[str] = None, im_end_id: int = 92542):
+    """The body of the reference's eval loop as ONE call (stage2_eval.py:908-972; stage1_eval.py:905-960 is the same body without the score):
+    every item of ``items`` (this rank's share: pass ``shard(dataset, rank, world)`` wrapped in the driver's ``DataLoader(batch_size=1)``) scored
+    through ``batched`` in groups of ``k``; per item the answer-token slice (:940-941) is decoded with ``tokenizer``, parsed into a level
+    (:956-967) and appended as the driver's row ``[video_name, answer, output, mos, score1, level]`` (:970); the rows of all ranks of ``group``
+    are put back into the set's order (``gather_rows``) and, on the caller's side, go through ``save_and_evaluate`` (:973) when ``output_file``
+    is given or metrics are wanted.  Returns ``(rows, metrics)``; ``metrics`` is None when the set is empty.  A stage-1 model returns no ``score1``: its
+    rows carry 0.0 in that column."""
+    rows = []
+    for item, out in batched(items, model, k=k, frames=frames):
+        labels_row = item["labels"][0] if item["labels"].dim() == 2 else item["labels"]
+        pred = answer_ids(labels_row, out["logit"], im_end_id=im_end_id)
+        text = tokenizer.decode(pred)
+        name = item["video_name"][0] if isinstance(item.get("video_name"), (list, tuple)) else item.get("video_name")
+        answer = item["answer"][0] if isinstance(item.get("answer"), (list, tuple)) else item.get("answer", "")
+        mos = float(item["mos"].reshape(-1)[0]) if item.get("mos") is not None else 0.0
+        score1 = float(out["score1"].float().item()) if "score1" in out else 0.0
+        rows.append([name, answer, text, mos, score1, parse_level(text)])
+    rows = gather_rows(rows, group)
+    return rows, (save_and_evaluate(rows, output_file) if rows else None)

@@ -152,6 +152,35 @@ def test_batched_loop_over_a_real_dataloader_with_the_drivers_item_layout():
             assert name == wname and torch.equal(score, wscore) and torch.equal(logit, wlogit)
 
 
+def test_score_dataset_is_the_drivers_loop_body():
+    """eval_utils.score_dataset = stage2_eval.py:908-973 as one call: rows [video_name, answer, output, mos, score1, level] equal to the plain loop's,
+    CSV written with the driver's columns, the six correlation figures + substring accuracy returned."""
+    import csv
+    import tempfile
+
+    class Tok:          # token id -> one of the five level words (ids mod 5), joined by blanks: enough for the slice / decode / parse chain
+        words = ("bad", "poor", "fair", "good", "excellent")
+
+        def decode(self, ids):
+            return " ".join(self.words[int(i) % 5] for i in ids.tolist() if int(i) >= 0)
+    cfg, sd, items, ctx = _rig(n_items=5)
+    for it, a in zip(items, ("bad", "poor", "fair", "good", "excellent")):
+        it["answer"] = [f"The quality of the video is {a}."]
+    im_end = synth.canonical_tokens(cfg, 1, 2, seed=20)["im_end_id"]
+    want = []
+    for it, (name, score, logit, _label) in zip(items, _plain_loop(OracleLoopModel(cfg, sd, ctx), items)):
+        text = Tok().decode(eval_utils.answer_ids(it["labels"][0], logit, im_end_id=im_end))
+        want.append([name, it["answer"][0], text, float(it["mos"]), float(score.float().item()), eval_utils.parse_level(text)])
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "out.csv")
+        rows, metrics = eval_utils.score_dataset(items, OracleLoopModel(cfg, sd, ctx), Tok(), k=2, output_file=path, im_end_id=im_end)
+        assert rows == want
+        got = list(csv.reader(open(path)))
+        assert tuple(got[0]) == eval_utils.CSV_COLUMNS and len(got) == 1 + len(items) and got[1][0] == "clip0.mp4"
+    assert set(metrics) == {"acc", "level_srcc", "level_plcc", "level_krcc", "pred_score_srcc", "pred_score_plcc", "pred_score_krcc"}
+    assert eval_utils.score_dataset([], None, Tok()) == ([], None)
+
+
 def test_groups_break_where_the_frame_geometry_changes_and_uint8_frames_are_ingested():
     cfg, sd, items, ctx = _rig(n_items=7, ragged_geometry=True)          # items 3, 4 hold 40x40 frames, the others 56x56
     fr = lambda it: it["frames"]
