@@ -774,6 +774,8 @@ int aigv_sizeof_config(void) { return (int)sizeof(aigv_config); }
 
 const char* aigv_last_error(const aigv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
+void aigv_clear_hip_error(void) { (void)hipGetLastError(); }
+
 // Everything whose size depends on the capacities of aigv_config (frames, tokens, sequences, output rows, KV): activations, index
 // arrays, split-K scratch, KV caches.  Booked in ws_allocs so that aigv_ctx_resize can replace them without touching the weights.
 static int alloc_workspaces(aigv_ctx* c) {

@@ -728,12 +728,18 @@ class InternVLChatModel(nn.Module):
         SlowFast side stream, InternLM2, heads), the frames are copied into the graph's input buffer first.  Same kernels, same bits
         (tests/test_gpu_api.py); what changes is the host time per pass (5-6 ms -> ~0.1 ms) - decisive where the host is slower than the
         GPU's launch stream (a CPU-throttled container: 314 -> 115 ms per step measured, profiles/r5_graph_replay.txt).  Off by default;
-        any weight / mode / knob change drops the captured graphs."""
+        any weight / mode / knob change drops the captured graphs (after a device synchronisation).  At most GRAPH_CACHE_SIZE call shapes are
+        tracked; a captured graph is never evicted while the model runs - once every entry holds a graph, further call shapes stay eager (round 6:
+        a 1200-clip soak with ragged groups showed that destroying a graph to make room, possibly with its replay still in flight, poisons a later
+        capture: tests/manual/soak_loop.py)."""
         self._graph_replay_enabled = bool(on)
+        self._drop_graphs()
         self._graphs = {}
 
     def _drop_graphs(self):
         if getattr(self, "_graphs", None):
+            if any(isinstance(v, tuple) for v in self._graphs.values()) and self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)      # no replay may be in flight when a graph (and the memory pool of its static buffers) is destroyed
             self._graphs = {}
 
     def _graph_call(self, host_key, dev_inputs, fn, clone_outputs=True):
@@ -743,9 +749,18 @@ class InternVLChatModel(nn.Module):
         key = (host_key, tuple(None if t is None else (tuple(t.shape), t.dtype) for t in dev_inputs))
         graphs = self.__dict__.setdefault("_graphs", {})
         ent = graphs.get(key)
+        if os.environ.get("AIGV_GRAPH_DEBUG"):
+            import sys as _s
+            print(f"[graph] {host_key[0]} key#{hash(key) & 0xffff:04x} state={'new' if ent is None else ent if isinstance(ent, str) else 'captured'} cache={len(graphs)} "
+                  f"stream={torch.cuda.current_stream(self.device).cuda_stream:#x}", file=_s.stderr, flush=True)
         if ent is None:                      # first occurrence: eager (sizes the context, warms every kernel); remember the key
             if len(graphs) >= self.GRAPH_CACHE_SIZE:
-                graphs.pop(next(iter(graphs)))
+                # make room by forgetting a key that holds no graph; a CAPTURED graph is never destroyed while the model runs (only by _drop_graphs:
+                # a weight / mode / capacity change) - when all entries hold graphs, further call shapes simply stay eager
+                victim = next((k for k, v in graphs.items() if isinstance(v, str)), None)
+                if victim is None:
+                    return None
+                graphs.pop(victim)
             graphs[key] = "seen"
             return None
         if ent == "eager":
@@ -761,10 +776,20 @@ class InternVLChatModel(nn.Module):
                 keep = self._capture_keep
             except Exception as e:           # a pass that does not capture (an allocation or a synchronisation inside it) stays eager for good - and
                 import warnings              # says so; the eager run that follows raises whatever was a real error rather than a capture-illegal call
-                warnings.warn(f"graph replay: capture of {host_key[0]!r} failed ({type(e).__name__}: {e}); this call shape stays eager")
+                import traceback
+                where = "".join(traceback.format_tb(e.__traceback__)[-3:])
+                warnings.warn(f"graph replay: capture of {host_key[0]!r} failed ({type(e).__name__}: {str(e).splitlines()[0]}); this call shape stays eager\n{where}")
                 graphs[key] = "eager"
                 self._capture_keep = None
-                torch.cuda.synchronize(self.device)
+                native.load().aigv_clear_hip_error()
+                try:                             # can this process still launch?  (scripts/capture_error_probe.py: on ROCm 7.2 a capture that an illegal call INVALIDATED
+                    torch.zeros(1, device=self.device).add_(1)      # is never ended - hipStreamEndCapture on it crashes - and every later launch on any stream
+                    torch.cuda.synchronize(self.device)             # fails with hipErrorStreamCaptureInvalidated: there is nothing to fall back to)
+                except Exception as dead:
+                    raise native.NativeError(
+                        f"HIP-graph capture of {host_key[0]!r} was invalidated ({type(e).__name__}: {str(e).splitlines()[0]}) and this ROCm build cannot recover from that: every "
+                        "further kernel launch of the process fails.  Restart without enable_graph_replay() - the eager path runs the same kernels - and report the call "
+                        "sequence that led here") from dead
                 return None
             finally:
                 self._capture_keep = None

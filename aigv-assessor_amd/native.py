@@ -47,6 +47,7 @@ PROTOTYPES = {
     "aigv_ctx_destroy": (None, [_P]),
     "aigv_ctx_resize": (_I, [_P, C.POINTER(AigvConfig)]),
     "aigv_last_error": (C.c_char_p, [_P]),
+    "aigv_clear_hip_error": (None, []),
     "aigv_load_weight": (_I, [_P, C.c_char_p, _P, _I64P, _I, _I, _I]),
     "aigv_finalize_weights": (_I, [_P]),
     "aigv_vit_forward": (_I, [_P, _P, _I, _P, _P]),

@@ -89,6 +89,10 @@ void aigv_ctx_destroy(aigv_ctx* ctx);
  * context unusable: destroy it. */
 int aigv_ctx_resize(aigv_ctx* ctx, const aigv_config* cfg);
 const char* aigv_last_error(const aigv_ctx* ctx);     /* ctx may be NULL (creation errors) */
+/* Read and clear the HIP runtime's sticky last-error state of the calling thread.  The launchers report hipGetLastError() after every launch, so an error
+ * left behind by something ELSE - a stream capture the caller's framework abandoned (hipErrorStreamCaptureInvalidated stays pending after the failed
+ * hipStreamEndCapture) - would be blamed on the next launch of this library.  A host that falls back from a failed capture to eager launches calls this first. */
+void aigv_clear_hip_error(void);
 
 /* Weight upload.  `name` is the reference state-dict key, e.g.
  * "vision_model.encoder.layers.3.attn.qkv.weight", "language_model.model.layers.0.attention.wqkv.weight",
