@@ -31,6 +31,14 @@ for rnd in range(6):
     n = sum(isinstance(v, tuple) for v in model._graphs.values())
     # drop every captured graph in three different ways, then run again (recapture under the look-ahead)
     [lambda: model.set_gemm_mode(-1), lambda: model._drop_graphs(), lambda: model.set_attention_numerics("fp32")][rnd % 3]()
+    if rnd in (1, 4):     # a generate() call between the rounds: the KV cache is sized (a context resize: graphs dropped), decode steps run eager, then the loop recaptures
+        n_prompt = int((toks["labels"][0] == -100).sum())
+        ids = toks["input_ids"][:, :n_prompt].clone()
+        ids[0, (ids[0] == toks["img_context_token_id"]).nonzero()[-1]] = 7
+        pvg = model.ingest_frames(pool[0].cuda())
+        gen = model.generate(pixel_values=pvg, input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=4 + rnd, do_sample=False).cpu()
+        if "gen" in first and first["gen"] != gen[0, :4].tolist(): bad += 1
+        first.setdefault("gen", gen[0, :4].tolist())
     print(f"round {rnd}: captured graphs before the drop {n}, mismatches so far {bad}", flush=True)
 # a bigger group mid-run: the context grows (resize), graphs are dropped, recaptured
 model2_items = list(items(16))
