@@ -154,6 +154,9 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor):
     node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
+_PARKED_GRAPHS: list = []      # captured passes that were dropped: kept alive until the interpreter exits (InternVLChatModel._drop_graphs)
+
+
 # ------------------------------------------------------------------------------------------------------
 class VisualAhead:
     """The visual front of a LATER ``forward`` call, started ahead of time by ``InternVLChatModel.prefetch``: pre-projector tokens
@@ -498,8 +501,12 @@ class InternVLChatModel(nn.Module):
 
     def __del__(self):
         try:
+            _PARKED_GRAPHS.extend(v for v in getattr(self, "_graphs", {}).values() if isinstance(v, tuple))      # (see _drop_graphs)
+        except Exception:
+            pass
+        try:
             if getattr(self, "_ctx", None) is not None:
-                native.load().aigv_ctx_destroy(self._ctx)
+                native.release("aigv_ctx_destroy", self._ctx)      # (parked while a stream capture is underway: native.release)
         except Exception:
             pass
 
@@ -737,9 +744,17 @@ class InternVLChatModel(nn.Module):
         self._graphs = {}
 
     def _drop_graphs(self):
+        """Forget every captured pass (a weight / mode / knob / capacity change made them stale).  The graph OBJECTS are not destroyed: they are parked in a
+        process-wide list until the interpreter exits.  On this stack (ROCm 7.2, torch 2.10) destroying a graph object - like any device-memory release - INSIDE a
+        stream capture kills that capture (the process aborts or can launch nothing any more: scripts/capture_hipfree_probe.py), and an object that is merely dropped
+        may be destroyed at any later moment by Python's cyclic collector, also in the middle of another capture.  native.capturing() keeps the collector off during
+        the captures this package starts; parking covers captures started by anyone else.  It costs the static buffers of the dropped graphs (tens of MB each at 8B
+        sizes) per drop; drops are rare."""
         if getattr(self, "_graphs", None):
-            if any(isinstance(v, tuple) for v in self._graphs.values()) and self.device.type == "cuda":
-                torch.cuda.synchronize(self.device)      # no replay may be in flight when a graph (and the memory pool of its static buffers) is destroyed
+            held = [v for v in self._graphs.values() if isinstance(v, tuple)]
+            if held and self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)      # (no replay in flight while the entries change hands)
+            _PARKED_GRAPHS.extend(held)
             self._graphs = {}
 
     def _graph_call(self, host_key, dev_inputs, fn, clone_outputs=True):
@@ -771,7 +786,7 @@ class InternVLChatModel(nn.Module):
             graph = torch.cuda.CUDAGraph()
             self._capture_keep = []
             try:
-                with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+                with native.capturing(), torch.cuda.graph(graph, capture_error_mode="relaxed"):
                     outputs = fn(*statics)
                 keep = self._capture_keep
             except Exception as e:           # a pass that does not capture (an allocation or a synchronisation inside it) stays eager for good - and
@@ -811,6 +826,8 @@ class InternVLChatModel(nn.Module):
     def _forward_through_graph(self, mos, pixel_values, input_ids, attention_mask, image_flags, labels, motion_feature, visual_tokens, full_logits):
         """The replay path of ``forward``; returns None when the call does not qualify (the eager path then runs)."""
         src = visual_tokens if visual_tokens is not None else pixel_values
+        if self._rope_seq_len(int(input_ids.shape[1])) != getattr(self, "_rope_ntk", 0):
+            return None      # this pass re-derives the rotary tables (dynamic NTK: another sequence length than the last pass) - synchronous uploads, never inside a capture
         if (mos is not None or src is None or not src.is_cuda or self._dirty or self._ctx is None or getattr(self, "_prof_on", False)
                 or (motion_feature is not None and not motion_feature.is_cuda) or (visual_tokens is not None and motion_feature is None)):
             return None
@@ -1478,7 +1495,7 @@ class InternVLChatModel(nn.Module):
         graph = torch.cuda.CUDAGraph()
         self._capture_keep = []
         try:
-            with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+            with native.capturing(), torch.cuda.graph(graph, capture_error_mode="relaxed"):
                 outputs = self.forward(**forward_kwargs)
             keep = self._capture_keep
         finally:

@@ -150,3 +150,57 @@ def stream_ptr() -> Optional[int]:
 def i32_array(values):
     arr = (C.c_int32 * len(values))(*[int(v) for v in values])
     return arr
+
+
+# ---- releases of native handles and stream captures ------------------------------------------------------------------------------------------------------
+# aigv_ctx_destroy / aigv_slowfast_destroy free device memory (hipFree: a device synchronisation).  Inside a stream capture that INVALIDATES the capture, and
+# on ROCm 7.2 an invalidated capture cannot be recovered from (scripts/capture_error_probe.py).  A finalizer can run at any moment: the host-side models hold
+# reference cycles, so they die in Python's CYCLIC collector - which torch 2.10 no longer runs in front of a capture (torch.cuda.graph.__enter__,
+# force_cudagraph_gc) and which may therefore fire in the middle of one (seen as a now-and-then failure of whichever capture came after a model had gone out of
+# scope).  So: every capture this package starts runs inside `capturing()` - cyclic garbage collected first, the collector off for the duration - and a
+# release requested while a capture is underway is parked and carried out afterwards.
+import contextlib
+import gc
+
+_captures_underway = 0
+_deferred_releases = []
+
+
+def release(fn_name: str, handle) -> None:
+    """Destroy a native handle now, or - while a stream capture is underway - after it."""
+    if handle is None:
+        return
+    capturing = _captures_underway > 0
+    if not capturing:
+        try:
+            import torch
+            capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        except Exception:
+            capturing = False
+    if capturing:
+        _deferred_releases.append((fn_name, handle))
+    else:
+        getattr(load(), fn_name)(handle)
+
+
+def flush_releases() -> None:
+    while _deferred_releases and _captures_underway == 0:
+        fn_name, handle = _deferred_releases.pop()
+        getattr(load(), fn_name)(handle)
+
+
+@contextlib.contextmanager
+def capturing():
+    """Bracket of every stream capture this package starts (InternVLChatModel._graph_call / capture_forward)."""
+    global _captures_underway
+    gc.collect()                      # whatever is garbage now dies now, outside the capture
+    was_enabled = gc.isenabled()
+    gc.disable()
+    _captures_underway += 1
+    try:
+        yield
+    finally:
+        _captures_underway -= 1
+        if was_enabled:
+            gc.enable()
+        flush_releases()

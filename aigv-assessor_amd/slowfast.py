@@ -64,7 +64,7 @@ class SlowFastR50:
     # ---- native handle ---------------------------------------------------------------------------------------------------
     def _release(self):
         if self._handle is not None:
-            native.load().aigv_slowfast_destroy(self._handle)
+            native.release("aigv_slowfast_destroy", self._handle)      # (parked while a stream capture is underway: native.release)
         self._handle, self._key = None, None
 
     def __del__(self):

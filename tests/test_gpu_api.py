@@ -744,6 +744,39 @@ def test_graph_cache_keeps_captured_graphs_and_survives_a_failed_capture():
     assert all(torch.equal(s, eager[0][0]) and torch.equal(l, eager[0][1]) for s, l in again)
 
 
+def test_graph_replay_with_dynamic_ntk_lengths_alternating():
+    """Round 6: under rope_scaling = dynamic a pass whose sequence length differs from the last pass's re-derives the rotary tables - synchronous uploads, which
+    must never happen inside a stream capture (an invalidated capture cannot be recovered from on this ROCm build).  Such a pass takes the eager path; prompts of
+    215 and 144 tokens (max_position_embeddings 128: both rescaled, by different bases) alternate under graph replay and score exactly as the eager model."""
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    cfg.llm_config.rope_scaling = {"type": "dynamic", "factor": 2.0}
+    cfg.llm_config.max_position_embeddings = 128
+    model = InternVLChatModel(cfg, max_clips=2)
+    model.load_state_dict(synth.make_state_dict(cfg, seed=51, rich=True))
+    model.eval().cuda()
+    cases = {}
+    for name, T, seed in (("long", 2, 1), ("short", 1, 2)):
+        cases[name] = (synth.canonical_tokens(cfg, 1, T, seed=seed), synth.synthetic_frames(T, 224, seed=seed).cuda(), synth.synthetic_motion(1, cfg.motion_dim, seed=seed).cuda())
+    assert [cases[n][0]["input_ids"].shape[1] for n in ("long", "short")] == [215, 144]
+
+    def run(name):
+        t, pv, mo = cases[name]
+        model.img_context_token_id = t["img_context_token_id"]
+        o = model(mos=None, pixel_values=pv, input_ids=t["input_ids"], attention_mask=t["attention_mask"], image_flags=torch.ones(pv.shape[0], 1, dtype=torch.long), labels=t["labels"],
+                  motion_feature=mo)
+        torch.cuda.synchronize()
+        return o["score1"].item(), o["logit"].clone(), model._rope_ntk
+    seq = ["long", "short", "long", "short", "long", "long", "long", "long", "short", "short", "short", "long"]
+    model.enable_graph_replay(False)
+    eager = [run(n) for n in seq]
+    model.enable_graph_replay(True)
+    got = [run(n) for n in seq]
+    assert all(a[0] == b[0] and torch.equal(a[1], b[1]) and a[2] == b[2] for a, b in zip(got, eager))
+    assert {e[2] for e in eager} == {215, 144} and eager[0][0] != eager[1][0]
+    model.enable_graph_replay(False)
+
+
 def test_lookahead_with_split_k_tails_in_the_vit_frames():
     """prefetch() runs aigv_vit_forward on its own stream beside the InternLM2 pass of the same context.  At 336 px a
     frame has 577 rows - two body tiles and a 65-row tail that InternViT's K = 1024 linears run as split-K slices through fp32 scratch.
