@@ -744,6 +744,16 @@ def test_graph_cache_keeps_captured_graphs_and_survives_a_failed_capture():
     assert all(torch.equal(s, eager[0][0]) and torch.equal(l, eager[0][1]) for s, l in again)
 
 
+def test_a_finalizer_firing_inside_a_capture_is_parked():
+    """Round 6: a device-memory release inside a stream capture invalidates the capture, and on ROCm 7.2 that is the end of the process (scripts/capture_hipfree_probe.py).
+    The host-side models die in Python's cyclic collector, i.e. at any moment: tests/capture_guard_child.py collects one in the middle of another model's captured pass."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "capture_guard_child.py")], capture_output=True, text=True, timeout=600, cwd=root)
+    print(r.stdout[-500:], r.stderr[-1500:])
+    assert r.returncode == 0 and "GUARD_OK" in r.stdout, r.stderr[-2000:]
+
+
 def test_graph_replay_with_dynamic_ntk_lengths_alternating():
     """Round 6: under rope_scaling = dynamic a pass whose sequence length differs from the last pass's re-derives the rotary tables - synchronous uploads, which
     must never happen inside a stream capture (an invalidated capture cannot be recovered from on this ROCm build).  Such a pass takes the eager path; prompts of
