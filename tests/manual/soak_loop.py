@@ -3,7 +3,7 @@ prompts, cycled - through eval_utils.batched(k = 4) with graph replay on, checki
 gives the SAME bits as its first occurrence, device memory in use does not grow (torch allocator + the native context's own allocations via hipMemGetInfo), host RSS
 does not grow, the graph cache stays bounded.
 
-    python tests/manual/soak_loop.py [n_clips = 1200]        # MI355X, ~1 min"""
+    python tests/manual/soak_loop.py [n_clips = 1200] [--uniform] [--k=K] [--tiny]       # MI355X, ~1 min (--k: group size of the loop, default 4)"""
 import os
 import resource
 import sys
@@ -22,11 +22,12 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n_clips = int(args[0]) if args else 1200
 tiny = "--tiny" in sys.argv                                            # a small model (debugging the loop itself)
 uniform = "--uniform" in sys.argv                                      # every clip behind the same prompt (the reference's eval set per perspective): every group replays
+K = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--k=")), 4)
 cfg = pkg.tiny(image_size=224, vit_layers=2, llm_layers=2) if tiny else pkg.internvl2_8b()
 T = 8
 dev = torch.device("cuda", 0)
 N = synth.canonical_len(cfg, T)
-model = InternVLChatModel(cfg, device=dev, max_clips=4, max_frames=4 * T, max_tokens=4 * (N + 8))
+model = InternVLChatModel(cfg, device=dev, max_clips=K, max_frames=K * T, max_tokens=K * (N + 8))
 model.load_state_dict(synth.make_state_dict(cfg, seed=0, device=dev, rich=True))
 model.eval()
 model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=0))
@@ -48,7 +49,7 @@ model.img_context_token_id = toks["img_context_token_id"]
 
 def items():
     for i in range(n_clips):
-        ids, lab = prompts[0] if uniform else prompts[(i // 4) % 3 if i % 7 else i % 3]   # mostly group-uniform prompts (graphs replay), now and then a ragged group (eager)
+        ids, lab = prompts[0] if uniform else prompts[(i // K) % 3 if i % 7 else i % 3]   # mostly group-uniform prompts (graphs replay), now and then a ragged group (eager)
         yield {"input_ids": ids, "labels": lab, "attention_mask": torch.ones_like(ids, dtype=torch.bool), "image_flags": torch.ones(1, T, 1, dtype=torch.long),
                "frames": pool[i % 5], "key": (i % 5, ids.shape[1])}
 
@@ -60,7 +61,7 @@ def mem():
 
 first, mismatches, marks = {}, 0, []
 t0 = time.time()
-for j, (it, out) in enumerate(eval_utils.batched(items(), model, k=4, frames=lambda it: it["frames"])):
+for j, (it, out) in enumerate(eval_utils.batched(items(), model, k=K, frames=lambda it: it["frames"])):
     val = (out["score1"].item(), tuple(eval_utils.answer_ids(it["labels"][0], out["logit"]).tolist()))
     if first.setdefault(it["key"], val) != val:
         mismatches += 1
@@ -68,7 +69,7 @@ for j, (it, out) in enumerate(eval_utils.batched(items(), model, k=4, frames=lam
         torch.cuda.synchronize()
         marks.append((j + 1,) + mem())
 dt = time.time() - t0
-print(f"{n_clips} clips in {dt:.1f} s = {n_clips / dt:.1f} clips/s through eval_utils.batched(k = 4) (uint8 720p frames from pinned host memory, graph replay on, {'one prompt for every clip' if uniform else 'ragged groups mixed in'})")
+print(f"{n_clips} clips in {dt:.1f} s = {n_clips / dt:.1f} clips/s through eval_utils.batched(k = {K}) (uint8 720p frames from pinned host memory, graph replay on, {'one prompt for every clip' if uniform else 'ragged groups mixed in'})")
 print(f"{len(first)} distinct (clip, prompt length) pairs; repetitions that differ from their first occurrence: {mismatches}")
 for n, used, alloc, rss in marks:
     print(f"after {n:5d} clips: device memory in use {used:9.0f} MiB (torch allocator {alloc:9.0f} MiB), host max RSS {rss:7.0f} MiB")
