@@ -12,6 +12,8 @@ on such weights (then HIP can be held to a hard per-clip bar), or not (then the 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_8b_conditioned.py --phase bf16 --threads 8 4
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_8b_conditioned.py --phase bf16 --threads 1 --seeds 0
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_8b_conditioned.py --phase fp32
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_8b_conditioned.py --phase bf16 --threads 8 --seeds 4 5 6 7     (later in round 6: 16 more clips
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_8b_conditioned.py --phase fp32 --seeds 4 5 6 7                   for the task-level statistics)
     python tests/golden/make_golden_8b_conditioned.py --merge
 
 Output: tests/golden/e2e_8b_conditioned.pt (outputs only; the test regenerates the weights: synth.make_state_dict(W_SEED) +
@@ -85,6 +87,9 @@ def merge():
     parts = sorted(glob.glob(part_path("*")))
     assert parts, "no part files"
     out = None
+    dst = os.path.join(HERE, "e2e_8b_conditioned.pt")
+    if os.path.exists(dst):                              # more cases recorded later (seeds 4-7) join the cases already there
+        out = torch.load(dst, weights_only=True)
     for p in parts:
         d = torch.load(p, weights_only=True)
         if out is None:
@@ -93,7 +98,6 @@ def merge():
         for k in ("llm_config", "vision_config", "w_seed", "overrides"):
             assert out[k] == d[k], (p, k)
         out["cases"].update(d["cases"])
-    dst = os.path.join(HERE, "e2e_8b_conditioned.pt")
     torch.save(out, dst)
     print("merged", [os.path.basename(p) for p in parts], "->", dst)
     for k in sorted(out["cases"]):

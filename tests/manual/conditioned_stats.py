@@ -55,7 +55,7 @@ for precision in ("bf16", "fp8"):
     model.set_precision(precision)
     for numerics in ("fp32", "reference"):
         model.set_attention_numerics(numerics)
-        d16, d32, lev, rows, s_hip, s_ref = [], [], 0, 0, [], []
+        d16, d32, lev, rows, s_hip, s_ref, s_hip32, s_ref32 = [], [], 0, 0, [], [], [], []
         for s in seeds:
             r8 = cases[f"batch4/seed{s}/bf16/t8"]
             toks = synth.canonical_tokens(cfg, 4, 8, seed=s)
@@ -68,8 +68,9 @@ for precision in ("bf16", "fp8"):
             f = cases.get(f"batch4/seed{s}/fp32/t8")
             if f is not None:
                 d32 += [abs(float(hip[i] - f["score1"].float()[i])) / ulp(a[i]) for i in range(4)]
+                s_hip32 += hip.tolist(); s_ref32 += f["score1"].float().tolist()
             lev += int((o["logit"].cpu()[r8["answer_rows"]] != r8["logit"]).sum()); rows += int(r8["logit"].numel())
-        print(f"hip {precision}, attention numerics {numerics:9s}: vs ref bf16 {st(d16)};  vs ref fp32 {st(d32)};  level tokens differing {lev}/{rows};  task level vs ref bf16: {corr(s_hip, s_ref)}")
+        print(f"hip {precision}, attention numerics {numerics:9s}: vs ref bf16 {st(d16)};  vs ref fp32 {st(d32)};  level tokens differing {lev}/{rows};  task level vs ref bf16: {corr(s_hip, s_ref)}, vs ref fp32: {corr(s_hip32, s_ref32)}")
 # the reference against itself at task level (every recorded thread count against the 8-thread pass, pooled)
 x, y = [], []
 for s in seeds:
@@ -79,3 +80,9 @@ for s in seeds:
         if o is not None:
             x += o["score1"].float().tolist(); y += a
 print(f"reference vs itself, task level ({len(x)} pairs pooled): {corr(x, y)}")
+x, y = [], []
+for s in seeds:
+    f = cases.get(f"batch4/seed{s}/fp32/t8")
+    if f is not None:
+        x += cases[f"batch4/seed{s}/bf16/t8"]["score1"].float().tolist(); y += f["score1"].float().tolist()
+print(f"reference bf16 (8 threads) vs its fp32 pass, task level ({len(x)} clips): {corr(x, y)}")
