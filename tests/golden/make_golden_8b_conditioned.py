@@ -3,8 +3,8 @@
 The full-size fixtures so far use iid N(0, 0.02^2) weights, on which a score is a chaotic function of the rounding history: the reference
 moves 2.56 bf16 ulps (mean) against ITSELF with the host's thread count (e2e_8b_r5.pt).  A trained checkpoint is better conditioned.  This
 script records the same reference on the same seeded weights after ``synth.condition_state_dict`` (InternViT ls1 / ls2 x 0.1, InternLM2
-wo / w2 x 1 / sqrt(2 L)): two batches of the benched shape (4 clips x 8 frames x 448 px, N = 2177; input seeds 0 and 1) in bf16 under
-8 / 4 host threads, the first batch also under 1 thread, and both in fp32 - to answer: is the reference stable against itself to <= 1 ulp
+wo / w2 x 1 / sqrt(2 L)): eight batches of the benched shape (4 clips x 8 frames x 448 px, N = 2177; input seeds 0-7) in bf16 under
+8 host threads - seeds 0-3 also under 4, seeds 0-1 under 2, seed 0 under 1 - and all of them in fp32 - to answer: is the reference stable against itself to <= 1 ulp
 on such weights (then HIP can be held to a hard per-clip bar), or not (then the statistical bar of tests/test_gpu_e2e.py is what there is).
 
 (reference: internvl/model/internvl_chat_eval2/modeling_internvl_chat.py:306-488; internvl/train/internvl/eval/stage2_eval.py:908-941.)

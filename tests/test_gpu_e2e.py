@@ -1231,7 +1231,7 @@ def test_full_size_8b_properties(full_8b):
 
 def test_full_size_8b_conditioned_weights_against_the_reference(full_8b, golden_dir):
     """the same seeded weights made to look like a trained checkpoint (synth.condition_state_dict: InternViT layer scales
-    x 0.1, InternLM2 wo / w2 x 1 / sqrt(2 L)), 16 clips recorded from the imported reference in bf16 under 8 / 4 (/ 2 / 1) host threads, 8+ of
+    x 0.1, InternLM2 wo / w2 x 1 / sqrt(2 L)), 32 clips recorded from the imported reference in bf16 (16 of them also under 4 (/ 2 / 1) host threads), all of
     them in fp32 (tests/golden/make_golden_8b_conditioned.py).  The question was whether the reference is then stable against itself to <= 1 bf16
     ulp, so that HIP could be held to a hard per-clip bar.  MEASURED: it is not - its passes under other thread counts sit 3.1
     bf16 ulps (mean; max 10) from its 8-thread pass, and its bf16 pass 4.7 (max 11.9) from its OWN fp32 pass.  In absolute terms the noise is
@@ -1269,6 +1269,7 @@ def test_full_size_8b_conditioned_weights_against_the_reference(full_8b, golden_
         d_hip, d_self, d32_hip, d32_ref, lev_rows = [], [], [], [], 0
         lev_hip, lev_ref = [0, 0, 0, 0], [0, 0, 0, 0]             # flips, flips to a token outside the 8-thread pass's top four, flips beyond the near-tie bar, rows
         h_hip, h_self, h32_hip, h32_ref = [], [], [], []          # the same four distances on hidden[:, -4] (relative L2 over its 4096 coordinates)
+        s_hip, s_ref16, s_hip_on32, s_ref16_on32, s_ref32 = [], [], [], [], []   # the scores themselves, for the task-level statistics (SRCC / PLCC, stage2_eval.py:652-688)
         for seed in seeds:
             r8 = cases[f"batch4/seed{seed}/bf16/t8"]
             toks = synth.canonical_tokens(cfg, 4, 8, seed=seed)
@@ -1280,6 +1281,8 @@ def test_full_size_8b_conditioned_weights_against_the_reference(full_8b, golden_
             hid = model.last_hidden_rows(4).cpu()
             d_hip += [_ulps(hip[i] - want[i], want[i]) for i in range(4)]
             h_hip += _rel_l2(hid, r8["hidden_m4"])
+            s_hip += hip.tolist()
+            s_ref16 += want.tolist()
             for t in (1, 2, 4):
                 o = cases.get(f"batch4/seed{seed}/bf16/t{t}")
                 if o is not None:
@@ -1292,6 +1295,9 @@ def test_full_size_8b_conditioned_weights_against_the_reference(full_8b, golden_
                 d32_ref += [_ulps(want[i] - w32[i], want[i]) for i in range(4)]
                 h32_hip += _rel_l2(hid, r32["hidden_m4"])
                 h32_ref += _rel_l2(r8["hidden_m4"], r32["hidden_m4"])
+                s_hip_on32 += hip.tolist()
+                s_ref16_on32 += want.tolist()
+                s_ref32 += w32.tolist()
             # level tokens: on these weights the vocabulary logits are near-uniform and the reference flips 8.5 % of its own level tokens with the thread
             # count, some to tokens outside its recorded top four - counted for both sides, compared below
             tie = _level_tie_bar(golden_dir)
@@ -1312,6 +1318,14 @@ def test_full_size_8b_conditioned_weights_against_the_reference(full_8b, golden_
         print(f"conditioned weights, hidden[:, -4] relative L2: hip vs ref bf16 {mean(h_hip):.4f}, the reference vs itself {mean(h_self):.4f}; hip vs ref fp32 {mean(h32_hip):.4f}, "
               f"the reference's bf16 pass vs its fp32 pass {mean(h32_ref):.4f}")
         assert len(d_hip) >= 8 and len(d_self) >= 8 and len(d32_hip) >= 8
+        # task level (the reference's own quality measure): on the 32 recorded clips HIP ranks like the reference - SRCC 0.9875 / PLCC 0.9917 against its bf16 scores,
+        # 0.9911 / 0.9936 against its fp32 scores, where the reference's bf16 pass reaches 0.9944 / 0.9951 against its own fp32 pass
+        c16, c32, cref = _corr(s_hip, s_ref16), _corr(s_hip_on32, s_ref32), _corr(s_ref16_on32, s_ref32)
+        print(f"conditioned weights, task level over {len(s_hip)} clips (SRCC / PLCC / KRCC): hip vs ref bf16 {c16[0]:.4f} / {c16[1]:.4f} / {c16[2]:.4f}; hip vs ref fp32 "
+              f"{c32[0]:.4f} / {c32[1]:.4f} / {c32[2]:.4f}; the reference's bf16 pass vs its fp32 pass {cref[0]:.4f} / {cref[1]:.4f} / {cref[2]:.4f}")
+        if len(s_hip) >= 24:
+            assert c16[0] >= 0.97 and c16[1] >= 0.98, c16
+            assert c32[0] >= cref[0] - 0.015 and c32[1] >= cref[1] - 0.01, (c32, cref)
         # the 4096-wide hidden state the score head reads - a vector norm, far less noisy than the scalar: as close to the fp32 computation as the reference's bf16
         # pass is, and no farther from the reference's bf16 pass than 1.3 x the larger of the reference's own two distances
         assert mean(h32_hip) <= REF_SELF_FACTOR * mean(h32_ref), (mean(h32_hip), mean(h32_ref))
