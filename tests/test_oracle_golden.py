@@ -300,6 +300,34 @@ def test_reference_self_consistency_fixture():
     assert torch.equal(old["score1"], c["batch4/seed0/t8"]["score1"]) and torch.equal(old["hidden_m4"], c["batch4/seed0/t8"]["hidden_m4"])
 
 
+def test_conditioned_fixture_structure_and_the_reference_against_itself():
+    """tests/golden/e2e_8b_conditioned.pt (make_golden_8b_conditioned.py: the imported reference, full depth, conditioned weights): 32 clips in bf16
+    and fp32, 16 of them under other host thread counts.  Structure, and the facts BASELINE.md 6b quotes from it: the reference is NOT stable
+    against itself to an ulp on these weights either, and its bf16 pass ranks the clips like its fp32 pass (SRCC 0.9944 / PLCC 0.9951) - the yardstick
+    the GPU test holds the HIP scores to."""
+    import os
+    from scipy.stats import pearsonr, spearmanr
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_8b_conditioned.pt"), weights_only=True)
+    c = g["cases"]
+    assert g["conditioned"] is True and g["llm_config"]["num_hidden_layers"] == 32 and g["vision_config"]["num_hidden_layers"] == 24
+    seeds = sorted({int(k.split("/")[1][4:]) for k in c if k.endswith("/bf16/t8")})
+    assert seeds == list(range(8))
+    s16, s32, moved = [], [], []
+    for s in seeds:
+        b, f = c[f"batch4/seed{s}/bf16/t8"], c[f"batch4/seed{s}/fp32/t8"]
+        assert b["score1"].shape == (4,) and b["hidden_m4"].shape == (4, 4096) and f["hidden_m4"].shape == (4, 4096) and b["threads"] == 8
+        assert b["logit"].shape == b["answer_rows"].shape and b["top_ids"].shape[0] == b["logit"].numel()
+        s16 += b["score1"].float().tolist()
+        s32 += f["score1"].float().tolist()
+        o = c.get(f"batch4/seed{s}/bf16/t4")
+        if o is not None:
+            moved += ((o["score1"].float() - b["score1"].float()).abs() / 2.0 ** (b["score1"].float().abs().log2().floor() - 7)).tolist()
+    assert len(moved) == 16 and max(moved) >= 2.0 and sum(moved) / len(moved) >= 1.0            # bf16 ulps: the thread count alone moves the reference's scores
+    assert min(s16) > 0.15 and max(s16) < 0.8 and max(s16) - min(s16) > 0.4                     # a spread wide enough for a rank statistic
+    srcc, plcc = float(spearmanr(s16, s32)[0]), float(pearsonr(s16, s32)[0])
+    assert abs(srcc - 0.9944) < 5e-4 and abs(plcc - 0.9951) < 5e-4, (srcc, plcc)
+
+
 def test_26b_fixture_structure_and_streamed_weights():
     """tests/golden/e2e_26b_full.pt (make_golden_26b.py: ORACLE-only, streamed): structure, consistency with the canonical inputs, and the
     streaming generator itself - make_state_dict_iter yields exactly make_state_dict's tensors (same generator walk)."""
