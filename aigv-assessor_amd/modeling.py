@@ -757,6 +757,21 @@ class InternVLChatModel(nn.Module):
             _PARKED_GRAPHS.extend(held)
             self._graphs = {}
 
+    def _prepare_motion_branch(self, frames, n_clips: int):
+        """In front of every pass that may be captured or replayed with the native SlowFast branch inside: make the branch's native handle for
+        this geometry exist NOW (creating one allocates and uploads weights - illegal inside a capture), and drop this model's graphs when any
+        handle of the branch has been destroyed since they were captured (a graph holds the addresses of a handle's buffers; SlowFastR50.epoch)."""
+        sf = self.slowfast_model
+        if sf is None or not hasattr(sf, "prepare"):
+            return
+        if frames is not None and n_clips > 0 and frames.dim() == 4 and frames.shape[0] % n_clips == 0:
+            sf.prepare(self.device, int(n_clips), int(frames.shape[0]) // int(n_clips), int(frames.shape[2]), int(frames.shape[3]))
+        seen = (id(sf), sf.epoch)
+        if getattr(self, "_sf_epoch", None) != seen:
+            if getattr(self, "_sf_epoch", None) is not None and any(isinstance(v, tuple) for v in self.__dict__.get("_graphs", {}).values()):
+                self._drop_graphs()
+            self._sf_epoch = seen
+
     def _graph_call(self, host_key, dev_inputs, fn, clone_outputs=True):
         """Graph-cached call of ``fn(*dev_inputs)`` (launches on torch's current stream only; device tensors in, a tensor / tuple / dict of
         device tensors out): first occurrence of (host_key, input shapes) -> None (the caller runs eager); second -> capture on static copies
@@ -837,6 +852,7 @@ class InternVLChatModel(nn.Module):
                     bool(getattr(self, "overlap_motion_branch", True)), bool(getattr(self, "drop_dead_tail", True)),
                     tuple(None if t is None else (tuple(t.shape), t.dtype, t.numpy().tobytes()) for t in parts))
         self._join_side_stream()             # (a motion feature started by motion_feature_async: joined BEFORE the graph copies it in)
+        self._prepare_motion_branch(pixel_values if (motion_feature is None and visual_tokens is None) else None, int(input_ids.shape[0]))
 
         def fn(src_static, mf_static):
             return self.forward(mos=None, pixel_values=None if visual_tokens is not None else src_static, input_ids=input_ids, attention_mask=attention_mask,
@@ -858,6 +874,7 @@ class InternVLChatModel(nn.Module):
             return tok, mf
         if (self._graph_replay_enabled and self._capture_keep is None and frames_local.is_cuda and not self._dirty and self._ctx is not None
                 and not getattr(self, "_prof_on", False) and (frames_clips is None or (frames_clips.is_cuda and hasattr(self.slowfast_model, "features")))):
+            self._prepare_motion_branch(frames_clips, int(n_clips))
             out = self._graph_call(("dp_front", int(n_clips), id(self.slowfast_model), bool(getattr(self, "overlap_motion_branch", True))),
                                    [frames_local, frames_clips], fn, clone_outputs=False)
             if out is not None:
@@ -1490,7 +1507,12 @@ class InternVLChatModel(nn.Module):
         ~1000 launches of the pass with ONE host call and refreshes ``outputs`` (the dict ``forward`` returned, static tensors) from the
         CURRENT contents of the input tensors' device memory; host-side arguments (token ids, labels, masks) are frozen at capture time.
         For callers whose host cannot keep up with the launch stream (a CPU-throttled container): same kernels, same bits.  The context
-        must be warm (one eager ``forward`` of the same shapes first); profiling brackets must be off."""
+        must be warm (one eager ``forward`` of the same shapes first); profiling brackets must be off.  The replay stays valid until the model's
+        weights, modes or capacities change or the motion branch retires the native handle of this geometry (SlowFastR50 keeps MAX_HANDLES
+        geometries alive): capture again after any of those (``enable_graph_replay`` tracks all of that by itself)."""
+        pv = forward_kwargs.get("pixel_values")
+        if torch.is_tensor(pv) and forward_kwargs.get("motion_feature") is None and forward_kwargs.get("input_ids") is not None:
+            self._prepare_motion_branch(pv, int(forward_kwargs["input_ids"].shape[0]))
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         self._capture_keep = []

@@ -12,6 +12,7 @@ from the checkpoint's state dict or a user-supplied file.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 from typing import Dict, Iterator, Optional, Tuple
 
@@ -24,10 +25,18 @@ FEATURE_DIM = 2304
 
 
 class SlowFastR50:
+    MAX_HANDLES = 4      # native handles kept alive, one per (device, T, H, W) geometry, least recently used first out
+
     def __init__(self, state_dict: Optional[Dict[str, torch.Tensor]] = None):
         self._sd: Dict[str, torch.Tensor] = {}
-        self._handle: Optional[int] = None
-        self._key: Optional[Tuple] = None
+        # A native handle owns the activation buffers of ONE geometry at a clip capacity.  A model that replays captured HIP graphs has the
+        # addresses of those buffers inside its graphs, so a handle must not die under them: handles are cached per geometry (a loop that
+        # alternates between frame counts keeps both alive), and ``epoch`` counts every destruction - InternVLChatModel compares it before
+        # it replays anything and drops its graphs when it moved (found by tests/manual/fuzz_batched.py: a replay through a destroyed
+        # handle's buffers was a GPU memory fault).
+        self._handles: "collections.OrderedDict[Tuple, Tuple[int, int]]" = collections.OrderedDict()      # geometry -> (handle, clip capacity)
+        self._handle: Optional[int] = None      # the handle of the last call
+        self.epoch = 0
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
@@ -62,10 +71,16 @@ class SlowFastR50:
         return self
 
     # ---- native handle ---------------------------------------------------------------------------------------------------
+    def _destroy(self, handle):
+        self.epoch += 1
+        native.release("aigv_slowfast_destroy", handle)      # (parked while a stream capture is underway: native.release)
+
     def _release(self):
-        if self._handle is not None:
-            native.release("aigv_slowfast_destroy", self._handle)      # (parked while a stream capture is underway: native.release)
-        self._handle, self._key = None, None
+        """Destroy every native handle (a weight reload, the end of the object)."""
+        for h, _cap in list(self._handles.values()):
+            self._destroy(h)
+        self._handles.clear()
+        self._handle = None
 
     def __del__(self):
         try:
@@ -73,15 +88,29 @@ class SlowFastR50:
         except Exception:
             pass
 
-    def _native(self, device: torch.device, clips: int, T: int, H: int, W: int):
+    def prepare(self, device: torch.device, clips: int, T: int, H: int, W: int):
+        """The native handle for ``clips`` clips of T frames of H x W on ``device``, created (weights uploaded) if there is none yet or the
+        cached one is too small.  Creating one allocates and copies synchronously: it cannot happen inside a stream capture, so a caller
+        that captures calls this first (InternVLChatModel does) - and compares ``epoch`` afterwards."""
         lib = native.load()
         dev = device.index if device.index is not None else torch.cuda.current_device()
-        k = self._key
-        if k is not None and k[0] == dev and k[1] >= clips and k[2:] == (T, H, W):
-            return lib, self._handle
-        self._release()
+        key = (dev, T, H, W)
+        ent = self._handles.get(key)
+        if ent is not None and ent[1] >= clips:
+            self._handles.move_to_end(key)
+            self._handle = ent[0]
+            return lib, ent[0]
+        if native._captures_underway > 0 or torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"SlowFastR50: no native handle for {clips} clips of {T} x {H} x {W} yet and one cannot be created inside a stream capture "
+                               "(call prepare() before capturing)")
         if not self._sd:
             raise RuntimeError("SlowFastR50 has no weights: load_state_dict() first")
+        if ent is not None:                                  # the same geometry at a larger clip count: the old handle goes
+            del self._handles[key]
+            self._destroy(ent[0])
+        while len(self._handles) >= self.MAX_HANDLES:
+            _k, (h_old, _cap) = self._handles.popitem(last=False)
+            self._destroy(h_old)
         h = C.c_void_p()
         native.check(lib.aigv_slowfast_create(dev, clips, T, H, W, C.byref(h)))
         try:
@@ -92,8 +121,12 @@ class SlowFastR50:
         except Exception:
             lib.aigv_slowfast_destroy(h)
             raise
-        self._handle, self._key = h, (dev, clips, T, H, W)
+        self._handles[key] = (h, clips)
+        self._handle = h
         return lib, h
+
+    def _native(self, device: torch.device, clips: int, T: int, H: int, W: int):
+        return self.prepare(device, clips, T, H, W)
 
     # ---- forward -----------------------------------------------------------------------------------------------------------
     def features(self, pixel_values: torch.Tensor, clips: int) -> torch.Tensor:

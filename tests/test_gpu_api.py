@@ -744,6 +744,58 @@ def test_graph_cache_keeps_captured_graphs_and_survives_a_failed_capture():
     assert all(torch.equal(s, eager[0][0]) and torch.equal(l, eager[0][1]) for s, l in again)
 
 
+def test_graph_replay_survives_the_motion_branch_retiring_a_native_handle():
+    """Round 6 (found by tests/manual/fuzz_batched.py as a GPU memory fault): a captured pass holds the addresses of the SlowFast handle's activation buffers.
+    The branch used to keep ONE native handle and re-create it whenever the clip geometry changed - a later replay of a pass captured on the old geometry then
+    wrote through freed memory.  Now SlowFastR50 keeps a handle per geometry (MAX_HANDLES, least recently used first out), counts destructions in ``epoch``, and the
+    model drops its graphs when the count has moved since they were captured.  Five frame counts against four cached handles: the first one's handle is retired
+    while its graph is still cached; its next pass must come out of a fresh eager run / capture with the eager bits."""
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    from aigv_assessor_amd.slowfast import SlowFastR50
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=2)
+    model = InternVLChatModel(cfg, max_clips=2)
+    model.load_state_dict(synth.make_state_dict(cfg, seed=97, rich=True))
+    model.eval().cuda()
+    sf = model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=3))
+    assert sf.MAX_HANDLES == 4
+    data = {}
+    for T in (8, 12, 16, 20, 24):
+        toks = synth.canonical_tokens(cfg, 2, T, seed=T)
+        model.img_context_token_id = toks["img_context_token_id"]
+        data[T] = dict(mos=None, pixel_values=synth.synthetic_frames(2 * T, 224, seed=T).cuda(), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+                       image_flags=torch.ones(2 * T, 1, dtype=torch.long), labels=toks["labels"])
+    want = {T: {k: v.clone() for k, v in model(**kw).items() if torch.is_tensor(v)} for T, kw in data.items()}      # eager
+    assert sf.epoch == 1 and len(sf._handles) == 4                          # five geometries: the first handle (T = 8) has been retired once already
+    same = lambda a, b: all(torch.equal(a[k], b[k]) for k in ("score1", "logit", "label"))
+    model.enable_graph_replay(True)
+    captured = lambda: sum(isinstance(v, tuple) for v in model._graphs.values())
+    for _ in range(3):
+        assert same(model(**data[8]), want[8])                              # eager ("seen"; re-creates the T = 8 handle: T = 12 goes), captured, replayed
+    assert captured() == 1
+    e0 = sf.epoch
+    for T in (12, 16, 20, 24):                                              # four other geometries, each retiring the least recently used handle: T = 8's goes last
+        assert same(model(**data[T]), want[T])
+    assert sf.epoch > e0
+    assert not any(k[1] == 8 for k in sf._handles)                          # (the handle the captured T = 8 pass launches through is gone)
+    # every graph entry point compares the destruction count first: no captured graph has survived (asserted BEFORE the pass that would replay one)
+    model._prepare_motion_branch(None, 0)
+    assert captured() == 0
+    for _ in range(3):
+        assert same(model(**data[8]), want[8])
+    assert captured() >= 1
+    # two models sharing one branch: the other model's geometry churn retires handles under this model's graphs - noticed the same way
+    other = InternVLChatModel(cfg, max_clips=2)
+    other.load_state_dict(synth.make_state_dict(cfg, seed=97, rich=True))
+    other.eval().cuda()
+    other.img_context_token_id = model.img_context_token_id
+    other.slowfast_model = sf
+    for T in (12, 16, 20, 24):
+        assert same(other(**data[T]), want[T])
+    assert not any(k[1] == 8 for k in sf._handles)
+    for _ in range(2):
+        assert same(model(**data[8]), want[8])
+
+
 def test_a_finalizer_firing_inside_a_capture_is_parked():
     """Round 6: a device-memory release inside a stream capture invalidates the capture, and on ROCm 7.2 that is the end of the process (scripts/capture_hipfree_probe.py).
     The host-side models die in Python's cyclic collector, i.e. at any moment: tests/capture_guard_child.py collects one in the middle of another model's captured pass."""
