@@ -154,7 +154,20 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor):
     node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
-_PARKED_GRAPHS: list = []      # captured passes that were dropped: kept alive until the interpreter exits (InternVLChatModel._drop_graphs)
+_PARKED_GRAPHS: list = []      # captured passes that were dropped: kept alive until the next SAFE moment to destroy them (_retire_parked_graphs)
+
+
+def _retire_parked_graphs(device=None) -> int:
+    """Destroy the parked graph objects NOW and hand their private memory pools back to the driver - called at moments that are known to be safe: no stream
+    capture underway (a release of device memory inside a capture kills it on this stack: scripts/capture_hipfree_probe.py), the device idle.  The
+    ``empty_cache`` matters: torch returns a destroyed graph's pool segments lazily (on an allocation retry) - which could be in the middle of a later capture."""
+    if not _PARKED_GRAPHS or native._captures_underway > 0 or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return 0
+    torch.cuda.synchronize(device)
+    n = len(_PARKED_GRAPHS)
+    _PARKED_GRAPHS.clear()
+    torch.cuda.empty_cache()
+    return n
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -744,18 +757,23 @@ class InternVLChatModel(nn.Module):
         self._graphs = {}
 
     def _drop_graphs(self):
-        """Forget every captured pass (a weight / mode / knob / capacity change made them stale).  The graph OBJECTS are not destroyed: they are parked in a
-        process-wide list until the interpreter exits.  On this stack (ROCm 7.2, torch 2.10) destroying a graph object - like any device-memory release - INSIDE a
-        stream capture kills that capture (the process aborts or can launch nothing any more: scripts/capture_hipfree_probe.py), and an object that is merely dropped
-        may be destroyed at any later moment by Python's cyclic collector, also in the middle of another capture.  native.capturing() keeps the collector off during
-        the captures this package starts; parking covers captures started by anyone else.  It costs the static buffers of the dropped graphs (tens of MB each at 8B
-        sizes) per drop; drops are rare."""
+        """Forget every captured pass (a weight / mode / knob / capacity change made them stale).  The graph OBJECTS are first parked in a process-wide list and
+        destroyed only at a safe moment (``_retire_parked_graphs``: right here when no stream capture is underway - the normal case -, else at the next drop).  On
+        this stack (ROCm 7.2, torch 2.10) destroying a graph object - like any device-memory release - INSIDE a stream capture kills that capture (the process
+        aborts or can launch nothing any more: scripts/capture_hipfree_probe.py), and an object that is merely dropped may be destroyed at any later moment by
+        Python's cyclic collector, also in the middle of another capture: so nothing here is ever left to the collector."""
         if getattr(self, "_graphs", None):
             held = [v for v in self._graphs.values() if isinstance(v, tuple)]
             if held and self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)      # (no replay in flight while the entries change hands)
             _PARKED_GRAPHS.extend(held)
             self._graphs = {}
+        if _PARKED_GRAPHS and self.device.type == "cuda":
+            _retire_parked_graphs(self.device)
+
+    def _branch_uid(self):
+        sf = self.slowfast_model
+        return None if sf is None else getattr(sf, "uid", None) or ("id", id(sf))
 
     def _prepare_motion_branch(self, frames, n_clips: int):
         """In front of every pass that may be captured or replayed with the native SlowFast branch inside: make the branch's native handle for
@@ -766,7 +784,7 @@ class InternVLChatModel(nn.Module):
             return
         if frames is not None and n_clips > 0 and frames.dim() == 4 and frames.shape[0] % n_clips == 0:
             sf.prepare(self.device, int(n_clips), int(frames.shape[0]) // int(n_clips), int(frames.shape[2]), int(frames.shape[3]))
-        seen = (id(sf), sf.epoch)
+        seen = (self._branch_uid(), sf.epoch)
         if getattr(self, "_sf_epoch", None) != seen:
             if getattr(self, "_sf_epoch", None) is not None and any(isinstance(v, tuple) for v in self.__dict__.get("_graphs", {}).values()):
                 self._drop_graphs()
@@ -848,7 +866,7 @@ class InternVLChatModel(nn.Module):
             return None
         host = lambda t: None if t is None else t.detach().to("cpu").contiguous()
         parts = [host(input_ids), host(attention_mask), host(labels), host(image_flags)]
-        host_key = ("forward", visual_tokens is not None, bool(full_logits), int(self.img_context_token_id), id(self.slowfast_model),
+        host_key = ("forward", visual_tokens is not None, bool(full_logits), int(self.img_context_token_id), self._branch_uid(),
                     bool(getattr(self, "overlap_motion_branch", True)), bool(getattr(self, "drop_dead_tail", True)),
                     tuple(None if t is None else (tuple(t.shape), t.dtype, t.numpy().tobytes()) for t in parts))
         self._join_side_stream()             # (a motion feature started by motion_feature_async: joined BEFORE the graph copies it in)
@@ -875,7 +893,7 @@ class InternVLChatModel(nn.Module):
         if (self._graph_replay_enabled and self._capture_keep is None and frames_local.is_cuda and not self._dirty and self._ctx is not None
                 and not getattr(self, "_prof_on", False) and (frames_clips is None or (frames_clips.is_cuda and hasattr(self.slowfast_model, "features")))):
             self._prepare_motion_branch(frames_clips, int(n_clips))
-            out = self._graph_call(("dp_front", int(n_clips), id(self.slowfast_model), bool(getattr(self, "overlap_motion_branch", True))),
+            out = self._graph_call(("dp_front", int(n_clips), self._branch_uid(), bool(getattr(self, "overlap_motion_branch", True))),
                                    [frames_local, frames_clips], fn, clone_outputs=False)
             if out is not None:
                 return out

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import itertools
 from typing import Dict, Iterator, Optional, Tuple
 
 import torch
@@ -22,6 +23,9 @@ from . import native
 
 PREFIX = "slowfast_model.feature_extraction."
 FEATURE_DIM = 2304
+
+
+_UIDS = itertools.count(1)
 
 
 class SlowFastR50:
@@ -37,6 +41,7 @@ class SlowFastR50:
         self._handles: "collections.OrderedDict[Tuple, Tuple[int, int]]" = collections.OrderedDict()      # geometry -> (handle, clip capacity)
         self._handle: Optional[int] = None      # the handle of the last call
         self.epoch = 0
+        self.uid = next(_UIDS)                  # what graph caches key on (id() of a dead object can come back with the next one)
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
