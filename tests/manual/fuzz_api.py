@@ -1,0 +1,178 @@
+"""Randomised differential run of the model's API under graph replay (tiny model, one MI355X): a device-under-test with `enable_graph_replay()` on and whatever state the
+operations before left behind (captured graphs, grown contexts, cached SlowFast handles, a prefetch in flight) against a FRESH eager model per operation.  Operations:
+forward at 1-4 clips x 8 / 12 / 16 frames (SlowFast inside or a given motion feature; stage 2), the four-perspective shared-prefix pass, generate() at 1-3 sequences,
+the look-ahead loop, eval_utils.batched, score_clips_dp on one rank, frame ingest at several decoded sizes, and mode toggles (precision bf16 / fp8, attention numerics, row
+trimming, GEMM mode) applied to both sides.  Every result must equal the fresh model's bit for bit.  (Parity with the reference is other tests' business: this one hunts state.)
+
+    python tests/manual/fuzz_api.py [n_ops = 150] [seed = 0]"""
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import aigv_assessor_amd as pkg  # noqa: E402
+from aigv_assessor_amd import dist_utils, eval_utils, synth  # noqa: E402
+from aigv_assessor_amd.modeling import InternVLChatModel  # noqa: E402
+from aigv_assessor_amd.slowfast import SlowFastR50  # noqa: E402
+
+n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+cfg = pkg.tiny(image_size=224, vit_layers=2, llm_layers=2)
+S = cfg.image_size
+dev = torch.device("cuda", 0)
+sd = synth.make_state_dict(cfg, seed=5, rich=True)
+sf_sd = synth.slowfast_state_dict(seed=3)
+modes = dict(precision="bf16", numerics="fp32", trim=True, gemm=-1)
+
+
+def make(graph):
+    m = InternVLChatModel(cfg, device=dev, max_clips=1)
+    m.load_state_dict(sd)
+    m.eval()
+    m.slowfast_model = SlowFastR50(sf_sd)
+    apply_modes(m)
+    m.enable_graph_replay(graph)
+    return m
+
+
+def apply_modes(m):
+    m.set_precision(modes["precision"])
+    m.set_attention_numerics(modes["numerics"])
+    m.set_row_trimming(modes["trim"])
+    m.set_gemm_mode(modes["gemm"])
+
+
+dut = make(True)
+rng = random.Random(seed0)
+g = torch.Generator().manual_seed(seed0)
+bad, counts = 0, {}
+
+
+def same(a, b):
+    if torch.is_tensor(a):
+        return torch.is_tensor(b) and a.shape == b.shape and torch.equal(a.detach().cpu(), b.detach().cpu())
+    if isinstance(a, dict):
+        return all(same(a[k], b[k]) for k in a if torch.is_tensor(a[k]))
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+    return a == b
+
+
+def inputs(B, T, seed, branch, extra=0):
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    ids, lab = toks["input_ids"], toks["labels"]
+    if extra:
+        a0 = int((lab[0] != -100).nonzero()[0])
+        fill = torch.randint(3, cfg.llm_config.vocab_size - 16, (B, extra), generator=torch.Generator().manual_seed(seed))
+        ids = torch.cat([ids[:, :a0], fill, ids[:, a0:]], 1)
+        lab = torch.cat([lab[:, :a0], torch.full((B, extra), -100), lab[:, a0:]], 1)
+    kw = dict(mos=None, pixel_values=synth.synthetic_frames(B * T, S, seed=seed).to(dev), input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool),
+              image_flags=torch.ones(B * T, 1, dtype=torch.long), labels=lab)
+    if not branch:
+        kw["motion_feature"] = synth.synthetic_motion(B, cfg.motion_dim, seed=seed).to(dev)
+    return kw, toks["img_context_token_id"]
+
+
+def op_forward(m, B, T, seed, branch, extra):
+    kw, ctx = inputs(B, T, seed, branch, extra)
+    m.img_context_token_id = ctx
+    return m(**kw)
+
+
+def op_prefix(m, B, T, seed):
+    base = synth.canonical_tokens(cfg, B, T, seed=seed)
+    m.img_context_token_id = base["img_context_token_id"]
+    prompts = [(p["input_ids"], p["attention_mask"], p["labels"]) for p in synth.perspective_prompts(base, 4, seed=seed)]
+    outs = m.forward_shared_prefix(prompts, pixel_values=synth.synthetic_frames(B * T, S, seed=seed).to(dev), image_flags=torch.ones(B * T, 1, dtype=torch.long))
+    return [{k: v for k, v in o.items() if torch.is_tensor(v)} for o in outs]
+
+
+def op_generate(m, B, T, n_new, seed):
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    ctx = toks["img_context_token_id"]
+    m.img_context_token_id = ctx
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    ids = toks["input_ids"][:, :n_prompt].clone()
+    for b in range(B):
+        ids[b, (ids[b] == ctx).nonzero()[-1]] = 7
+    return m.generate(pixel_values=synth.synthetic_frames(B * T, S, seed=seed).to(dev), input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=n_new, do_sample=False)
+
+
+def loop_items(n, T, hw, seed):
+    gg = torch.Generator().manual_seed(seed)
+    items, ctx = [], None
+    for i in range(n):
+        toks = synth.canonical_tokens(cfg, 1, T, seed=seed + i)
+        ctx = toks["img_context_token_id"]
+        items.append({"input_ids": toks["input_ids"], "labels": toks["labels"], "attention_mask": toks["attention_mask"], "image_flags": torch.ones(1, T, 1, dtype=torch.long),
+                      "frames": torch.randint(0, 256, (T,) + hw + (3,), dtype=torch.uint8, generator=gg).pin_memory()})
+    return items, ctx
+
+
+def op_batched(m, n, T, hw, k, ahead, seed):
+    items, ctx = loop_items(n, T, hw, seed)
+    m.img_context_token_id = ctx
+    return [o for _, o in eval_utils.batched(items, m, k=k, ahead=ahead, frames=lambda it: it["frames"])]
+
+
+def op_lookahead(m, n, T, hw, seed):
+    items, ctx = loop_items(n, T, hw, seed)
+    m.img_context_token_id = ctx
+    outs = []
+    for it, ahead in eval_utils.lookahead(items, m, frames=lambda it: it["frames"]):
+        o = m(mos=None, pixel_values=ahead, input_ids=it["input_ids"], attention_mask=it["attention_mask"], image_flags=it["image_flags"][0], labels=it["labels"])
+        outs.append({k: v.clone() for k, v in o.items() if torch.is_tensor(v)})
+    return outs
+
+
+def op_dp(m, B, T, seed, branch):
+    kw, ctx = inputs(B, T, seed, branch)
+    m.img_context_token_id = ctx
+    return dist_utils.score_clips_dp(m, kw["pixel_values"], kw["input_ids"], kw["attention_mask"], kw["image_flags"], kw["labels"], kw.get("motion_feature"))
+
+
+def op_ingest(m, T, hw, seed):
+    gg = torch.Generator().manual_seed(seed)
+    return m.ingest_frames(torch.randint(0, 256, (T,) + hw + (3,), dtype=torch.uint8, generator=gg).to(dev))
+
+
+for it in range(n_ops):
+    r = rng.random()
+    T = rng.choice([8, 8, 12, 16])
+    if r < 0.30:
+        name, fn = "forward", (lambda m, a=(rng.randint(1, 4), T, rng.randint(0, 3), rng.random() < 0.6, rng.choice([0, 0, 2])): op_forward(m, *a))
+    elif r < 0.40:
+        name, fn = "prefix", (lambda m, a=(rng.randint(1, 2), T, rng.randint(0, 2)): op_prefix(m, *a))
+    elif r < 0.52:
+        name, fn = "generate", (lambda m, a=(rng.randint(1, 3), 8, rng.randint(2, 6), rng.randint(0, 2)): op_generate(m, *a))
+    elif r < 0.66:
+        name, fn = "batched", (lambda m, a=(rng.randint(1, 7), T, rng.choice([(240, 320), (300, 400), (224, 224)]), rng.randint(1, 4), rng.random() < 0.7, rng.randint(0, 2)): op_batched(m, *a))
+    elif r < 0.74:
+        name, fn = "lookahead", (lambda m, a=(rng.randint(1, 4), T, rng.choice([(240, 320), (300, 400)]), rng.randint(0, 2)): op_lookahead(m, *a))
+    elif r < 0.84:
+        name, fn = "dp", (lambda m, a=(rng.randint(1, 4), T, rng.randint(0, 3), rng.random() < 0.6): op_dp(m, *a))
+    elif r < 0.90:
+        name, fn = "ingest", (lambda m, a=(rng.choice([4, 8]), rng.choice([(240, 320), (360, 640), (224, 224)]), rng.randint(0, 3)): op_ingest(m, *a))
+    else:
+        which = rng.choice(["precision", "numerics", "trim", "gemm"])
+        modes[which] = {"precision": rng.choice(["bf16", "fp8"]), "numerics": rng.choice(["fp32", "reference"]), "trim": rng.random() < 0.7, "gemm": rng.choice([-1, -1, 2])}[which]
+        apply_modes(dut)
+        counts["toggle"] = counts.get("toggle", 0) + 1
+        continue
+    counts[name] = counts.get(name, 0) + 1
+    ref = make(False)
+    want = fn(ref)
+    reps = 3 if name in ("forward", "dp") else 1          # (repeat: eager -> captured -> replayed)
+    for rep in range(reps):
+        got = fn(dut)
+        if not same(want, got):
+            bad += 1
+            print(f"MISMATCH op {it} {name} rep {rep} modes {modes}", flush=True)
+    del ref, want, got
+    if it % 25 == 24:
+        print(f"op {it + 1}/{n_ops}: {counts}; mismatches {bad}; captured graphs {sum(isinstance(v, tuple) for v in dut._graphs.values())}", flush=True)
+assert bad == 0, bad
+print(f"FUZZ_API_OK {n_ops} ops {counts}")
