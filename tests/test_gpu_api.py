@@ -744,6 +744,17 @@ def test_graph_cache_keeps_captured_graphs_and_survives_a_failed_capture():
     assert all(torch.equal(s, eager[0][0]) and torch.equal(l, eager[0][1]) for s, l in again)
 
 
+def test_batched_loop_randomised_against_the_plain_loop():
+    """Twelve rounds of tests/manual/fuzz_batched.py (seeded): random item streams (frame counts 2-16, decoded sizes, ragged prompts, uint8 frames or pixel_values, with /
+    without mos) and loop settings (k = 1-6, look-ahead, graph replay, contexts that grow, both stages, native SlowFast or a given motion feature); every yielded result equals
+    the plain one-clip-per-call loop's bit for bit.  (A child process: the script is a manual tool first; ~10 s.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "manual", "fuzz_batched.py"), "12", "0"], capture_output=True, text=True, timeout=600, cwd=root)
+    print(r.stdout[-500:], r.stderr[-1500:])
+    assert r.returncode == 0 and "FUZZ_OK 12 rounds" in r.stdout, r.stderr[-2000:]
+
+
 def test_graph_replay_survives_the_motion_branch_retiring_a_native_handle():
     """Round 6 (found by tests/manual/fuzz_batched.py as a GPU memory fault): a captured pass holds the addresses of the SlowFast handle's activation buffers.
     The branch used to keep ONE native handle and re-create it whenever the clip geometry changed - a later replay of a pass captured on the old geometry then
