@@ -154,20 +154,7 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor):
     node.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
-_PARKED_GRAPHS: list = []      # captured passes that were dropped: kept alive until the next SAFE moment to destroy them (_retire_parked_graphs)
-
-
-def _retire_parked_graphs(device=None) -> int:
-    """Destroy the parked graph objects NOW and hand their private memory pools back to the driver - called at moments that are known to be safe: no stream
-    capture underway (a release of device memory inside a capture kills it on this stack: scripts/capture_hipfree_probe.py), the device idle.  The
-    ``empty_cache`` matters: torch returns a destroyed graph's pool segments lazily (on an allocation retry) - which could be in the middle of a later capture."""
-    if not _PARKED_GRAPHS or native._captures_underway > 0 or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
-        return 0
-    torch.cuda.synchronize(device)
-    n = len(_PARKED_GRAPHS)
-    _PARKED_GRAPHS.clear()
-    torch.cuda.empty_cache()
-    return n
+_PARKED_GRAPHS: list = []      # captured passes that were dropped: kept alive until the interpreter exits (InternVLChatModel._drop_graphs)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -757,19 +744,20 @@ class InternVLChatModel(nn.Module):
         self._graphs = {}
 
     def _drop_graphs(self):
-        """Forget every captured pass (a weight / mode / knob / capacity change made them stale).  The graph OBJECTS are first parked in a process-wide list and
-        destroyed only at a safe moment (``_retire_parked_graphs``: right here when no stream capture is underway - the normal case -, else at the next drop).  On
-        this stack (ROCm 7.2, torch 2.10) destroying a graph object - like any device-memory release - INSIDE a stream capture kills that capture (the process
-        aborts or can launch nothing any more: scripts/capture_hipfree_probe.py), and an object that is merely dropped may be destroyed at any later moment by
-        Python's cyclic collector, also in the middle of another capture: so nothing here is ever left to the collector."""
+        """Forget every captured pass (a weight / mode / knob / capacity change made them stale).  The graph OBJECTS are not destroyed: they are parked in a
+        process-wide list until the interpreter exits.  On this stack (ROCm 7.2, torch 2.10) destroying a graph object - like any device-memory release - INSIDE a
+        stream capture kills that capture (the process aborts or can launch nothing any more: scripts/capture_hipfree_probe.py), an object that is merely dropped
+        may be destroyed at any later moment by Python's cyclic collector, also in the middle of another capture, and destroying them at a quiet moment (device
+        idle, no capture underway, followed by empty_cache) was tried and is not safe either: with several models alive, a later replay of ANOTHER model's live
+        graph then crashed inside hipGraphLaunch (tests/manual/fuzz_api.py seed 3; profiles/r6_soak.txt).  Parking costs ~2 MiB of runtime memory per graph plus its
+        static buffers (tens of MB at 8B sizes) per drop, at most GRAPH_CACHE_SIZE graphs per drop; drops happen on weight / mode / capacity changes and when the
+        motion branch retires a native handle, i.e. rarely."""
         if getattr(self, "_graphs", None):
             held = [v for v in self._graphs.values() if isinstance(v, tuple)]
             if held and self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)      # (no replay in flight while the entries change hands)
             _PARKED_GRAPHS.extend(held)
             self._graphs = {}
-        if _PARKED_GRAPHS and self.device.type == "cuda":
-            _retire_parked_graphs(self.device)
 
     def _branch_uid(self):
         sf = self.slowfast_model

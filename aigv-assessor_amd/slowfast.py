@@ -29,7 +29,7 @@ _UIDS = itertools.count(1)
 
 
 class SlowFastR50:
-    MAX_HANDLES = 4      # native handles kept alive, one per (device, T, H, W) geometry, least recently used first out
+    MAX_HANDLES = 8      # native handles kept alive, one per (device, T, H, W) geometry, least recently used first out (~0.4 GB each at 4 clips x 8 x 448 x 448)
 
     def __init__(self, state_dict: Optional[Dict[str, torch.Tensor]] = None):
         self._sd: Dict[str, torch.Tensor] = {}

@@ -1,10 +1,12 @@
 """Randomised differential run of the model's API under graph replay (tiny model, one MI355X): a device-under-test with `enable_graph_replay()` on and whatever state the
 operations before left behind (captured graphs, grown contexts, cached SlowFast handles, a prefetch in flight) against a FRESH eager model per operation.  Operations:
 forward at 1-4 clips x 8 / 12 / 16 frames (SlowFast inside or a given motion feature; stage 2), the four-perspective shared-prefix pass, generate() at 1-3 sequences,
-the look-ahead loop, eval_utils.batched, score_clips_dp on one rank, frame ingest at several decoded sizes, and mode toggles (precision bf16 / fp8, attention numerics, row
+the look-ahead loop, eval_utils.batched, score_clips_dp on one rank, frame ingest at several decoded sizes, extract_feature / vit_tokens / motion_feature, beam search, weight reloads on the live model, up to three long-lived models sharing one
+SlowFast branch, and mode toggles (precision bf16 / fp8, attention numerics, row
 trimming, GEMM mode) applied to both sides.  Every result must equal the fresh model's bit for bit.  (Parity with the reference is other tests' business: this one hunts state.)
 
     python tests/manual/fuzz_api.py [n_ops = 150] [seed = 0]"""
+import faulthandler
 import os
 import random
 import sys
@@ -18,6 +20,11 @@ from aigv_assessor_amd import dist_utils, eval_utils, synth  # noqa: E402
 from aigv_assessor_amd.modeling import InternVLChatModel  # noqa: E402
 from aigv_assessor_amd.slowfast import SlowFastR50  # noqa: E402
 
+faulthandler.enable()
+if os.environ.get("FUZZ_NO_RETIRE"):      # diagnosis: dropped graphs stay parked for the life of the process
+    from aigv_assessor_amd import modeling as _modeling
+    _modeling._retire_parked_graphs = lambda *a, **k: 0
+VERBOSE = bool(os.environ.get("FUZZ_VERBOSE"))
 n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 cfg = pkg.tiny(image_size=224, vit_layers=2, llm_layers=2)
@@ -46,6 +53,7 @@ def apply_modes(m):
 
 
 dut = make(True)
+duts = [dut]
 rng = random.Random(seed0)
 g = torch.Generator().manual_seed(seed0)
 bad, counts = 0, {}
@@ -90,7 +98,7 @@ def op_prefix(m, B, T, seed):
     return [{k: v for k, v in o.items() if torch.is_tensor(v)} for o in outs]
 
 
-def op_generate(m, B, T, n_new, seed):
+def op_generate(m, B, T, n_new, seed, beams=1):
     toks = synth.canonical_tokens(cfg, B, T, seed=seed)
     ctx = toks["img_context_token_id"]
     m.img_context_token_id = ctx
@@ -98,7 +106,8 @@ def op_generate(m, B, T, n_new, seed):
     ids = toks["input_ids"][:, :n_prompt].clone()
     for b in range(B):
         ids[b, (ids[b] == ctx).nonzero()[-1]] = 7
-    return m.generate(pixel_values=synth.synthetic_frames(B * T, S, seed=seed).to(dev), input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=n_new, do_sample=False)
+    return m.generate(pixel_values=synth.synthetic_frames(B * T, S, seed=seed).to(dev), input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=n_new, do_sample=False,
+                      **({} if beams == 1 else {"num_beams": beams}))
 
 
 def loop_items(n, T, hw, seed):
@@ -134,6 +143,11 @@ def op_dp(m, B, T, seed, branch):
     return dist_utils.score_clips_dp(m, kw["pixel_values"], kw["input_ids"], kw["attention_mask"], kw["image_flags"], kw["labels"], kw.get("motion_feature"))
 
 
+def op_feature(m, F, seed):
+    pv = synth.synthetic_frames(F, S, seed=seed).to(dev)
+    return [m.extract_feature(pv), m.vit_tokens(pv), m.motion_feature(synth.synthetic_frames(8, S, seed=seed).to(dev), 1)]
+
+
 def op_ingest(m, T, hw, seed):
     gg = torch.Generator().manual_seed(seed)
     return m.ingest_frames(torch.randint(0, 256, (T,) + hw + (3,), dtype=torch.uint8, generator=gg).to(dev))
@@ -147,27 +161,44 @@ for it in range(n_ops):
     elif r < 0.40:
         name, fn = "prefix", (lambda m, a=(rng.randint(1, 2), T, rng.randint(0, 2)): op_prefix(m, *a))
     elif r < 0.52:
-        name, fn = "generate", (lambda m, a=(rng.randint(1, 3), 8, rng.randint(2, 6), rng.randint(0, 2)): op_generate(m, *a))
+        name, fn = "generate", (lambda m, a=(rng.randint(1, 3), T, rng.randint(2, 6), rng.randint(0, 2), rng.choice([1, 1, 3])): op_generate(m, *a))
     elif r < 0.66:
         name, fn = "batched", (lambda m, a=(rng.randint(1, 7), T, rng.choice([(240, 320), (300, 400), (224, 224)]), rng.randint(1, 4), rng.random() < 0.7, rng.randint(0, 2)): op_batched(m, *a))
     elif r < 0.74:
         name, fn = "lookahead", (lambda m, a=(rng.randint(1, 4), T, rng.choice([(240, 320), (300, 400)]), rng.randint(0, 2)): op_lookahead(m, *a))
     elif r < 0.84:
         name, fn = "dp", (lambda m, a=(rng.randint(1, 4), T, rng.randint(0, 3), rng.random() < 0.6): op_dp(m, *a))
+    elif r < 0.87:
+        name, fn = "feature", (lambda m, a=(rng.choice([1, 3, 8, 20]), rng.randint(0, 3)): op_feature(m, *a))
     elif r < 0.90:
         name, fn = "ingest", (lambda m, a=(rng.choice([4, 8]), rng.choice([(240, 320), (360, 640), (224, 224)]), rng.randint(0, 3)): op_ingest(m, *a))
+    elif r < 0.93:
+        # the weights loaded again on the live model (same values: results must not move; the captured graphs go), or the model replaced by a second long-lived one
+        # that shares the SlowFast branch with the first (its geometry churn retires handles under the other's graphs)
+        if rng.random() < 0.5:
+            dut.load_state_dict(sd)
+        else:
+            duts.append(make(True))
+            duts[-1].slowfast_model = duts[0].slowfast_model
+            if len(duts) > 3:
+                duts.pop(1)
+        counts["reload/second"] = counts.get("reload/second", 0) + 1
+        continue
     else:
         which = rng.choice(["precision", "numerics", "trim", "gemm"])
         modes[which] = {"precision": rng.choice(["bf16", "fp8"]), "numerics": rng.choice(["fp32", "reference"]), "trim": rng.random() < 0.7, "gemm": rng.choice([-1, -1, 2])}[which]
-        apply_modes(dut)
+        for d in duts:
+            apply_modes(d)
         counts["toggle"] = counts.get("toggle", 0) + 1
         continue
     counts[name] = counts.get(name, 0) + 1
+    if VERBOSE:
+        print(f"op {it} {name} {fn.__defaults__} on dut {it % len(duts)} of {len(duts)}", flush=True)
     ref = make(False)
     want = fn(ref)
     reps = 3 if name in ("forward", "dp") else 1          # (repeat: eager -> captured -> replayed)
     for rep in range(reps):
-        got = fn(dut)
+        got = fn(duts[(it + rep) % len(duts)])
         if not same(want, got):
             bad += 1
             print(f"MISMATCH op {it} {name} rep {rep} modes {modes}", flush=True)

@@ -759,7 +759,7 @@ def test_graph_replay_survives_the_motion_branch_retiring_a_native_handle():
     """Round 6 (found by tests/manual/fuzz_batched.py as a GPU memory fault): a captured pass holds the addresses of the SlowFast handle's activation buffers.
     The branch used to keep ONE native handle and re-create it whenever the clip geometry changed - a later replay of a pass captured on the old geometry then
     wrote through freed memory.  Now SlowFastR50 keeps a handle per geometry (MAX_HANDLES, least recently used first out), counts destructions in ``epoch``, and the
-    model drops its graphs when the count has moved since they were captured.  Five frame counts against four cached handles: the first one's handle is retired
+    model drops its graphs when the count has moved since they were captured.  Five frame counts against (here) four cached handles: the first one's handle is retired
     while its graph is still cached; its next pass must come out of a fresh eager run / capture with the eager bits."""
     from aigv_assessor_amd.modeling import InternVLChatModel
     from aigv_assessor_amd.slowfast import SlowFastR50
@@ -768,7 +768,7 @@ def test_graph_replay_survives_the_motion_branch_retiring_a_native_handle():
     model.load_state_dict(synth.make_state_dict(cfg, seed=97, rich=True))
     model.eval().cuda()
     sf = model.slowfast_model = SlowFastR50(synth.slowfast_state_dict(seed=3))
-    assert sf.MAX_HANDLES == 4
+    sf.MAX_HANDLES = 4                                                      # (the class default is 8)
     data = {}
     for T in (8, 12, 16, 20, 24):
         toks = synth.canonical_tokens(cfg, 2, T, seed=T)
