@@ -749,8 +749,8 @@ class InternVLChatModel(nn.Module):
         stream capture kills that capture (the process aborts or can launch nothing any more: scripts/capture_hipfree_probe.py), an object that is merely dropped
         may be destroyed at any later moment by Python's cyclic collector, also in the middle of another capture, and destroying them at a quiet moment (device
         idle, no capture underway, followed by empty_cache) was tried and is not safe either: with several models alive, a later replay of ANOTHER model's live
-        graph then crashed inside hipGraphLaunch (tests/manual/fuzz_api.py seed 3; profiles/r6_soak.txt).  Parking costs ~2 MiB of runtime memory per graph plus its
-        static buffers (tens of MB at 8B sizes) per drop, at most GRAPH_CACHE_SIZE graphs per drop; drops happen on weight / mode / capacity changes and when the
+        graph then crashed inside hipGraphLaunch (tests/manual/fuzz_api.py seed 3; profiles/r6_soak.txt).  Parking costs the graph's private pool and static copies
+        (~95 MB per captured 4-clip pass at 8B sizes) plus ~1.5 MiB of runtime memory, at most GRAPH_CACHE_SIZE graphs per drop; drops happen on weight / mode / capacity changes and when the
         motion branch retires a native handle, i.e. rarely."""
         if getattr(self, "_graphs", None):
             held = [v for v in self._graphs.values() if isinstance(v, tuple)]
