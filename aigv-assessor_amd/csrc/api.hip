@@ -2116,6 +2116,11 @@ int aigv_op_frame_resize_ingest(const void* hwc_u8, int n_frames, int in_h, int 
     return fail(nullptr, AIGV_ERR_ARG, "aigv_op_frame_resize_ingest: bad argument (frames %d, %dx%d -> %dx%d)", n_frames, in_h, in_w, out_h, out_w);
   if (in_h > 16384 || in_w > 16384 || out_h > 16384 || out_w > 16384)
     return fail(nullptr, AIGV_ERR_ARG, "aigv_op_frame_resize_ingest: sizes above 16384 are not supported");
+  // Pillow (12.2, observed against the live package: tests/manual/fuzz_resize.py) runs the VERTICAL pass first for frames more than 100 times taller than wide
+  // that shrink vertically - the intermediate uint8 image, and so the result, differs from the horizontal-first order implemented here.  Not a video
+  // geometry: refused rather than answered differently from Pillow.
+  if (in_w != out_w && in_h != out_h && in_h > out_h && (long)in_h > 100L * in_w)
+    return fail(nullptr, AIGV_ERR_ARG, "aigv_op_frame_resize_ingest: %dx%d frames (more than 100 times taller than wide) are not supported: Pillow orders its passes differently there", in_h, in_w);
   HIPCHK(nullptr, aigv_launch_frame_resize_ingest((const uint8_t*)hwc_u8, n_frames, in_h, in_w, out_h, out_w, mean, stdv,
                                                   (uint8_t*)tmp_u8, (uint8_t*)out_u8_hwc, (bf16_t*)out_nchw, (hipStream_t)stream));
   return 0;

@@ -873,6 +873,12 @@ def test_frame_resize_rejects_bad_arguments(lib):
     assert lib.aigv_op_frame_resize_ingest(t.data_ptr(), 1, 2, 2, 2, 2, None, None, t.data_ptr(), None, None, None) != 0   # no output
     assert lib.aigv_op_frame_resize_ingest(t.data_ptr(), 1, 0, 2, 2, 2, None, None, t.data_ptr(), t.data_ptr(), None, None) != 0
     assert lib.aigv_op_frame_resize_ingest(t.data_ptr(), 1, 2, 2, 2, 2, None, None, t.data_ptr(), None, t.data_ptr(), None) != 0   # nchw needs mean/std
+    # frames more than 100 times taller than wide that shrink vertically: Pillow runs its vertical pass first there (tests/manual/fuzz_resize.py) - refused
+    src, tmp, out = (torch.zeros(n, dtype=torch.uint8, device="cuda") for n in (3 * 801 * 8, 3 * 801 * 448, 3 * 448 * 448))
+    assert lib.aigv_op_frame_resize_ingest(src.data_ptr(), 1, 801, 8, 448, 448, None, None, tmp.data_ptr(), out.data_ptr(), None, None) != 0
+    assert b"100 times taller" in lib.aigv_last_error(None)
+    assert lib.aigv_op_frame_resize_ingest(src.data_ptr(), 1, 800, 8, 448, 448, None, None, tmp.data_ptr(), out.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
 
 
 # ---------------------------------------------------------------------------------------------------------
