@@ -873,6 +873,8 @@ int aigv_ctx_create(int device, const aigv_config* cfg, aigv_ctx** out) {
   if (k.llm_hidden <= 0 || k.llm_heads <= 0 || k.llm_hidden % k.llm_heads || k.llm_hidden / k.llm_heads != 128)
     return fail(nullptr, AIGV_ERR_ARG, "LLM head_dim must be 128");
   if (k.llm_kv_heads <= 0 || k.llm_heads % k.llm_kv_heads) return fail(nullptr, AIGV_ERR_ARG, "bad GQA split");
+  if (k.llm_heads / k.llm_kv_heads > 8)   // the decode attention is instantiated for 1..8 query heads per KV head (InternLM2-8B: 4, -20B: 6): say so here, not at the first decode step
+    return fail(nullptr, AIGV_ERR_ARG, "GQA groups of more than 8 query heads per KV head are not supported (%d / %d)", k.llm_heads, k.llm_kv_heads);
   if (k.vit_hidden % 128 || k.vit_inter % 128 || k.llm_hidden % 128 || k.llm_inter % 128)
     return fail(nullptr, AIGV_ERR_ARG, "hidden/intermediate sizes must be multiples of 128");
   if (k.image_size % k.patch_size || k.shuffle != 2 || ((k.image_size / k.patch_size) % 2))

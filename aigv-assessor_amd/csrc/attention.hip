@@ -850,8 +850,11 @@ hipError_t aigv_launch_attention_decode(const bf16_t* q, int ldq, int q_group_st
   switch (g) {
     case 1: DEC(1); break;
     case 2: DEC(2); break;
+    case 3: DEC(3); break;
     case 4: DEC(4); break;
+    case 5: DEC(5); break;
     case 6: DEC(6); break;
+    case 7: DEC(7); break;
     case 8: DEC(8); break;
     default: return hipErrorInvalidValue;
   }

@@ -60,7 +60,7 @@ typedef struct aigv_config {
   int32_t select_layer;      /* -1 = last (modeling_internvl_chat.py:509-518) */
   int32_t shuffle;           /* 1/downsample_ratio (2) */
   /* InternLM2 */
-  int32_t llm_hidden, llm_inter, llm_heads, llm_kv_heads, llm_layers, vocab;
+  int32_t llm_hidden, llm_inter, llm_heads, llm_kv_heads, llm_layers, vocab;   /* head width 128; 1..8 query heads per KV head (8B: 4, 20B: 6); widths multiples of 128 */
   float rms_eps;
   int32_t max_positions;     /* rows of the RoPE tables the host uploads */
   /* heads */

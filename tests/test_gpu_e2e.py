@@ -525,6 +525,40 @@ def test_greedy_generate_matches_oracle_cache_path():
     assert torch.equal(got2.cpu(), want)
 
 
+@pytest.mark.parametrize("heads,kv", [(6, 2), (5, 1), (7, 1)])
+def test_greedy_generate_with_odd_gqa_groups(heads, kv):
+    """Round 6 (tests/manual/fuzz_generate.py): the decode attention was instantiated for 1 / 2 / 4 / 6 / 8 query heads per KV head only - a
+    configuration with 3 (or 5, 7) scored fine (the prefill kernel takes any group) and failed with 'invalid argument' at its first decode step.
+    Now 1..8 are built (more are refused when the context is created).  Teacher-forced against the oracle's cache path: every generated token is
+    the oracle's argmax at its step or within 2 bf16 ulps of it."""
+    cfg = pkg.tiny(image_size=224, llm_hidden=128 * heads, llm_heads=heads, llm_kv_heads=kv, llm_layers=2, llm_inter=512)
+    seed, B, T, n_new = 40 + heads, 3, 2, 5
+    sd = synth.make_state_dict(cfg, seed=seed, rich=True)
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    n_prompt = int((toks["labels"][0] == -100).sum())
+    ids = toks["input_ids"][:, :n_prompt].clone()
+    ctx = toks["img_context_token_id"]
+    for b in range(B):
+        ids[b, (ids[b] == ctx).nonzero()[-1]] = 7
+    pv = synth.synthetic_frames(B * T, 224, seed=seed)
+    model = make_model(cfg, sd)
+    model.img_context_token_id = ctx
+    got = model.generate(pixel_values=pv, input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=n_new, do_sample=False).cpu()
+    emb = O.scatter_embeds(sd, ids, ctx, O.extract_feature(sd, cfg, pv), None)
+    exact, gaps = _teacher_forced_gaps(sd, cfg, emb, torch.ones_like(ids), got)
+    print(f"GQA group {heads // kv}: {exact}/{B * n_new} tokens are the oracle's argmax, gaps {gaps}")
+    assert got.shape == (B, n_new) and all(x <= 2 for x in gaps) and exact >= B * n_new - 3, gaps
+    if heads == 7:          # more than 8 query heads per KV head: refused when the context is created, with a message that says why
+        from aigv_assessor_amd import native
+        big = pkg.tiny(image_size=224, llm_hidden=128 * 9, llm_heads=9, llm_kv_heads=1, llm_layers=1, llm_inter=256)
+        m9 = make_model(big, synth.make_state_dict(big, seed=1, rich=True))
+        m9.img_context_token_id = ctx
+        t9 = synth.canonical_tokens(big, 1, 1, seed=1)
+        with pytest.raises(native.NativeError, match="GQA groups of more than 8"):
+            m9(mos=None, pixel_values=synth.synthetic_frames(1, 224, seed=1), input_ids=t9["input_ids"], attention_mask=t9["attention_mask"],
+               image_flags=torch.ones(1, 1, dtype=torch.long), labels=t9["labels"], motion_feature=synth.synthetic_motion(1, big.motion_dim, seed=1))
+
+
 @pytest.mark.parametrize("B,T", [(6, 1), (20, 1)])
 def test_greedy_generate_with_many_sequences(B, T):
     """Decode steps with more sequences than the small-batch forms take (<= 4: fused-norm / 4-row forms, <= 8: 8-row forms, <= 16: one
