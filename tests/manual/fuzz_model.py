@@ -4,7 +4,7 @@ head width 64 / 128, 1-3 layers, LayerNorm or RMSNorm + QK-norm, with / without 
 (tests/test_gpu_e2e.py::run_case + check_levels + score_ok): level tokens equal to the oracle's up to its own near-ties, score1 within 2 bf16 ulps (or 1e-3).
 (test infrastructure: uses oracle/.)
 
-    python tests/manual/fuzz_model.py [n_cases = 40] [seed = 0]"""
+    python tests/manual/fuzz_model.py [n_cases = 40] [seed = 0] [--llama]       # --llama: a third of the cases use the Llama family"""
 import os
 import random
 import sys
@@ -16,6 +16,29 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import aigv_assessor_amd as pkg  # noqa: E402
 import test_gpu_e2e as E  # noqa: E402
+
+LLAMA = "--llama" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--llama"]
+
+
+def run_case_llama(cfg, B, T, seed, stage):
+    """run_case of the suite with the state dict under transformers-Llama names (both sides: the oracle restates modeling_llama.py for such a dict)."""
+    from aigv_assessor_amd import synth, weights
+    sd = weights.internlm2_to_llama(synth.make_state_dict(cfg, seed=seed, rich=True), cfg.llm_config)
+    toks = synth.canonical_tokens(cfg, B, T, seed=seed)
+    pv = synth.synthetic_frames(B * T, cfg.image_size, seed=seed)
+    motion = synth.synthetic_motion(B, cfg.motion_dim, seed=seed)
+    flags = torch.ones(B * T, 1, dtype=torch.long)
+    mos = torch.full((B,), 0.5, dtype=torch.bfloat16)
+    ref = E.O.forward_eval(sd, cfg, pv, toks["input_ids"], toks["attention_mask"], flags, toks["labels"], motion, toks["img_context_token_id"], mos=mos, stage=stage,
+                           return_intermediates=True)
+    model = E.make_model(cfg, sd, stage=stage)
+    assert model.llm_arch_name == "LlamaForCausalLM"
+    model.img_context_token_id = toks["img_context_token_id"]
+    out = model(mos=mos, pixel_values=pv, input_ids=toks["input_ids"], attention_mask=toks["attention_mask"], image_flags=flags, labels=toks["labels"], motion_feature=motion)
+    torch.cuda.synchronize()
+    return model, sd, toks, pv, motion, ref, out
+
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -37,12 +60,18 @@ for c in range(n_cases):
     if kw["vit_layers"] >= 2 and rng.random() < 0.3:
         cfg.select_layer = -2
     stage = rng.choice([2, 2, 2, 1])
+    llama = LLAMA and rng.random() < 0.35          # the reference's second LLM family: HF Llama tensor names, re-packed at load (weights.llama_to_internlm2)
+    if llama:
+        cfg.llm_config.architectures = ["LlamaForCausalLM"]
     B, T, seed = rng.randint(1, 3), rng.choice([1, 2, 4, 8]), rng.randint(0, 999)
     if kw["image_size"] == 448:
         T = min(T, 4)
-    tag = f"case {c}: {kw} select_layer {cfg.select_layer} stage {stage} B {B} T {T} seed {seed}"
+    tag = f"case {c}: {'llama ' if llama else ''}{kw} select_layer {cfg.select_layer} stage {stage} B {B} T {T} seed {seed}"
     try:
-        model, sd, toks, pv, motion, ref, out = E.run_case(cfg, B=B, T=T, seed=seed, stage=stage)
+        if llama:
+            model, sd, toks, pv, motion, ref, out = run_case_llama(cfg, B, T, seed, stage)
+        else:
+            model, sd, toks, pv, motion, ref, out = E.run_case(cfg, B=B, T=T, seed=seed, stage=stage)
         # (check_levels without its cap on the NUMBER of near-tie rows - max(1, rows // 10), tuned to the suite's fixed seeds: on random small vocabularies the bf16
         #  logits tie exactly now and then, e.g. three of ten rows; every differing row must still be a near-tie of the oracle's own logits: assert_levels)
         want = ref["label"] != -100
