@@ -25,23 +25,32 @@ if os.environ.get("FUZZ_NO_RETIRE"):      # diagnosis: dropped graphs stay parke
     from aigv_assessor_amd import modeling as _modeling
     _modeling._retire_parked_graphs = lambda *a, **k: 0
 VERBOSE = bool(os.environ.get("FUZZ_VERBOSE"))
+BIG = "--8b" in sys.argv          # InternVL2-8B sizes (weights generated on the device; the eager comparison model is then built once and reused)
+sys.argv = [a for a in sys.argv if a != "--8b"]
 n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-cfg = pkg.tiny(image_size=224, vit_layers=2, llm_layers=2)
+cfg = pkg.internvl2_8b() if BIG else pkg.tiny(image_size=224, vit_layers=2, llm_layers=2)
 S = cfg.image_size
 dev = torch.device("cuda", 0)
-sd = synth.make_state_dict(cfg, seed=5, rich=True)
+sd = synth.make_state_dict(cfg, seed=5, rich=True, **({"device": dev} if BIG else {}))
+print(f"model: InternViT {cfg.vision_config.hidden_size} x {cfg.vision_config.num_hidden_layers}, LLM {cfg.llm_config.hidden_size} x {cfg.llm_config.num_hidden_layers}, {S} px", flush=True)
+_REF = []
 sf_sd = synth.slowfast_state_dict(seed=3)
 modes = dict(precision="bf16", numerics="fp32", trim=True, gemm=-1)
 
 
 def make(graph):
+    if BIG and not graph and _REF:            # the eager comparison model: one for the whole run at these sizes (still eager, still without captured graphs)
+        apply_modes(_REF[0])
+        return _REF[0]
     m = InternVLChatModel(cfg, device=dev, max_clips=1)
     m.load_state_dict(sd)
     m.eval()
     m.slowfast_model = SlowFastR50(sf_sd)
     apply_modes(m)
     m.enable_graph_replay(graph)
+    if BIG and not graph:
+        _REF.append(m)
     return m
 
 

@@ -3,7 +3,7 @@ frames per clip), decoded-frame sizes, ragged prompt lengths, uint8 frames and n
 off, graph replay on / off, model contexts smaller than k (the context grows), stage 1 and stage 2, the native SlowFast branch or a precomputed motion feature.  Every yielded
 (score1, logit, label, loss) must equal the plain loop's bit for bit, in the stream's order.
 
-    python tests/manual/fuzz_batched.py [n_rounds = 40] [seed = 0]"""
+    python tests/manual/fuzz_batched.py [n_rounds = 40] [seed = 0] [--8b]        # --8b: InternVL2-8B sizes, two long-lived models (use ~8 rounds)"""
 import os
 import random
 import sys
@@ -17,14 +17,27 @@ from aigv_assessor_amd import eval_utils, synth  # noqa: E402
 from aigv_assessor_amd.modeling import InternVLChatModel  # noqa: E402
 from aigv_assessor_amd.slowfast import SlowFastR50  # noqa: E402
 
+BIG = "--8b" in sys.argv          # InternVL2-8B sizes: the 256-tile GEMM row plans, split-K tails and the 448 px ingest instead of the tiny model's generic forms; the two
+sys.argv = [a for a in sys.argv if a != "--8b"]      # models (plain / under test) are built once and live through all rounds
 n_rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-cfg = pkg.tiny(image_size=224, vit_layers=2, llm_layers=2)
-sd = synth.make_state_dict(cfg, seed=5, rich=True)
+cfg = pkg.internvl2_8b() if BIG else pkg.tiny(image_size=224, vit_layers=2, llm_layers=2)
+sd = synth.make_state_dict(cfg, seed=5, rich=True, **({"device": torch.device("cuda", 0)} if BIG else {}))
 sf_sd = synth.slowfast_state_dict(seed=3)
+_CACHE = {}
+print(f"model: InternViT {cfg.vision_config.hidden_size} x {cfg.vision_config.num_hidden_layers}, LLM {cfg.llm_config.hidden_size} x {cfg.llm_config.num_hidden_layers}, {cfg.image_size} px", flush=True)
 
 
-def make_model(stage, max_clips, branch):
+def make_model(stage, max_clips, branch, role="dut"):
+    if BIG:                                   # one long-lived model per (role, stage); the motion branch is switched per round
+        m = _CACHE.get((role, stage))
+        if m is None:
+            m = _CACHE[(role, stage)] = InternVLChatModel(cfg, stage=stage, max_clips=1, device=torch.device("cuda", 0))
+            m.load_state_dict(sd)
+            m.eval()
+            m._branch = SlowFastR50(sf_sd)
+        m.slowfast_model = m._branch if branch else None
+        return m
     m = InternVLChatModel(cfg, stage=stage, max_clips=max_clips)
     m.load_state_dict(sd)
     m.eval().cuda()
@@ -77,9 +90,10 @@ for r in range(n_rounds):
     k = rng.randint(1, 6)
     max_clips = rng.choice([1, 2, 4, 6])
     ahead, graph, as_pv = rng.random() < 0.7, rng.random() < 0.6, rng.random() < 0.25
-    n = rng.randint(1, 14)
+    n = rng.randint(1, 8 if BIG else 14)
     items, ctx = make_items(rng, n, branch, g)
-    ref_model = make_model(stage, 1, branch)
+    ref_model = make_model(stage, 1, branch, role="ref")
+    ref_model.enable_graph_replay(False)
     ref_model.img_context_token_id = ctx
     want = plain(ref_model, items, stage)
     model = make_model(stage, max_clips, branch)
