@@ -107,7 +107,7 @@ def op_prefix(m, B, T, seed):
     return [{k: v for k, v in o.items() if torch.is_tensor(v)} for o in outs]
 
 
-def op_generate(m, B, T, n_new, seed, beams=1):
+def op_generate(m, B, T, n_new, seed, beams=1, extra=None):
     toks = synth.canonical_tokens(cfg, B, T, seed=seed)
     ctx = toks["img_context_token_id"]
     m.img_context_token_id = ctx
@@ -115,8 +115,18 @@ def op_generate(m, B, T, n_new, seed, beams=1):
     ids = toks["input_ids"][:, :n_prompt].clone()
     for b in range(B):
         ids[b, (ids[b] == ctx).nonzero()[-1]] = 7
-    return m.generate(pixel_values=synth.synthetic_frames(B * T, S, seed=seed).to(dev), input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=n_new, do_sample=False,
-                      **({} if beams == 1 else {"num_beams": beams}))
+    return m.generate(pixel_values=synth.synthetic_frames(B * T, S, seed=seed).to(dev), input_ids=ids, attention_mask=torch.ones_like(ids), max_new_tokens=n_new,
+                      **{"do_sample": False, **({} if beams == 1 else {"num_beams": beams}), **_gen_extra(extra, seed)})
+
+
+def _gen_extra(extra, seed):
+    """Sampling (a fresh seeded device generator per call: the same draws on both sides when the logits are the same bits), an EOS id, HF's logits processors."""
+    if not extra:
+        return {}
+    kw = dict(extra)
+    if kw.pop("sample", False):
+        kw.update(do_sample=True, generator=torch.Generator(device=dev).manual_seed(1000 + seed))
+    return kw
 
 
 def loop_items(n, T, hw, seed):
@@ -170,7 +180,8 @@ for it in range(n_ops):
     elif r < 0.40:
         name, fn = "prefix", (lambda m, a=(rng.randint(1, 2), T, rng.randint(0, 2)): op_prefix(m, *a))
     elif r < 0.52:
-        name, fn = "generate", (lambda m, a=(rng.randint(1, 3), T, rng.randint(2, 6), rng.randint(0, 2), rng.choice([1, 1, 3])): op_generate(m, *a))
+        name, fn = "generate", (lambda m, a=(rng.randint(1, 3), T, rng.randint(2, 6), rng.randint(0, 2), rng.choice([1, 1, 3])), e=rng.choice([None, None, dict(sample=True, temperature=0.8, top_k=20, top_p=0.9), dict(sample=True),
+            dict(repetition_penalty=1.3, no_repeat_ngram_size=2), dict(eos_token_id=[5, 9, 11, 17, 23, 42, 77, 101, 300, 301, 302, 303])]): op_generate(m, *(a if not (e and e.get("sample")) else a[:4] + (1,)), extra=e))
     elif r < 0.66:
         name, fn = "batched", (lambda m, a=(rng.randint(1, 7), T, rng.choice([(240, 320), (300, 400), (224, 224)]), rng.randint(1, 4), rng.random() < 0.7, rng.randint(0, 2)): op_batched(m, *a))
     elif r < 0.74:
