@@ -727,6 +727,7 @@ class InternVLChatModel(nn.Module):
     _graph_replay_enabled = False
     _capture_keep = None
     GRAPH_CACHE_SIZE = 8
+    PARKED_GRAPHS_LIMIT = 384     # dropped graphs kept alive before capturing stops for good (~95 MB each for a 4-clip pass at 8B sizes: ~36 GB)
 
     def enable_graph_replay(self, on: bool = True):
         """``forward`` calls whose HOST-side arguments (token ids, masks, labels, frame flags, options) and tensor shapes repeat - the
@@ -800,6 +801,16 @@ class InternVLChatModel(nn.Module):
             graphs[key] = "seen"
             return None
         if ent == "eager":
+            return None
+        if ent == "seen" and len(_PARKED_GRAPHS) >= self.PARKED_GRAPHS_LIMIT:
+            # dropped graphs cannot be destroyed safely on this stack (_drop_graphs): they are parked, with their memory.  A process that has dropped this many
+            # (hundreds of mode / weight / capacity changes under graph replay) stops capturing instead of running out of device memory: same kernels, same bits, eager
+            if not getattr(InternVLChatModel, "_park_limit_warned", False):
+                InternVLChatModel._park_limit_warned = True
+                import warnings
+                warnings.warn(f"graph replay: {len(_PARKED_GRAPHS)} dropped graphs are parked (they cannot be destroyed safely on this ROCm build); no further pass is "
+                              "captured in this process - the eager path runs the same kernels")
+            graphs[key] = "eager"
             return None
         if ent == "seen":                    # second occurrence: capture, on static copies of the device inputs
             statics = [None if t is None else t.clone() for t in dev_inputs]

@@ -807,6 +807,44 @@ def test_graph_replay_survives_the_motion_branch_retiring_a_native_handle():
         assert same(model(**data[8]), want[8])
 
 
+def test_graph_replay_stops_capturing_when_too_many_dropped_graphs_are_parked():
+    """Dropped graphs cannot be destroyed safely on this stack: they are parked with their memory (modeling._drop_graphs; tests/manual/fuzz_api.py at 8B sizes ran out of
+    device memory after ~50 mode toggles on three models).  Past PARKED_GRAPHS_LIMIT parked graphs a process captures nothing more and says so once; the passes run eager
+    with the same bits."""
+    import warnings
+    from aigv_assessor_amd import modeling
+    from aigv_assessor_amd.modeling import InternVLChatModel
+    cfg = pkg.tiny(image_size=224, vit_layers=1, llm_layers=1)
+    model = InternVLChatModel(cfg, max_clips=1)
+    model.load_state_dict(synth.make_state_dict(cfg, seed=99, rich=True))
+    model.eval().cuda()
+    toks = synth.canonical_tokens(cfg, 1, 2, seed=99)
+    model.img_context_token_id = toks["img_context_token_id"]
+    kw = dict(mos=None, pixel_values=synth.synthetic_frames(2, 224, seed=99).cuda(), input_ids=toks["input_ids"], attention_mask=toks["attention_mask"],
+              image_flags=torch.ones(2, 1, dtype=torch.long), labels=toks["labels"], motion_feature=synth.synthetic_motion(1, cfg.motion_dim, seed=99).cuda())
+    want = model(**kw)["score1"].clone()
+    captured = lambda: sum(isinstance(v, tuple) for v in model._graphs.values())
+    import gc
+    gc.collect()                                     # (dead models of earlier tests park their graphs when they are collected: let that happen now)
+    parked0 = len(modeling._PARKED_GRAPHS)
+    print(f"dropped graphs parked by the tests before this one: {parked0} (process limit {InternVLChatModel.PARKED_GRAPHS_LIMIT})")
+    assert parked0 < InternVLChatModel.PARKED_GRAPHS_LIMIT // 2
+    model.PARKED_GRAPHS_LIMIT = parked0 + 3          # (an instance override: room for three more dropped graphs)
+    modeling.InternVLChatModel._park_limit_warned = False
+    try:
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            for cycle in range(5):
+                model.enable_graph_replay(True)          # (drops - parks - whatever was captured)
+                for _ in range(3):
+                    assert torch.equal(model(**kw)["score1"], want)
+                assert captured() == (1 if cycle < 3 else 0), (cycle, captured(), len(modeling._PARKED_GRAPHS))
+        assert len(modeling._PARKED_GRAPHS) == parked0 + 3
+        assert sum("no further pass is captured" in str(w.message) for w in seen) == 1
+    finally:
+        modeling.InternVLChatModel._park_limit_warned = False
+
+
 def test_a_finalizer_firing_inside_a_capture_is_parked():
     """Round 6: a device-memory release inside a stream capture invalidates the capture, and on ROCm 7.2 that is the end of the process (scripts/capture_hipfree_probe.py).
     The host-side models die in Python's cyclic collector, i.e. at any moment: tests/capture_guard_child.py collects one in the middle of another model's captured pass."""
