@@ -99,8 +99,13 @@ def gather_rows(rows: Sequence, group=None) -> list:
     world = dist.get_world_size(group)
     parts = [None] * world
     dist.all_gather_object(parts, list(rows), group=group)
+    return _interleave(parts)
+
+
+def _interleave(parts: Sequence[Sequence]) -> list:
+    """The inverse of ``shard``: rank r holds items r, r + world, r + 2 world, ... of the set as its 0th, 1st, 2nd, ... row."""
     out = []
-    for i in range(max(len(p) for p in parts)):
+    for i in range(max((len(p) for p in parts), default=0)):
         for p in parts:                                   # item j of the set went to rank j % world as its (j // world)-th
             if i < len(p):
                 out.append(p[i])

@@ -268,3 +268,30 @@ def test_sharded_batched_loop_over_gloo_scores_every_clip_once(world):
         assert [r[4] for r in allrows] == [w[1].float().item() for w in want]
     stats = eval_utils.save_and_evaluate(res[0][2])
     assert set(stats) >= {"acc", "pred_score_srcc", "pred_score_plcc"}
+
+
+def test_shard_and_interleave_are_inverse_for_every_set_size_and_world():
+    """eval_utils.shard / gather_rows' interleave for every (set size 0..40, world 1..9): the shares are disjoint, cover the set, differ in size by at most one, and
+    interleaving the per-rank rows gives the set back in its order - for map-style datasets (Subset) and plain iterables (islice) alike."""
+    from aigv_assessor_amd import eval_utils
+
+    class DS:                                   # map-style: __len__ + __getitem__
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            if not 0 <= i < self.n:
+                raise IndexError(i)
+            return i
+    for world in range(1, 10):
+        for n in range(0, 41):
+            for make in (lambda: DS(n), lambda: iter(range(n))):
+                parts = [[x for x in eval_utils.shard(make(), r, world)] for r in range(world)]
+                assert sorted(x for p in parts for x in p) == list(range(n))
+                assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+                assert eval_utils._interleave(parts) == list(range(n)), (n, world)
+    with pytest.raises(ValueError):
+        eval_utils.shard(range(4), 3, 3)
